@@ -1,0 +1,195 @@
+"""ORACLE restatement of the three optimisation-in-the-loop phases (tests / cpu_baseline only).
+
+Follows third_party_patches/hy3dgen/shapegen/pipelines.py (PL) of the reference:
+  phase A  hand only   PL:1295-1358   (Adam,  eps 1e-4)
+  phase B  object only PL:1361-1453   (AdamW, eps 1e-4)
+  phase C  joint       PL:1455-1601   (AdamW, eps 1e-4)  <- one iteration = one "guidance step"
+with the object mesh as an input (latent2sdf + FlexiCubes, PL:1507-1509, are outside the
+synthetic step): the gradient sink on the object side is `obj_verts`.
+
+Scene dict (all torch CPU tensors):
+  hand_verts (Vh,3)  hand mesh already in MoGe space (mano_mesh_moge, PL:1241), constant
+  hand_faces (Fh,3) int64, obj_verts (Vo,3) Hunyuan space, obj_faces (Fo,3) int64, T_h2m (4,4)
+  J_regressor (16,Vh), kps_2d (21,2), moge_normal (H,W,3), moge_disp (H,W),
+  hand_mask (H,W) bool, obj_mask (H,W) bool, fov (deg), H, W
+Params dict: scale_hand (1,), trans_hand (3,), rot_hand (4,), scale_obj, trans_obj, rot_obj.
+"""
+import torch
+
+from . import ref_ops as R
+
+
+def bce(pred, target):
+    """F.binary_cross_entropy (mean), log clamped at -100."""
+    return torch.nn.functional.binary_cross_entropy(pred, target)
+
+
+def _cam(scene, dtype):
+    return R.Camera(scene["fov"], scene["H"], scene["W"], dtype=dtype)
+
+
+def hand_transform(scene, p):
+    """PL:1483-1486."""
+    Rm = R.quaternion_to_matrix(p["rot_hand"])
+    return R.transform_around_center_w_scale(scene["hand_verts"].to(p["rot_hand"].dtype), Rm, p["trans_hand"], p["scale_hand"])
+
+
+def obj_transform(scene, p, obj_verts):
+    """PL:1520-1526."""
+    moge = R.transform_hunyuan2moge(obj_verts, scene["T_h2m"].to(obj_verts.dtype))
+    Rm = R.quaternion_to_matrix(p["rot_obj"])
+    return R.transform_around_center_w_scale(moge, Rm, p["trans_obj"], p["scale_obj"])
+
+
+def render_all(verts, faces, cam, blur, want_sil):
+    sel = R.rasterize_select(R.world_to_ndc(verts, cam), faces, cam.H, cam.W, blur)
+    rgba, zbuf = R.render_normals(verts, faces, cam, sel)
+    nrm, disp = R.render_normal_and_disparity(rgba, zbuf)
+    sil = R.render_silhouette(verts, faces, cam, sel) if want_sil else None
+    return dict(sel=sel, rgba=rgba, zbuf=zbuf, normal=nrm, disp=disp, sil=sil)
+
+
+def hand_losses(scene, p, cam, blur, want_sil):
+    dt = p["rot_hand"].dtype
+    hv = hand_transform(scene, p)
+    r = render_all(hv, scene["hand_faces"], cam, blur, want_sil)
+    kp3 = R.mano_vert_to_3dkps(hv, scene["J_regressor"])
+    kp2 = R.ndc_to_screen(R.world_to_ndc(kp3, cam), cam.H, cam.W)
+    hm = scene["hand_mask"]
+    out = dict(
+        verts=hv, render=r,
+        kps=torch.nn.functional.mse_loss(kp2, scene["kps_2d"].to(dt)),
+        normal=R.normal_alignment_loss(r["normal"], scene["moge_normal"].to(dt), valid_mask=hm),
+        disp=torch.nn.functional.l1_loss(r["disp"], scene["moge_disp"].to(dt) * hm),
+        trans=(p["trans_hand"] ** 2).mean(),
+    )
+    if want_sil:
+        out["sil"] = bce(r["sil"], hm.to(dt))
+    return out
+
+
+def phase_a_loss(scene, p):
+    """PL:1320-1349."""
+    cam = _cam(scene, p["rot_hand"].dtype)
+    blur = R.blur_radius_from_sigma()
+    h = hand_losses(scene, p, cam, blur, True)
+    total = 1e-2 * h["kps"] + 1 * h["normal"] + 10 * h["disp"] + 1 * h["sil"] + 1e-2 * h["trans"]
+    terms = dict(kps=h["kps"], normal_hand=h["normal"], disp_hand=h["disp"], sil_hand=h["sil"], trans_hand=h["trans"])
+    return total, terms, h
+
+
+def phase_b_loss(scene, p, obj_verts, edges):
+    """PL:1386-1440."""
+    dt = obj_verts.dtype
+    cam = _cam(scene, dt)
+    blur = R.blur_radius_from_sigma()
+    ov = obj_transform(scene, p, obj_verts)
+    r = render_all(ov, scene["obj_faces"], cam, blur, True)
+    om = scene["obj_mask"]
+    terms = dict(
+        edge=R.mesh_edge_loss(ov, edges),
+        normal_obj=R.normal_alignment_loss(r["normal"], scene["moge_normal"].to(dt), valid_mask=om),
+        disp_obj=torch.nn.functional.l1_loss(r["disp"], scene["moge_disp"].to(dt) * om),
+        sil_obj=bce(r["sil"], om.to(dt)),
+        verts_obj=ov.pow(2).mean(),
+        trans_obj=(p["trans_obj"] ** 2).mean(),
+    )
+    total = (1 * terms["edge"] + 10 * terms["normal_obj"] + 10 * terms["disp_obj"] + 100 * terms["sil_obj"]
+             + 1e-3 * terms["verts_obj"] + 1e-2 * terms["trans_obj"])
+    return total, terms, dict(verts=ov, render=r)
+
+
+def phase_c_loss(scene, p, obj_verts, edges, denoise_i=19, num_inference_steps=20, use_intersection=True,
+                 grid_res=64):
+    """PL:1480-1588: one joint guidance step's loss."""
+    dt = obj_verts.dtype
+    cam = _cam(scene, dt)
+    blur = R.blur_radius_from_sigma()
+    h = hand_losses(scene, p, cam, blur, False)
+    hand_loss = 1e-4 * h["kps"] + 10 * h["normal"] + 10 * h["disp"] + 1e-2 * h["trans"]
+    hv = h["verts"]
+    ov = obj_transform(scene, p, obj_verts)
+
+    d_ho, knn_idx = R.knn1(hv, ov)
+    distance_loss = torch.clamp(d_ho - 0.01, min=0).mean()
+
+    Vh = hv.shape[0]
+    hoi_v = torch.cat([hv, ov], dim=0)  # join_meshes_as_scene: hand first (PL:1544)
+    hoi_f = torch.cat([scene["hand_faces"], scene["obj_faces"] + Vh], dim=0)
+    r = render_all(hoi_v, hoi_f, cam, blur, True)
+
+    if use_intersection:
+        n_int = R.intersection_count(hv, scene["hand_faces"], ov, scene["obj_faces"], grid_res)
+        loss_int = torch.tensor(n_int / 1000, dtype=dt)
+    else:
+        n_int = 0
+        loss_int = torch.tensor(0.0, dtype=dt)
+    w_int = 1e-5 if (float(d_ho.detach().mean()) < 0.001 and denoise_i >= num_inference_steps - 3) else 1e-9
+
+    hoi_mask = scene["hand_mask"] | scene["obj_mask"]
+    terms = dict(
+        intersection=loss_int, contact=distance_loss,
+        normal_hoi=R.normal_alignment_loss(r["normal"], scene["moge_normal"].to(dt), valid_mask=hoi_mask),
+        disp_hoi=torch.nn.functional.l1_loss(r["disp"], scene["moge_disp"].to(dt)),
+        sil_hoi=bce(r["sil"], hoi_mask.to(dt)),
+        verts_obj=ov.pow(2).mean(), edge=R.mesh_edge_loss(ov, edges),
+        trans_obj=(p["trans_obj"] ** 2).mean(), hand_loss=hand_loss,
+        kps=h["kps"], normal_hand=h["normal"], disp_hand=h["disp"], trans_hand=h["trans"],
+    )
+    total = (w_int * loss_int + 10 * distance_loss + 10 * terms["normal_hoi"] + 10 * terms["disp_hoi"]
+             + 10 * terms["sil_hoi"] + 1e-3 * terms["verts_obj"] + 1 * terms["edge"] + 1e-3 * terms["trans_obj"]
+             + 1e-3 * hand_loss)
+    aux = dict(hand=h, obj_verts_t=ov, render=r, knn_idx=knn_idx, n_int=n_int, w_int=w_int, hoi_faces=hoi_f)
+    return total, terms, aux
+
+
+PARAM_KEYS = ["scale_hand", "trans_hand", "rot_hand", "scale_obj", "trans_obj", "rot_obj"]
+
+
+def make_params(dtype=torch.float32, **over):
+    """PL:1207-1215 identity start."""
+    p = dict(scale_hand=torch.tensor([1.0]), trans_hand=torch.zeros(3), rot_hand=torch.tensor([1.0, 0, 0, 0]),
+             scale_obj=torch.tensor([1.0]), trans_obj=torch.zeros(3), rot_obj=torch.tensor([1.0, 0, 0, 0]))
+    p.update(over)
+    return {k: v.detach().clone().to(dtype) for k, v in p.items()}
+
+
+def leafify(p, keys):
+    return {k: (v.detach().clone().requires_grad_(True) if k in keys else v.detach().clone()) for k, v in p.items()}
+
+
+class JointStepper:
+    """Drives phase-C iterations with the real torch.optim.AdamW (PL:1478), obj_verts as grad sink."""
+
+    # guid_config.py:21-26
+    PHASE2_HAND_LRS = {"scale": 1e-4, "trans": 1e-4, "rot": 1e-2}
+    OBJ_LRS = {"scale": 5e-2, "trans": 1e-2, "rot": 1e-2}
+
+    def __init__(self, scene, params, denoise_i=19, num_inference_steps=20, grid_res=64):
+        self.scene = scene
+        self.grid_res = grid_res
+        self.p = leafify(params, PARAM_KEYS)
+        self.obj_verts = scene["obj_verts"].detach().clone().requires_grad_(True)
+        self.edges = R.unique_edges(scene["obj_faces"])
+        self.i, self.n = denoise_i, num_inference_steps
+        h, o = self.PHASE2_HAND_LRS, self.OBJ_LRS
+        groups = [
+            {"params": [self.p["scale_hand"]], "lr": h["scale"]}, {"params": [self.p["trans_hand"]], "lr": h["trans"]},
+            {"params": [self.p["rot_hand"]], "lr": h["rot"]}, {"params": [self.p["scale_obj"]], "lr": o["scale"]},
+            {"params": [self.p["trans_obj"]], "lr": o["trans"]}, {"params": [self.p["rot_obj"]], "lr": o["rot"]},
+        ]
+        self.opt = torch.optim.AdamW(groups, eps=1e-4)
+
+    def step(self, update=True):
+        self.opt.zero_grad()
+        self.obj_verts.grad = None
+        total, terms, aux = phase_c_loss(self.scene, self.p, self.obj_verts, self.edges, self.i, self.n,
+                                         grid_res=self.grid_res)
+        if torch.isnan(total):
+            return total, terms, aux, None
+        total.backward()
+        grads = {k: self.p[k].grad.detach().clone() for k in PARAM_KEYS}
+        grads["obj_verts"] = self.obj_verts.grad.detach().clone()
+        if update:
+            self.opt.step()
+        return total.detach(), {k: v.detach() for k, v in terms.items()}, aux, grads

@@ -1,0 +1,246 @@
+"""Generate golden vectors by importing the REFERENCE's own pure-torch/numpy helpers.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+    python tests/golden/make_golden.py
+Writes tests/golden/ref_helpers.npz (+ ref_meta.json).  The un-vendored dependencies of the
+reference (pytorch3d, kaolin, diffusers, trimesh, cv2, ...) are replaced by empty stub modules,
+so only functions whose arithmetic lives in /root/reference itself are exercised (SURVEY.md 8c,
+fixtures F1-F9).  Nothing from the reference is copied: the outputs are data.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, n):
+        return _Anything()
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__getattr__ = lambda n: _Anything  # any other attribute resolves to a dummy class
+    sys.modules[name] = m
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], child, m)
+    return m
+
+
+def install_stubs():
+    for n in ["torchvision", "torchvision.transforms", "trimesh", "diffusers", "diffusers.utils",
+              "diffusers.utils.torch_utils", "skimage", "skimage.measure", "kiui", "kiui.vis", "cv2",
+              "pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.renderer.mesh",
+              "pytorch3d.renderer.mesh.textures", "pytorch3d.renderer.mesh.shader", "pytorch3d.ops",
+              "pytorch3d.renderer.blending", "pytorch3d.io", "pytorch3d.loss", "pytorch3d.transforms",
+              "kaolin", "kaolin.non_commercial", "kaolin.ops", "kaolin.ops.mesh", "kaolin.metrics"]:
+        _stub(n)
+    sys.modules["pytorch3d.renderer.mesh.shader"].ShaderBase = object
+
+    # minimal stand-ins for the diffusers mixins the scheduler subclasses (SCH:23-25)
+    class ConfigMixin:
+        pass
+
+    class SchedulerMixin:
+        pass
+
+    class BaseOutput(dict):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.__dict__.update(kw)
+
+        def __init_subclass__(cls, **kw):
+            pass
+
+    def register_to_config(init):
+        def wrapper(self, *a, **kw):
+            import inspect
+            sig = inspect.signature(init)
+            ba = sig.bind(self, *a, **kw)
+            ba.apply_defaults()
+            cfg = {k: v for k, v in ba.arguments.items() if k != "self"}
+            self.config = types.SimpleNamespace(**cfg)
+            init(self, *a, **kw)
+        return wrapper
+
+    cu = _stub("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    su = _stub("diffusers.schedulers", )
+    _stub("diffusers.schedulers.scheduling_utils", SchedulerMixin=SchedulerMixin)
+    lg = types.SimpleNamespace(get_logger=lambda n: types.SimpleNamespace(warning=print, info=print))
+    sys.modules["diffusers.utils"].BaseOutput = BaseOutput
+    sys.modules["diffusers.utils"].logging = lg
+
+
+def load_reference():
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "third_party"))
+    sys.path.insert(0, os.path.join(REF, "src"))
+    spec = importlib.util.spec_from_file_location(
+        "ref_pipelines", os.path.join(REF, "third_party_patches/hy3dgen/shapegen/pipelines.py"))
+    PL = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(PL)
+    spec = importlib.util.spec_from_file_location(
+        "ref_schedulers", os.path.join(REF, "third_party_patches/hy3dgen/shapegen/schedulers.py"))
+    SCH = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SCH)
+    from utilz.code_utils import get_guidance_params
+    from foho.configs.guid_config import OptimizationConfig
+    return PL, SCH, get_guidance_params, OptimizationConfig
+
+
+class FakeMesh:
+    """Exposes the handful of Meshes methods the reference helpers touch."""
+
+    def __init__(self, verts):
+        self.v = verts
+
+    def verts_padded(self):
+        return self.v.unsqueeze(0)
+
+    def verts_packed(self):
+        return self.v
+
+    def update_padded(self, v):
+        return FakeMesh(v.squeeze(0))
+
+
+class FakeRenderer:
+    def __init__(self, rgba, zbuf):
+        self.rgba, self.z = rgba, zbuf
+        self.rasterizer = lambda mesh: types.SimpleNamespace(zbuf=self.z.clone())
+
+    def __call__(self, mesh):
+        return self.rgba.clone()
+
+
+def main():
+    PL, SCH, get_guidance_params, OptimizationConfig = load_reference()
+    g = torch.Generator().manual_seed(1234)
+    out, meta = {}, {}
+
+    # F1 normal_alignment_loss (PL:178-186)
+    a = torch.randn(1, 16, 16, 3, generator=g)
+    b = torch.randn(1, 16, 16, 3, generator=g)
+    m = torch.rand(1, 16, 16, generator=g) > 0.4
+    out.update(f1_a=a, f1_b=b, f1_mask=m, f1_loss_mask=PL.normal_alignment_loss(a, b, m),
+               f1_loss_nomask=PL.normal_alignment_loss(a, b))
+
+    # F2 intersection losses (PL:204-239)
+    sh = torch.randn(4096, generator=g)
+    so = torch.randn(4096, generator=g)
+    out.update(f2_sdf_hand=sh, f2_sdf_obj=so, f2_honerf=PL.honerf_intersection_loss(sh, so),
+               f2_safe=PL.safe_intersection_loss(sh, so))
+    meta["f2_honerf_requires_grad"] = bool(PL.honerf_intersection_loss(sh.requires_grad_(True), so).requires_grad)
+
+    # F3 dense grid (PL:341-360)
+    xyz, gs, length = PL.generate_dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 5, "ij", 64)
+    out.update(f3_first=xyz[:70], f3_last=xyz[-70:], f3_grid_size=np.array(gs), f3_length=length,
+               f3_shape=np.array(xyz.shape), f3_checksum=np.array([xyz.astype(np.float64).sum(), (xyz.astype(np.float64) ** 2).sum()]))
+    xyz2, _, _ = PL.generate_dense_grid_points(np.array([-0.3, 0.1, -0.7], np.float32), np.array([0.4, 0.35, -0.2], np.float32), 5, "ij", 8)
+    out.update(f3_small=xyz2)
+
+    # F4 render_normal_and_disparity with a fake renderer (PL:272-289)
+    rgba = torch.rand(1, 32, 32, 4, generator=g) * 2 - 0.5
+    hit = torch.rand(1, 32, 32, generator=g) > 0.5
+    rgba[..., 3] = hit.float()
+    rgba[..., :3] = torch.where(hit[..., None], rgba[..., :3], torch.ones_like(rgba[..., :3]))
+    z = torch.where(hit, 0.3 + torch.rand(1, 32, 32, generator=g), torch.full((1, 32, 32), -1.0)).unsqueeze(-1)
+    nn_, dd_ = PL.render_normal_and_disparity(FakeRenderer(rgba, z), None)
+    out.update(f4_rgba=rgba, f4_zbuf=z, f4_normal=nn_, f4_disp=dd_)
+
+    # F5 transforms + keypoints (PL:95-135, PL:242-250)
+    v = torch.randn(778, 3, generator=g) * 0.05
+    T = torch.eye(4)
+    q = torch.randn(4, generator=g)
+    q = q / q.norm()
+    r, i, j, k = q.tolist()
+    T[:3, :3] = torch.tensor([[1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r)],
+                              [2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r)],
+                              [2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)]])
+    T[:3, 3] = torch.randn(3, generator=g) * 0.1
+    scale = torch.tensor([1.3])
+    jr = torch.rand(16, 778, generator=g)
+    jr = jr / jr.sum(1, keepdim=True)
+    out.update(f5_verts=v, f5_T=T, f5_scale=scale, f5_jreg=jr,
+               f5_center=PL.transform_mesh_around_center(FakeMesh(v), T).v,
+               f5_center_scale=PL.transform_mesh_around_center_w_scale(FakeMesh(v), T, scale).v,
+               f5_h2m=PL.transform_hunyuan2moge(FakeMesh(v), T).v,
+               f5_kps=PL.mano_vert_to_3dkps(FakeMesh(v), jr, "cpu"))
+
+    # F6 get_guidance_params (GP:3-83)
+    cfg = OptimizationConfig()
+    noise = torch.randn(1, 8, 4, generator=g).half()
+    base = dict(noise_pred_obj=noise, scale_hand=torch.tensor([1.0]), trans_hand=torch.zeros(3),
+                rotation_hand=torch.tensor([1.0, 0, 0, 0]), device="cpu", phase1_hand_lrs=cfg.phase1_hand_lrs,
+                phase2_hand_lrs=cfg.phase2_hand_lrs, noise_obj_lr1=cfg.noise_obj_lr1, noise_obj_lr2=cfg.noise_obj_lr2,
+                obj_lrs=cfg.obj_lrs, obj_2half_lrs=cfg.obj_2half_lrs, scale_obj=torch.tensor([1.0]),
+                trans_obj=torch.zeros(3), rotation_obj=torch.tensor([1.0, 0, 0, 0]))
+    f6 = {}
+    for phase in (1, 1.5, 2):
+        res = get_guidance_params(phase, **base)
+        groups = res[0]
+        names = ["noise_pred_obj", "scale_hand", "trans_hand", "rotation_hand", "scale_obj", "trans_obj", "rotation_obj"]
+        f6[str(phase)] = dict(
+            lrs=[gp["lr"] for gp in groups], shapes=[list(gp["params"][0].shape) for gp in groups],
+            dtypes=[str(gp["params"][0].dtype) for gp in groups],
+            requires_grad={n: bool(t.requires_grad) for n, t in zip(names, res[1:])},
+            is_same_object={n: bool(t is base[n]) for n, t in zip(names, res[1:])})
+    try:
+        get_guidance_params(3, **base)
+        f6["bad_phase_raises"] = False
+    except ValueError:
+        f6["bad_phase_raises"] = True
+    meta["f6"] = f6
+
+    # F7 OptimizationConfig (CFG:6-32)
+    meta["f7"] = {k: v for k, v in vars(cfg).items()}
+    meta["f7_call_returns_self"] = bool(cfg() is cfg)
+
+    # F8 scheduler (SCH:171-211, 235-318, 411-493) via retrieve_timesteps (PL:363-419)
+    sch = SCH.FlowMatchEulerDiscreteScheduler()
+    sig_in = np.linspace(0, 1, 20)
+    ts, n = PL.retrieve_timesteps(sch, 20, "cpu", sigmas=sig_in)
+    lat = torch.randn(1, 8, 4, generator=g).half()
+    vel = [torch.randn(1, 8, 4, generator=g).half() for _ in range(3)]
+    f8 = dict(f8_timesteps=ts, f8_sigmas=sch.sigmas, f8_lat0=lat, f8_vel=torch.stack(vel))
+    meta["f8_config"] = {k: v for k, v in vars(sch.config).items()}
+    x = lat
+    prevs, finals_before, finals_after = [], [], []
+    for s in range(3):
+        t = ts[s]
+        finals_before.append(sch.step_final(vel[s], t, x))  # what the inner loops see (PL:1391, PL:1507)
+        x = sch.step(vel[s], t, x).prev_sample            # PL:1612
+        prevs.append(x)
+        finals_after.append(sch.step_final(vel[s], t, x))  # the "debug" decode after step (PL:1621)
+    f8.update(f8_prev=torch.stack(prevs), f8_final_before=torch.stack(finals_before), f8_final_after=torch.stack(finals_after))
+    out.update(f8)
+
+    # compute_loss_stable_fp32 (PL:1001-1018)
+    lt = {"a": torch.tensor(1.5), "b": torch.tensor(float("nan")), "c": torch.tensor(0.25, dtype=torch.float16), "d": None}
+    out["f10_stable_sum"] = PL.compute_loss_stable_fp32(lt)
+
+    np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
+                        **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
+    with open(os.path.join(HERE, "ref_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True, default=str)
+    print("wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
