@@ -1,0 +1,317 @@
+// foho_common.h -- device helpers shared by the gfx950 kernels of libfoho_hip.so.
+//
+// Everything here is written for CDNA4: 64-lane wavefronts (hard-coded), LDS atomics, wave
+// ballots.  The translation units are compiled with -ffp-contract=off so that the geometric
+// predicates are plain IEEE-754 binary32 operations in a fixed association order: face indices
+// then agree bit-for-bit with the naive per-pixel algorithm of the reference's rasteriser
+// (pytorch3d rasterize_meshes naive path; reference src/foho/guidance/run.py:95-105).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FOHO_WAVE 64
+#define K_EPS 1e-8f
+
+namespace foho {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of NV floats per thread; result valid in thread 0.  `red` = NV * (blockDim/64) floats of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        float s = wave_sum(v[k]);
+        if (lane_id() == 0) red[k * nw + wave_id()] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            float s = 0.f;
+            for (int w = 0; w < nw; w++) s += red[k * nw + w];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// (value, index) arg-min / arg-max; ties keep the lower index (torch.min(dim) on CPU returns the first)
+struct ValIdx {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ ValIdx vi_max(ValIdx a, ValIdx b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ ValIdx wave_vi_min(ValIdx a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ValIdx b{__shfl_down(a.v, o, 64), __shfl_down(a.i, o, 64)};
+        a = vi_min(a, b);
+    }
+    return a;
+}
+__device__ __forceinline__ ValIdx wave_vi_max(ValIdx a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ValIdx b{__shfl_down(a.v, o, 64), __shfl_down(a.i, o, 64)};
+        a = vi_max(a, b);
+    }
+    return a;
+}
+
+// order-preserving float <-> uint32 (for atomicMin/atomicMax on signed floats)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+
+// ---------------------------------------------------------------- rasteriser primitives
+// pixel index -> NDC of the pixel centre (pytorch3d PixToNonSquareNdc)
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
+    float range = 2.0f;
+    if (S1 > S2) range = ((float)S1 * range) / (float)S2;
+    const float offset = range / 2.0f;
+    return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+__device__ __forceinline__ float seg_d2(float px, float py, float ax, float ay, float bx, float by) {
+    const float bax = bx - ax, bay = by - ay;
+    const float l2 = bax * bax + bay * bay;
+    if (l2 <= K_EPS) {
+        const float dx = px - bx, dy = py - by;
+        return dx * dx + dy * dy;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float qx = ax + t * bax, qy = ay + t * bay;
+    const float dx = qx - px, dy = qy - py;
+    return dx * dx + dy * dy;
+}
+
+struct Frag {
+    float z, sdist, c0, c1, c2;
+};
+
+// One (pixel centre, face) pair of the naive rasteriser with perspective-correct, clipped
+// barycentrics (FoV camera + blur_radius > 0 defaults).  fv = 9 floats (x,y,z)x3.
+__device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf, float yf, float blur_radius,
+                                          float sqrt_blur, Frag& out) {
+    const float x0 = fv[0], y0 = fv[1], z0 = fv[2];
+    const float x1 = fv[3], y1 = fv[4], z1 = fv[5];
+    const float x2 = fv[6], y2 = fv[7], z2 = fv[8];
+    const float zmax = fmaxf(fmaxf(z0, z1), z2);
+    if (zmax < 0.0f) return false;
+    const float xmin = fminf(fminf(x0, x1), x2) - sqrt_blur;
+    const float xmax = fmaxf(fmaxf(x0, x1), x2) + sqrt_blur;
+    const float ymin = fminf(fminf(y0, y1), y2) - sqrt_blur;
+    const float ymax = fmaxf(fmaxf(y0, y1), y2) + sqrt_blur;
+    if (!(xmin <= xf && xf <= xmax && ymin <= yf && yf <= ymax)) return false;
+    const float face_area = edge_fn(x0, y0, x1, y1, x2, y2);
+    if (face_area <= K_EPS && face_area >= -K_EPS) return false;
+
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+    const float a0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
+    const float a1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
+    const float a2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+    const float t0 = a0 * z1 * z2;
+    const float t1 = z0 * a1 * z2;
+    const float t2 = z0 * z1 * a2;
+    const float den = fmaxf(t0 + t1 + t2, K_EPS);
+    const float w0 = t0 / den, w1 = t1 / den, w2 = t2 / den;
+    float c0 = fmaxf(w0, 0.0f), c1 = fmaxf(w1, 0.0f), c2 = fmaxf(w2, 0.0f);
+    const float s = fmaxf(c0 + c1 + c2, 1e-5f);
+    c0 = c0 / s;
+    c1 = c1 / s;
+    c2 = c2 / s;
+    const float pz = c0 * z0 + c1 * z1 + c2 * z2;
+    if (pz < 0.0f) return false;
+    const float d01 = seg_d2(xf, yf, x0, y0, x1, y1);
+    const float d02 = seg_d2(xf, yf, x0, y0, x2, y2);
+    const float d12 = seg_d2(xf, yf, x1, y1, x2, y2);
+    const float dist = fminf(fminf(d01, d02), d12);
+    const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+    if (!inside && dist >= blur_radius) return false;
+    out.z = pz + 0.0f;  // canonicalise -0 -> +0 so the uint ordering of the z key holds
+    out.sdist = inside ? -dist : dist;
+    out.c0 = c0;
+    out.c1 = c1;
+    out.c2 = c2;
+    return true;
+}
+
+// d(seg_d2)/d(a,b) with the projection parameter held constant (envelope; pytorch3d
+// PointLineDistanceBackward).  Accumulates g * d(dist)/d(.) into ga[2], gb[2].
+__device__ __forceinline__ void seg_d2_bwd(float px, float py, float ax, float ay, float bx, float by, float g,
+                                           float* ga, float* gb) {
+    const float bax = bx - ax, bay = by - ay;
+    const float l2 = bax * bax + bay * bay;
+    if (l2 <= K_EPS) {
+        gb[0] += g * 2.0f * (bx - px);
+        gb[1] += g * 2.0f * (by - py);
+        return;
+    }
+    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float dx = (ax + t * bax) - px, dy = (ay + t * bay) - py;
+    ga[0] += g * 2.0f * dx * (1.0f - t);
+    ga[1] += g * 2.0f * dy * (1.0f - t);
+    gb[0] += g * 2.0f * dx * t;
+    gb[1] += g * 2.0f * dy * t;
+}
+
+// Backward of eval_frag for one fragment: inputs dL/dz (g_z), dL/dbary_clip (g_c[3]), dL/dsdist (g_sd);
+// accumulates into gv[9] = dL/d(x0,y0,z0,x1,y1,z1,x2,y2,z2).  
+__device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, float xf, float yf, float g_z,
+                                              const float* g_cin, float g_sd, float* gv) {
+    const float x0 = fv[0], y0 = fv[1], z0 = fv[2];
+    const float x1 = fv[3], y1 = fv[4], z1 = fv[5];
+    const float x2 = fv[6], y2 = fv[7], z2 = fv[8];
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+    const float e0 = edge_fn(xf, yf, x1, y1, x2, y2), e1 = edge_fn(xf, yf, x2, y2, x0, y0),
+                e2 = edge_fn(xf, yf, x0, y0, x1, y1);
+    const float a0 = e0 / area, a1 = e1 / area, a2 = e2 / area;
+    const float t0 = a0 * z1 * z2, t1 = z0 * a1 * z2, t2 = z0 * z1 * a2;
+    const float tsum = t0 + t1 + t2;
+    const float den = fmaxf(tsum, K_EPS);
+    const float w0 = t0 / den, w1 = t1 / den, w2 = t2 / den;
+    const float cp0 = fmaxf(w0, 0.0f), cp1 = fmaxf(w1, 0.0f), cp2 = fmaxf(w2, 0.0f);
+    const float csum = cp0 + cp1 + cp2;
+    const float s = fmaxf(csum, 1e-5f);
+    const float c0 = cp0 / s, c1 = cp1 / s, c2 = cp2 / s;
+    const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
+
+    if (g_z != 0.0f || g_cin[0] != 0.0f || g_cin[1] != 0.0f || g_cin[2] != 0.0f) {
+        // pz = c . z
+        const float gc0 = g_cin[0] + g_z * z0, gc1 = g_cin[1] + g_z * z1, gc2 = g_cin[2] + g_z * z2;
+        float gz0 = g_z * c0, gz1 = g_z * c1, gz2 = g_z * c2;
+        // c = cp / s
+        float gcp0, gcp1, gcp2;
+        if (csum >= 1e-5f) {
+            const float dot = gc0 * c0 + gc1 * c1 + gc2 * c2;
+            gcp0 = (gc0 - dot) / s;
+            gcp1 = (gc1 - dot) / s;
+            gcp2 = (gc2 - dot) / s;
+        } else {
+            gcp0 = gc0 / s;
+            gcp1 = gc1 / s;
+            gcp2 = gc2 / s;
+        }
+        const float gw0 = (w0 >= 0.0f) ? gcp0 : 0.0f, gw1 = (w1 >= 0.0f) ? gcp1 : 0.0f, gw2 = (w2 >= 0.0f) ? gcp2 : 0.0f;
+        // w = t / den
+        float gt0, gt1, gt2;
+        if (tsum >= K_EPS) {
+            const float dot = gw0 * w0 + gw1 * w1 + gw2 * w2;
+            gt0 = (gw0 - dot) / den;
+            gt1 = (gw1 - dot) / den;
+            gt2 = (gw2 - dot) / den;
+        } else {
+            gt0 = gw0 / den;
+            gt1 = gw1 / den;
+            gt2 = gw2 / den;
+        }
+        const float ga0 = gt0 * z1 * z2, ga1 = gt1 * z0 * z2, ga2 = gt2 * z0 * z1;
+        gz1 += gt0 * a0 * z2;
+        gz2 += gt0 * a0 * z1;
+        gz0 += gt1 * a1 * z2;
+        gz2 += gt1 * z0 * a1;
+        gz0 += gt2 * z1 * a2;
+        gz1 += gt2 * z0 * a2;
+        const float ge0 = ga0 / area, ge1 = ga1 / area, ge2 = ga2 / area;
+        const float garea = -(ga0 * a0 + ga1 * a1 + ga2 * a2) / area;
+        // e0 = E(p; v1, v2)
+        gv[3] += ge0 * (yf - y2);
+        gv[4] += ge0 * (x2 - xf);
+        gv[6] += -ge0 * (yf - y1);
+        gv[7] += ge0 * (xf - x1);
+        // e1 = E(p; v2, v0)
+        gv[6] += ge1 * (yf - y0);
+        gv[7] += ge1 * (x0 - xf);
+        gv[0] += -ge1 * (yf - y2);
+        gv[1] += ge1 * (xf - x2);
+        // e2 = E(p; v0, v1)
+        gv[0] += ge2 * (yf - y1);
+        gv[1] += ge2 * (x1 - xf);
+        gv[3] += -ge2 * (yf - y0);
+        gv[4] += ge2 * (xf - x0);
+        // area = E(v2; v0, v1) + eps
+        gv[6] += garea * (y1 - y0);
+        gv[7] += -garea * (x1 - x0);
+        gv[0] += garea * (y2 - y1);
+        gv[1] += garea * (x1 - x2);
+        gv[3] += -garea * (y2 - y0);
+        gv[4] += garea * (x2 - x0);
+        gv[2] += gz0;
+        gv[5] += gz1;
+        gv[8] += gz2;
+    }
+    if (g_sd != 0.0f) {
+        const float gd = inside ? -g_sd : g_sd;
+        const float d01 = seg_d2(xf, yf, x0, y0, x1, y1);
+        const float d02 = seg_d2(xf, yf, x0, y0, x2, y2);
+        const float d12 = seg_d2(xf, yf, x1, y1, x2, y2);
+        if (d01 <= d02 && d01 <= d12)
+            seg_d2_bwd(xf, yf, x0, y0, x1, y1, gd, gv + 0, gv + 3);
+        else if (d02 <= d01 && d02 <= d12)
+            seg_d2_bwd(xf, yf, x0, y0, x2, y2, gd, gv + 0, gv + 6);
+        else
+            seg_d2_bwd(xf, yf, x1, y1, x2, y2, gd, gv + 3, gv + 6);
+    }
+}
+
+// sigmoid in fp32 (torch.sigmoid: 1 / (1 + exp(-x)))
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// quaternion wxyz -> R (row-major 9), pytorch3d quaternion_to_matrix (valid for non-unit q)
+__device__ __forceinline__ void quat_to_mat(const float* q, float* R) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float two_s = 2.0f / (((r * r + i * i) + j * j) + k * k);
+    R[0] = 1.0f - two_s * (j * j + k * k);
+    R[1] = two_s * (i * j - k * r);
+    R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r);
+    R[4] = 1.0f - two_s * (i * i + k * k);
+    R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r);
+    R[7] = two_s * (j * k + i * r);
+    R[8] = 1.0f - two_s * (i * i + j * j);
+}
+
+}  // namespace foho

@@ -1,0 +1,334 @@
+"""Batched guidance-step engine: host side of libfoho_hip.so's foho_step_run.
+
+A `GuidanceBatch` packs B independent images (one guidance loop each; the reference processes them one at a
+time, src/foho/guidance/run.py:208-259) into device buffers owned by PyTorch-ROCm and drives the HIP kernels
+through the C ABI.  PyTorch is only plumbing here: allocation, the current stream, host<->device copies.
+
+Phase recipes follow third_party_patches/hy3dgen/shapegen/pipelines.py (PL) and
+src/foho/configs/guid_config.py (CFG) of the reference:
+  phase "A"  hand only    PL:1320-1349, Adam  (CFG phase1_hand_lrs)
+  phase "B"  object only  PL:1386-1440, AdamW (CFG obj_2half_lrs)
+  phase "C"  joint        PL:1480-1588, AdamW (CFG phase2_hand_lrs + obj_lrs)  <- the "guidance step"
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+PARAM_NAMES = ["scale_hand", "trans_hand", "rot_hand", "scale_obj", "trans_obj", "rot_obj"]
+PARAM_SLICES = {"scale_hand": slice(0, 1), "trans_hand": slice(1, 4), "rot_hand": slice(4, 8),
+                "scale_obj": slice(8, 9), "trans_obj": slice(9, 12), "rot_obj": slice(12, 16)}
+
+
+def fov_focal(fov_deg, aspect=1.0, znear=0.01):
+    """K[0,0], K[1,1] of pytorch3d FoVPerspectiveCameras (RUN:90) in float32 steps."""
+    f32 = np.float32
+    fov = f32(np.pi / 180.0) * f32(fov_deg)
+    tan_half = f32(np.tan(f32(fov / f32(2.0))))
+    max_y = f32(tan_half * f32(znear))
+    min_y = f32(-max_y)
+    max_x = f32(max_y * f32(aspect))
+    min_x = f32(-max_x)
+    k00 = f32(f32(2.0) * f32(znear)) / f32(max_x - min_x)
+    k11 = f32(f32(2.0) * f32(znear)) / f32(max_y - min_y)
+    return float(f32(k00)), float(f32(k11))
+
+
+def blur_radius_from_sigma(sigma=1e-8):
+    """RUN:97: np.log(1/1e-4 - 1) * sigma."""
+    return float(np.float32(np.log(1.0 / 1e-4 - 1.0) * np.float32(sigma)))
+
+
+def unique_edges(faces):
+    """Unique undirected edges (pytorch3d Meshes.edges_packed semantics: sorted (min,max) pairs)."""
+    f = np.asarray(faces, dtype=np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
+    e = np.sort(e, axis=1)
+    return np.unique(e, axis=0)
+
+
+def incidence_csr(faces, n_verts):
+    """vertex -> (face<<2 | corner), ordered corner-major then face (the accumulation order of
+    pytorch3d's three index_add calls in verts_normals_packed)."""
+    f = np.asarray(faces, dtype=np.int64)
+    F = f.shape[0]
+    v = f.T.reshape(-1)                       # corner-major
+    corner = np.repeat(np.arange(3), F)
+    face = np.tile(np.arange(F), 3)
+    order = np.lexsort((face, corner, v))
+    off = np.zeros(n_verts + 1, np.int64)
+    np.add.at(off, v + 1, 1)
+    off = np.cumsum(off)
+    fc = (face[order] << 2) | corner[order]
+    return off.astype(np.int32), fc.astype(np.int32)
+
+
+def neighbour_csr(edges, n_verts):
+    e = np.asarray(edges, dtype=np.int64)
+    src = np.concatenate([e[:, 0], e[:, 1]])
+    dst = np.concatenate([e[:, 1], e[:, 0]])
+    order = np.lexsort((dst, src))
+    off = np.zeros(n_verts + 1, np.int64)
+    np.add.at(off, src + 1, 1)
+    off = np.cumsum(off)
+    return off.astype(np.int32), dst[order].astype(np.int32)
+
+
+class OptimizationConfig:
+    """Same attributes and call-returns-self behaviour as src/foho/configs/guid_config.py:6-32."""
+
+    def __init__(self):
+        self.obj_guidance_scale = 5.0
+        self.batch_size = 1
+        self.optimization_steps_hand = 200
+        self.optimization_steps_joint = 50
+        self.optimization_steps_scale = 100
+        self.num_inference_steps = 20
+        self.guidance_start_step = self.num_inference_steps // 2
+        self.handopt_start_step = self.guidance_start_step - 1
+        self.guidance_end_step = self.num_inference_steps
+        self.phase1_hand_lrs = {"scale": 1e-2, "trans": 1e-2, "rot": 0.5}
+        self.phase2_hand_lrs = {"scale": 1e-4, "trans": 1e-4, "rot": 1e-2}
+        self.obj_2half_lrs = {"scale": 1e-2, "trans": 1e-2, "rot": 1e-2}
+        self.obj_lrs = {"scale": 5e-2, "trans": 1e-2, "rot": 1e-2}
+        self.noise_obj_lr1 = 1e-4
+        self.noise_obj_lr2 = 1e-2
+        self.use_intersection_loss = True
+
+    def __call__(self):
+        return self
+
+
+def _lr16(hand=None, obj=None):
+    lr = [0.0] * 16
+    if hand:
+        lr[0] = hand["scale"]
+        lr[1:4] = [hand["trans"]] * 3
+        lr[4:8] = [hand["rot"]] * 4
+    if obj:
+        lr[8] = obj["scale"]
+        lr[9:12] = [obj["trans"]] * 3
+        lr[12:16] = [obj["rot"]] * 4
+    return lr
+
+
+def phase_cfg(phase, config=None, denoise_i=19, do_update=True, sigma=1e-8, gamma=1e-8):
+    """foho_step_cfg for one inner-loop iteration of phase 'A', 'B' or 'C'."""
+    config = config or OptimizationConfig()
+    c = L.FohoStepCfg()
+    c.sigma, c.gamma = sigma, gamma
+    c.blur_radius = blur_radius_from_sigma(sigma)
+    c.beta1, c.beta2, c.eps = 0.9, 0.999, 1e-4
+    c.contact_margin = 0.01
+    c.w_int_near, c.w_int_far, c.int_gate = 1e-5, 1e-9, 0.001
+    c.do_update = int(do_update)
+    r0, r1 = c.render[0], c.render[1]
+    if phase == "A":      # PL:1343-1349, torch.optim.Adam (PL:1318)
+        r0.face_set, r0.normal_mask, r0.disp_mask, r0.sil_mask = L.FACES_HAND, L.MASK_HAND, L.MASK_HAND, L.MASK_HAND
+        r0.w_normal, r0.w_disp, r0.w_sil = 1.0, 10.0, 1.0
+        c.w_kps, c.w_trans_hand = 1e-2, 1e-2
+        c.weight_decay = 0.0
+        lr = _lr16(hand=config.phase1_hand_lrs)
+        n_renders = 1
+    elif phase == "B":    # PL:1433-1440, torch.optim.AdamW (PL:1384)
+        r0.face_set, r0.normal_mask, r0.disp_mask, r0.sil_mask = L.FACES_OBJ, L.MASK_OBJ, L.MASK_OBJ, L.MASK_OBJ
+        r0.w_normal, r0.w_disp, r0.w_sil = 10.0, 10.0, 100.0
+        c.w_edge, c.w_verts_obj, c.w_trans_obj = 1.0, 1e-3, 1e-2
+        c.weight_decay = 0.01
+        lr = _lr16(obj=config.obj_2half_lrs)
+        n_renders = 1
+    elif phase == "C":    # PL:1499-1504 nested in PL:1578-1588, torch.optim.AdamW (PL:1478)
+        f32 = np.float32
+        r0.face_set, r0.normal_mask, r0.disp_mask, r0.sil_mask = L.FACES_HAND, L.MASK_HAND, L.MASK_HAND, L.MASK_NONE
+        r0.w_normal, r0.w_disp, r0.w_sil = float(f32(1e-3) * f32(10)), float(f32(1e-3) * f32(10)), 0.0
+        r1.face_set, r1.normal_mask, r1.disp_mask, r1.sil_mask = L.FACES_ALL, L.MASK_HOI, L.MASK_NONE, L.MASK_HOI
+        r1.w_normal, r1.w_disp, r1.w_sil = 10.0, 10.0, 10.0
+        c.w_kps = float(f32(1e-3) * f32(1e-4))
+        c.w_trans_hand = float(f32(1e-3) * f32(1e-2))
+        c.w_contact, c.w_verts_obj, c.w_edge, c.w_trans_obj = 10.0, 1e-3, 1.0, 1e-3
+        c.use_intersection = int(bool(config.use_intersection_loss))
+        c.int_gate_step_ok = int(denoise_i >= config.num_inference_steps - 3)
+        c.weight_decay = 0.01
+        lr = _lr16(hand=config.phase2_hand_lrs, obj=config.obj_lrs)
+        n_renders = 2
+    else:
+        raise ValueError(f"Unknown phase {phase}. Expected 'A' (hand only), 'B' (object only) or 'C' (joint).")
+    for i, v in enumerate(lr):
+        c.lr[i] = v
+    return c, n_renders
+
+
+class GuidanceBatch:
+    """Device-resident state of B guidance loops.
+
+    scenes: list of dicts with numpy arrays hand_verts (Vh,3) [MoGe space], hand_faces (Fh,3),
+    obj_verts (Vo,3) [Hunyuan space], obj_faces (Fo,3), T_h2m (4,4), J_regressor (16,778), kps_2d (21,2),
+    moge_normal (H,W,3), moge_disp (H,W), hand_mask (H,W) bool, obj_mask (H,W) bool, fov (deg), H, W.
+    """
+
+    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self.B = B = len(scenes)
+        H, W = int(scenes[0]["H"]), int(scenes[0]["W"])
+        assert all(int(s["H"]) == H and int(s["W"]) == W for s in scenes), "one image size per batch"
+        self.H, self.W = H, W
+        verts, faces, images, edges_all = [], [], [], []
+        v_off = f_off = 0
+        self.meta = []
+        nbr_off_parts, nbr_idx_parts = [], []
+        for s in scenes:
+            hv, ov = np.asarray(s["hand_verts"], np.float32), np.asarray(s["obj_verts"], np.float32)
+            hf, of = np.asarray(s["hand_faces"], np.int64), np.asarray(s["obj_faces"], np.int64)
+            Vh, Vo, Fh, Fo = len(hv), len(ov), len(hf), len(of)
+            verts += [hv, ov]
+            faces += [hf + v_off, of + v_off + Vh]
+            e = unique_edges(of) if Fo else np.zeros((0, 2), np.int64)
+            im = L.FohoImage()
+            im.v_off, im.Vh, im.Vo, im.f_off, im.Fh, im.Fo = v_off, Vh, Vo, f_off, Fh, Fo
+            im.n_edges = len(e)
+            jr = np.asarray(s["J_regressor"], np.float32)
+            im.jcols = jr.shape[1]
+            im.k00, im.k11 = fov_focal(float(s["fov"]))
+            R = np.asarray(s.get("cam_R", np.diag([-1.0, 1.0, -1.0])), np.float32).reshape(-1)  # RUN:84-90
+            T = np.asarray(s.get("cam_T", np.zeros(3)), np.float32)
+            for k in range(9):
+                im.cam_R[k] = float(R[k])
+            for k in range(3):
+                im.cam_T[k] = float(T[k])
+            im.znear, im.zfar = 0.01, 100.0
+            M = np.asarray(s["T_h2m"], np.float32)[:3, :4].reshape(-1)
+            for k in range(12):
+                im.T_h2m[k] = float(M[k])
+            images.append(im)
+            edges_all.append(e + v_off + Vh)
+            self.meta.append(dict(v_off=v_off, Vh=Vh, Vo=Vo, f_off=f_off, Fh=Fh, Fo=Fo, n_edges=len(e)))
+            v_off += Vh + Vo
+            f_off += Fh + Fo
+        self.Vtot, self.Ftot = v_off, f_off
+        verts = np.concatenate(verts, 0)
+        faces = np.concatenate(faces, 0)
+        inc_off, inc_fc = incidence_csr(faces, self.Vtot)
+        edges = np.concatenate(edges_all, 0) if edges_all else np.zeros((0, 2), np.int64)
+        nbr_off, nbr_idx = neighbour_csr(edges, self.Vtot)
+        if len(nbr_idx) == 0:
+            nbr_idx = np.zeros(1, np.int32)
+
+        dev = self.device
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        self.verts_in = t(verts, torch.float32)
+        self.faces = t(faces, torch.int32)
+        self.inc_off, self.inc_fc = t(inc_off, torch.int32), t(inc_fc, torch.int32)
+        self.nbr_off, self.nbr_idx = t(nbr_off, torch.int32), t(nbr_idx, torch.int32)
+        self.J = t(np.asarray(scenes[0]["J_regressor"], np.float32), torch.float32)
+        img_bytes = b"".join(bytes(im) for im in images)
+        self.images = torch.frombuffer(bytearray(img_bytes), dtype=torch.uint8).to(dev)
+        self.tgt_normal = t(np.stack([s["moge_normal"] for s in scenes]), torch.float32)
+        self.tgt_disp = t(np.stack([s["moge_disp"] for s in scenes]), torch.float32)
+        mask = np.stack([(np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1))
+                         for s in scenes])
+        self.mask = t(mask, torch.uint8)
+        self.kps_2d = t(np.stack([s["kps_2d"] for s in scenes]), torch.float32)
+
+        ident = np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32)  # PL:1207-1215: s=1, t=0, q=(1,0,0,0)
+        self.params = t(np.tile(ident, (B, 1)), torch.float32)
+        self.adam_m = torch.zeros(B, 16, device=dev)
+        self.adam_v = torch.zeros(B, 16, device=dev)
+        self.adam_t = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.losses = torch.zeros(B, L.N_LOSS, device=dev)
+        self.grad_params = torch.zeros(B, 16, device=dev)
+        self.grad_verts_in = torch.zeros(self.Vtot, 3, device=dev)
+        self.flags = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        d = L.FohoDims()
+        d.B, d.H, d.W, d.Vtot, d.Ftot = B, H, W, self.Vtot, self.Ftot
+        d.Vmax = max(m["Vh"] + m["Vo"] for m in self.meta)
+        d.Fmax = max(m["Fh"] + m["Fo"] for m in self.meta)
+        d.Vh_max = max(m["Vh"] for m in self.meta)
+        d.Vo_max = max(m["Vo"] for m in self.meta)
+        d.grid_res, d.frac_cap, d.n_renders = grid_res, frac_cap, n_renders
+        self.dims = d
+        self._alloc_workspace()
+
+    # ------------------------------------------------------------------ plumbing
+    def _alloc_workspace(self):
+        nbytes = int(self.lib.foho_step_workspace_bytes(ctypes.byref(self.dims)))
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._desc = None
+
+    def set_n_renders(self, n):
+        if n != self.dims.n_renders:
+            self.dims.n_renders = n
+            self._alloc_workspace()
+
+    def desc(self):
+        if self._desc is None:
+            d = L.FohoStepDesc()
+            d.dims = self.dims
+            for name in ["images", "verts_in", "faces", "inc_off", "inc_fc", "nbr_off", "nbr_idx", "tgt_normal",
+                         "tgt_disp", "mask", "kps_2d", "params", "adam_m", "adam_v", "adam_t", "losses",
+                         "grad_params", "grad_verts_in", "flags", "workspace"]:
+                setattr(d, name, getattr(self, name).data_ptr())
+            d.J_regressor = self.J.data_ptr()
+            d.workspace_bytes = self.workspace.numel()
+            self._desc = d
+        return self._desc
+
+    def region(self, name, dtype, shape=None):
+        """View of a named workspace region (parity tests inspect intermediates through this)."""
+        n = ctypes.c_int64(0)
+        off = self.lib.foho_step_workspace_region(ctypes.byref(self.dims), L.WS_REGIONS.index(name), ctypes.byref(n))
+        assert off >= 0
+        v = self.workspace[off:off + n.value].view(dtype)
+        return v.reshape(shape) if shape is not None else v
+
+    # ------------------------------------------------------------------ state
+    def reset_optimizer(self):
+        """A fresh torch.optim.Adam/AdamW is created at every denoising step (PL:1318, 1384, 1478)."""
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.adam_t.zero_()
+        self.flags.zero_()
+
+    def set_params(self, b, **kw):
+        for k, v in kw.items():
+            self.params[b, PARAM_SLICES[k]] = torch.as_tensor(v, dtype=torch.float32, device=self.device).reshape(-1)
+
+    def get_params(self, b):
+        p = self.params[b].detach().cpu()
+        return {k: p[s].clone() for k, s in PARAM_SLICES.items()}
+
+    def set_obj_verts(self, b, verts):
+        m = self.meta[b]
+        lo = m["v_off"] + m["Vh"]
+        self.verts_in[lo:lo + m["Vo"]] = torch.as_tensor(verts, dtype=torch.float32, device=self.device)
+
+    def grad_obj_verts(self, b):
+        m = self.meta[b]
+        lo = m["v_off"] + m["Vh"]
+        return self.grad_verts_in[lo:lo + m["Vo"]]
+
+    # ------------------------------------------------------------------ the step
+    def step(self, cfg, stages=L.STAGE_ALL, stream=None):
+        """One iteration for every image of the batch; asynchronous on the current stream."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(stages), ctypes.c_void_p(stream)),
+                "foho_step_run")
+
+    def loss_dict(self, b=0):
+        l = self.losses[b].detach().cpu().tolist()
+        return dict(zip(L.LOSS_NAMES, l))
+
+    def raise_on_flags(self):
+        """bit1: fractional-fragment list overflow, bit2: a pixel saw more than K=100 faces -> results would
+        differ from the reference's K=100 silhouette; fail loudly instead."""
+        f = self.flags.detach().cpu().numpy()
+        if (f & 2).any():
+            raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
+        if (f & 4).any():
+            raise L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
+        return f

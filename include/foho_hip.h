@@ -1,0 +1,182 @@
+/*
+ * foho_hip.h -- C ABI of libfoho_hip.so, the MI355X (gfx950) implementation of FollowMyHold's
+ * guidance / alignment hot path.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - The caller owns every buffer (PyTorch-ROCm allocates them); the library allocates no
+ *     persistent device memory.  Scratch comes from a caller-provided workspace whose size is
+ *     queried with foho_step_workspace_bytes().
+ *   - Every launch is asynchronous on the hipStream_t passed as `void* stream`
+ *     (torch.cuda.current_stream().cuda_stream); no implicit device synchronisation.
+ *   - Return 0 on success, a negative foho_status otherwise; foho_last_error() gives a
+ *     thread-local message.  Nothing throws across the ABI.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo;
+ * PL = third_party_patches/hy3dgen/shapegen/pipelines.py, RUN = src/foho/guidance/run.py,
+ * SDF = third_party/utilz/kaolin_sdf_ops.py, ICP = src/foho/alignment/mesh_align.py):
+ *
+ *   foho_step_run            one optimisation iteration of PL:1320-1358 (phase A),
+ *                            PL:1386-1453 (phase B) or PL:1480-1601 (phase C, the "guidance step"):
+ *                            pytorch3d MeshRasterizer/MeshRenderer (RUN:95-116), PhongNormalShader
+ *                            (PL:74-92), render_normal_and_disparity (PL:272-289), loss heads
+ *                            (PL:178-186, 1338-1349, 1421-1440, 1495-1504, 1539-1541, 1567-1588),
+ *                            knn_points (PL:1529-1532), mesh_edge_loss (PL:1575),
+ *                            kaolin_sdf.get_sdf_of_meshes + honerf_intersection_loss
+ *                            (PL:1553-1554, SDF:131-160, PL:231-239), loss.backward() and
+ *                            torch.optim.Adam/AdamW(eps=1e-4).step() (PL:1357-1358, 1452-1453, 1600-1601)
+ *   foho_raster_fwd/_bwd     pytorch3d rasterize_meshes fwd/bwd as called by MeshRasterizer (PL:273-274)
+ *   foho_knn1_fwd            pytorch3d.ops.knn_points(K=1) (PL:1529-1538)
+ *   foho_inside_grid         kaolin.ops.mesh.check_sign on the joint 65^3 grid (SDF:104, SDF:146-157)
+ *   foho_point_mesh_dist     kaolin.metrics.trianglemesh.point_to_mesh_distance (SDF:101)
+ *   foho_lbs_fwd/_bwd        smplx MANOLayer forward (third_party/estimator/hamer/hamer/models/hamer.py:125-130)
+ *   foho_icp_nn              scipy cKDTree.query inside icp() (ICP:111-112)
+ *   foho_icp_procrustes_sums trimesh.registration.procrustes accumulations (ICP:127)
+ */
+#ifndef FOHO_HIP_H
+#define FOHO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FOHO_OK = 0,
+    FOHO_ERR_BAD_ARG = -1,
+    FOHO_ERR_LAUNCH = -2,
+    FOHO_ERR_WORKSPACE = -3
+} foho_status;
+
+const char* foho_last_error(void);
+int foho_version(void);
+
+/* ---- per-image constants (array of B of these lives in DEVICE memory) -------------------- */
+typedef struct {
+    int32_t v_off, Vh, Vo;   /* scene vertices [v_off, v_off+Vh+Vo): hand first, then object   */
+    int32_t f_off, Fh, Fo;   /* scene faces    [f_off, f_off+Fh+Fo): hand first (PL:1544)      */
+    int32_t n_edges;         /* unique undirected edges of the object mesh (mesh_edge_loss)    */
+    int32_t jcols;           /* columns of the joint regressor (778)                           */
+    float k00, k11;          /* FoVPerspectiveCameras K[0,0], K[1,1] (RUN:90)                   */
+    float cam_R[9];          /* row-vector convention: X_view = X_world @ R + T                */
+    float cam_T[3];
+    float znear, zfar;
+    float T_h2m[12];         /* rows of the 3x4 Hunyuan->MoGe transform (PL:1240-1241)          */
+} foho_image;
+
+/* ---- sizes (host) -------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, H, W;
+    int32_t Vtot, Ftot;      /* packed totals over the batch                                     */
+    int32_t Vmax, Fmax;      /* per-image maxima of Vh+Vo and Fh+Fo (grid sizing)                */
+    int32_t Vh_max, Vo_max;  /* per-image maxima of the hand / object vertex counts              */
+    int32_t grid_res;        /* SDF grid resolution (64 -> 65^3 points; PL:1126, SDF:146)        */
+    int32_t frac_cap;        /* capacity of the fractional-coverage fragment list per render     */
+    int32_t n_renders;       /* 1 (phase A/B) or 2 (phase C)                                     */
+} foho_dims;
+
+/* ---- one render = one mesh through renderer + sil_renderer --------------------------------- */
+enum { FOHO_FACES_HAND = 0, FOHO_FACES_OBJ = 1, FOHO_FACES_ALL = 2 };
+enum { FOHO_MASK_NONE = 0, FOHO_MASK_HAND = 1, FOHO_MASK_OBJ = 2, FOHO_MASK_HOI = 3 };
+typedef struct {
+    int32_t face_set;        /* FOHO_FACES_*                                                      */
+    int32_t normal_mask;     /* valid_mask of normal_alignment_loss (FOHO_MASK_*)                 */
+    int32_t disp_mask;       /* mask multiplied into the disparity TARGET (PL:1340; NONE at PL:1568) */
+    int32_t sil_mask;        /* BCE target mask                                                   */
+    float w_normal, w_disp, w_sil;   /* effective weights inside the total loss                   */
+} foho_render_cfg;
+
+/* ---- loss weights / optimiser (host, by value) ---------------------------------------------- */
+typedef struct {
+    foho_render_cfg render[2];
+    float w_kps, w_trans_hand, w_trans_obj, w_verts_obj, w_edge, w_contact;
+    float contact_margin;            /* 0.01 on the squared distance (PL:1539)                    */
+    int32_t use_intersection;        /* CFG use_intersection_loss                                 */
+    float w_int_near, w_int_far;     /* 1e-5 / 1e-9 (PL:1561-1564)                                 */
+    float int_gate;                  /* mean(d^2) < 0.001 (PL:1561)                                */
+    int32_t int_gate_step_ok;        /* i >= num_inference_steps - 3, evaluated by the host        */
+    float sigma, gamma, blur_radius; /* BlendParams / RasterizationSettings (RUN:91-101)           */
+    /* Adam / AdamW over the 16 similarity parameters [s_h t_h(3) q_h(4) s_o t_o(3) q_o(4)]        */
+    float lr[16];                    /* 0 = frozen (phase A freezes the object, phase B the hand) */
+    float beta1, beta2, eps, weight_decay;
+    int32_t do_update;               /* 0: gradients only                                          */
+} foho_step_cfg;
+
+/* ---- buffers of one batched step -------------------------------------------------------------- */
+typedef struct {
+    foho_dims dims;
+    const foho_image* images;        /* device, B entries                                          */
+    /* geometry (device) */
+    const float* verts_in;           /* (Vtot,3): hand part = mano_mesh_moge, object part = Hunyuan space */
+    const int32_t* faces;            /* (Ftot,3) GLOBAL vertex ids                                  */
+    const int32_t* inc_off;          /* (Vtot+1) CSR vertex -> incident (face<<2 | corner)          */
+    const int32_t* inc_fc;           /* (3*Ftot)                                                    */
+    const int32_t* nbr_off;          /* (Vtot+1) CSR vertex -> neighbour vertices over unique edges */
+    const int32_t* nbr_idx;          /* (2*E)                                                        */
+    const float* J_regressor;        /* (16, jcols) shared by the batch                             */
+    /* targets (device) */
+    const float* tgt_normal;         /* (B,H,W,3)  moge_normal (PL:1253)                             */
+    const float* tgt_disp;           /* (B,H,W)    moge_disp   (PL:1254)                             */
+    const uint8_t* mask;             /* (B,H,W)    bit0 = hand mask, bit1 = object mask              */
+    const float* kps_2d;             /* (B,21,2)   hamer_2d_kps (PL:1220)                            */
+    /* state (device, updated in place) */
+    float* params;                   /* (B,16)                                                       */
+    float* adam_m;                   /* (B,16)                                                       */
+    float* adam_v;                   /* (B,16)                                                       */
+    int32_t* adam_t;                 /* (B)   step counters; also hold the sticky NaN-break flag     */
+    /* outputs (device) */
+    float* losses;                   /* (B,FOHO_N_LOSS)                                              */
+    float* grad_params;              /* (B,16)                                                       */
+    float* grad_verts_in;            /* (Vtot,3)  dL/d verts_in (object rows are the autograd sink)  */
+    int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel */
+    void* workspace;
+    size_t workspace_bytes;
+} foho_step_desc;
+
+/* indices into losses[b][*] */
+enum {
+    FOHO_L_TOTAL = 0, FOHO_L_INTERSECTION, FOHO_L_CONTACT, FOHO_L_KPS, FOHO_L_TRANS_HAND, FOHO_L_TRANS_OBJ,
+    FOHO_L_VERTS_OBJ, FOHO_L_EDGE, FOHO_L_NORMAL0, FOHO_L_DISP0, FOHO_L_SIL0, FOHO_L_NORMAL1, FOHO_L_DISP1,
+    FOHO_L_SIL1, FOHO_L_N_INTERSECT, FOHO_L_W_INT, FOHO_L_MEAN_D2, FOHO_N_LOSS = 24
+};
+
+/* stage mask of foho_step_run (tests and profiling run prefixes of the step) */
+enum {
+    FOHO_STAGE_VERTEX = 1, FOHO_STAGE_RASTER = 2, FOHO_STAGE_LOSS = 4, FOHO_STAGE_BACKWARD = 8,
+    FOHO_STAGE_INSIDE = 16, FOHO_STAGE_FINAL = 32, FOHO_STAGE_ALL = 63
+};
+
+/* named workspace regions, for parity tests that inspect intermediates */
+enum {
+    FOHO_WS_WORLD = 0, FOHO_WS_NDC, FOHO_WS_VN, FOHO_WS_P2F, FOHO_WS_ZBUF, FOHO_WS_SDIST, FOHO_WS_PROD,
+    FOHO_WS_KNN_IDX, FOHO_WS_KNN_D2, FOHO_WS_GWORLD, FOHO_WS_FRAC_COUNT, FOHO_WS_STATS, FOHO_WS_PARITY,
+    FOHO_WS_NREGIONS
+};
+
+size_t foho_step_workspace_bytes(const foho_dims* dims);
+/* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
+int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
+int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
+
+/* ---- stand-alone operators (facade level) -------------------------------------------------- */
+/* pytorch3d rasterize_meshes(faces_per_pixel=1) on NDC vertices of ONE mesh.
+ * verts_ndc (V,3) = (x_ndc, y_ndc, z_view); faces (F,3) int32.  Outputs (H,W): pix_to_face int64
+ * (-1 background), zbuf, bary (H,W,3), dists (signed, squared NDC).  sil_prod (H,W) optional:
+ * prod_k(1 - sigmoid(-d_k/sigma)) over every fragment of the pixel (SoftSilhouetteShader alpha = 1 - it). */
+int foho_raster_fwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+                    float blur_radius, float sigma, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
+                    float* sil_prod, int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream);
+size_t foho_raster_workspace_bytes(int32_t V, int32_t F, int32_t H, int32_t W);
+/* backward of the K=1 fragments: grad_verts_ndc (V,3) += d(zbuf,bary,dists)/d verts_ndc */
+int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+                    const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
+                    const float* grad_dists, float* grad_verts_ndc, void* stream);
+/* K=1 nearest neighbour: d2 (N1), idx (N1) int64; ties -> lowest index */
+int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOHO_HIP_H */
