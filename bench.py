@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- guidance-steps/sec of the HIP hot path on MI355X (BASELINE.json metric).
+
+A "step" is one iteration of the reference's joint loop (pipelines.py:1480-1601) for one image: transforms,
+hand render, hand+object render with silhouette, keypoints, nearest-neighbour contact, edge loss, 65^3
+intersection count, all losses, backward and the AdamW update.  Workload at every N: configs[1] of
+BASELINE.json -- one synthetic 512x512 frame per GPU, 778-vertex hand + 10 242-vertex / 20 480-face object
+(image-sharded: rank r owns its own frame, no data-path collective; one RCCL all-reduce of the metrics
+vector at the end of the batch).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (hipEvent-timed on the launch
+stream), `cpu_baseline` the CPU oracle ("port" of the reference path) on a bounded sample of the same
+workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
+
+
+def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
+    """B_step = 206*H*W + 96*(Vh+Vo) + 48*(Fh+Fo) + 12*Fo bytes per guidance step."""
+    return 206 * H * W + 96 * (Vh + Vo) + 48 * (Fh + Fo) + 12 * Fo
+
+
+# Share of B_step that each kernel of the step touches algorithmically (DESIGN.md "Kernels"); per pixel P,
+# per vertex V, per face F, for the two live renders of phase C.
+def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo):
+    P, V, F = H * W, Vh + Vo, Fh + Fo
+    table = {
+        "k_raster": 2 * 16 * P + 36 * (Fh + F) + 12 * V,           # write 16 B/px G-buffer x 2 renders, read face NDC + normals
+        "k_loss": 2 * (16 + 17) * P + 12 * V,                      # read G-buffer + targets (12+4+1 B/px) x 2 renders
+        "k_pix_bwd": 2 * (16 + 17) * P + 48 * (Fh + F) + 12 * V,   # read G-buffer + targets, write 48 B/face x 2 renders
+        "k_bbox": 12 * V,
+        "k_xform": 36 * V,
+        "k_inside_faces": 12 * V + 12 * F,
+        "k_stage2": 48 * V + 60 * F + 12 * Fo,
+        "k_vert_gather": 96 * F + 36 * V,
+        "k_vert_bwd": 72 * V + 12 * F,
+    }
+    return table.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--obj", default="20k", choices=["ico4", "20k", "40k"])
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from followmyhold_amd import engine as E
+    from followmyhold_amd import synthetic
+    from followmyhold_amd import sharding
+
+    H = W = args.size
+    ipg = args.images_per_gpu
+    render_fn = E.hip_render_fn(dev)
+    # image-sharded: global image index = rank * ipg + j (seed per image)
+    scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=rank * ipg + j) for j in range(ipg)]
+    gb = E.GuidanceBatch(scenes, device=dev)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    gb.reset_optimizer()
+
+    graph = None if args.no_graph else gb.capture(cfg)
+    gb.reset_optimizer()
+
+    def run_steps(n):
+        for _ in range(n):
+            if graph is not None:
+                graph.replay()
+            else:
+                gb.step(cfg)
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    # end-of-batch metrics all-reduce (the only collective of the path)
+    metrics = sharding.local_metrics(gb, n_steps=args.steps, wall_ms=dt * 1e3)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        metrics = sharding.all_reduce_metrics(metrics, dist)
+    dt = float(tmax.item())
+    flags = gb.raise_on_flags()
+
+    m0 = gb.meta[0]
+    value = world * ipg * args.steps / dt
+    out = {
+        "metric": "guidance-steps/sec (512x512, 778+20k verts)", "value": value, "unit": "guidance-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
+                               f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
+                   "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
+                   "hip_graph": graph is not None},
+        "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[-2]),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: hipEvents around every launch, averaged over the timed step count
+        acc = {}
+        nprof = max(5, min(args.steps, 20))
+        for _ in range(nprof):
+            for k, v in gb.step_profiled(cfg).items():
+                acc[k] = acc.get(k, 0.0) + v / nprof
+        dom = max((k for k in acc if k != "memset"), key=lambda k: acc[k])
+        kb = kernel_bytes(dom, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
+        bstep = algorithmic_bytes(H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
+        if kb is None:
+            kb = bstep
+        achieved = kb * ipg / (acc[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": acc[dom],
+                           "algorithmic_bytes_per_launch": kb * ipg}
+        out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
+        out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
+        out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
+
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scenes[0], args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, n_steps):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path; the reference itself cannot run without
+    pytorch3d/kaolin) timed on this box's host cores on the SAME scene: 1 warm-up + n_steps joint steps."""
+    import torch
+    from oracle import clib
+    from oracle import step_ref as S
+    sc = {k: (torch.from_numpy(v) if hasattr(v, "dtype") and not isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))  # the oracle stops scaling (and oversubscribes) beyond a few dozen threads
+    torch.set_num_threads(cores)
+    clib.set_threads(cores)
+    st = S.JointStepper(sc, S.make_params(), denoise_i=19)
+    t0 = time.perf_counter()
+    st.step()
+    warm = time.perf_counter() - t0
+    n_steps = max(1, min(n_steps, int(25.0 / max(warm, 1e-3))))  # bound the sample to ~25 s of CPU work
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        st.step()
+    dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "guidance-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} joint steps (after 1 warm-up) of the same 512x512 / 20k-face scene, oracle/step_ref.py "
+                      f"with OpenMP C rasteriser + torch CPU autograd"}
+
+
+if __name__ == "__main__":
+    main()

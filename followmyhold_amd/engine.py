@@ -332,3 +332,68 @@ class GuidanceBatch:
         if (f & 4).any():
             raise L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
         return f
+
+    # ------------------------------------------------------------------ HIP graph + per-kernel timing
+    def capture(self, cfg, steps_per_graph=1):
+        """Capture `steps_per_graph` consecutive iterations into one hipGraph (the step has no host sync:
+        NaN break, intersection-weight gate and Adam state all live on the device)."""
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.step(cfg)  # warm-up launch outside capture (module load)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(steps_per_graph):
+                self.step(cfg)
+        return g
+
+    def step_profiled(self, cfg):
+        """One iteration with a hipEvent after every kernel; returns {kernel name: milliseconds}."""
+        lib = self.lib
+        lib.foho_step_run_profiled.restype = ctypes.c_int
+        lib.foho_kernel_name.restype = ctypes.c_char_p
+        ms = (ctypes.c_float * L.N_KERNELS)()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(lib.foho_step_run_profiled(ctypes.byref(self.desc()), ctypes.byref(cfg), ctypes.c_void_p(stream), ms),
+                "foho_step_run_profiled")
+        return {lib.foho_kernel_name(i).decode(): float(ms[i]) for i in range(L.N_KERNELS)}
+
+
+def hip_render_fn(device="cuda"):
+    """Target-map renderer for synthetic scenes backed by the HIP rasteriser (data generation only):
+    returns render_fn(verts, faces, H, W, fov) -> (normal (H,W,3), disp (H,W), pix_to_face (H,W)) following
+    render_normal_and_disparity (PL:272-289)."""
+
+    def render(verts, faces, H, W, fov):
+        verts = np.asarray(verts, np.float32)
+        faces = np.asarray(faces, np.int64)
+        dummy = dict(obj_verts=verts, obj_faces=faces, hand_verts=np.zeros((0, 3), np.float32),
+                     hand_faces=np.zeros((0, 3), np.int64), T_h2m=np.eye(4, dtype=np.float32),
+                     J_regressor=np.zeros((16, 1), np.float32), kps_2d=np.zeros((21, 2), np.float32),
+                     moge_normal=np.zeros((H, W, 3), np.float32), moge_disp=np.zeros((H, W), np.float32),
+                     hand_mask=np.zeros((H, W), bool), obj_mask=np.zeros((H, W), bool), fov=fov, H=H, W=W)
+        gb = GuidanceBatch([dummy], device=device, n_renders=1, grid_res=2)
+        cfg, _ = phase_cfg("B", do_update=False)
+        gb.step(cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)
+        torch.cuda.synchronize()
+        gb.raise_on_flags()
+        P = H * W
+        p2f = gb.region("p2f", torch.int32, (P,)).long()
+        z = gb.region("zbuf", torch.float32, (P,))
+        sd = gb.region("sdist", torch.float32, (P,))
+        vn = gb.region("vn", torch.float32, (-1, 3))
+        hit = p2f >= 0
+        f = gb.faces.long()[p2f.clamp(min=0)]
+        col = vn[f].sum(1)
+        p = torch.sigmoid(-sd / 1e-8)
+        rgb = torch.where(hit[:, None], (p[:, None] * col + 1e-10) / (p[:, None] + 1e-10), torch.ones_like(col))
+        nn = (rgb - rgb.min()) / (rgb.max() - rgb.min() + 1e-6)
+        nn = torch.where(hit[:, None], nn, torch.zeros_like(nn))
+        depth = torch.where(hit, z, torch.full_like(z, 10.0))
+        disp = 1 / (depth + 1e-6)
+        disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-6)
+        return (nn.reshape(H, W, 3).cpu().numpy(), disp.reshape(H, W).cpu().numpy(), p2f.reshape(H, W).cpu().numpy())
+
+    return render

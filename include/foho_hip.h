@@ -152,13 +152,18 @@ enum {
 enum {
     FOHO_WS_WORLD = 0, FOHO_WS_NDC, FOHO_WS_VN, FOHO_WS_P2F, FOHO_WS_ZBUF, FOHO_WS_SDIST, FOHO_WS_PROD,
     FOHO_WS_KNN_IDX, FOHO_WS_KNN_D2, FOHO_WS_GWORLD, FOHO_WS_FRAC_COUNT, FOHO_WS_STATS, FOHO_WS_PARITY,
-    FOHO_WS_NREGIONS
+    FOHO_WS_BIN_COUNT, FOHO_WS_NREGIONS
 };
 
 size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
 int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
+/* Same as foho_step_run(FOHO_STAGE_ALL) but brackets every launch with hipEvents on `stream`, synchronises
+ * the stream and returns the duration of each kernel in milliseconds (measurement aid for bench.py). */
+#define FOHO_N_KERNELS 14
+int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
+const char* foho_kernel_name(int i);
 
 /* ---- stand-alone operators (facade level) -------------------------------------------------- */
 /* pytorch3d rasterize_meshes(faces_per_pixel=1) on NDC vertices of ONE mesh.

@@ -64,3 +64,7 @@ print("grad obj_verts rel", rel(gv, grads["obj_verts"].numpy()), np.abs(gv).max(
 pa = gb.get_params(0)
 for k in E.PARAM_NAMES:
     print("  after", k, pa[k].numpy(), st.p[k].detach().numpy())
+bc = gb.region("bin_count", torch.int32).cpu().numpy().reshape(2, -1)
+print("bin max", bc.max(1), "nonempty", (bc > 0).sum(1), "sum", bc.sum(1))
+for _ in range(3): prof = gb.step_profiled(cfg)
+print({k: round(v * 1e3, 1) for k, v in prof.items()}, "us; total", round(sum(prof.values()) * 1e3, 1))
