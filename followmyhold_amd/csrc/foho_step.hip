@@ -276,3 +276,4 @@ __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (
 #include "k_inside.inc"
 #include "k_final.inc"
 #include "host.inc"
+#include "ops.inc"

@@ -347,22 +347,27 @@ void foho_oracle_free(void* p) { free(p); }
 /* inside test: +z ray parity with an exact-once shared-edge rule              */
 /* ------------------------------------------------------------------------- */
 
-/* "left of the directed edge i->j" with the edge function always evaluated
+/* "left of the directed edge i->j".  The edge function is always evaluated
  * from the lower-index endpoint so the two faces sharing an edge see exactly
- * negated values; a point exactly on the edge belongs to the face that walks
- * the edge in ascending-index direction. */
+ * negated values.  A point exactly ON the edge line (e == 0) is classified as
+ * the symbolically perturbed point p + (eps, eps^2) would be: the sign of
+ * -(dy) eps + (dx) eps^2 for the directed edge (dx, dy).  The perturbed point is
+ * in general position, so rays through edges AND vertices are counted once. */
 static inline int left_of(const float* V, int32_t i, int32_t j, float px, float py, float* e_out) {
     float e;
     if (i < j) {
         const float ax = V[3 * i], ay = V[3 * i + 1], bx = V[3 * j], by = V[3 * j + 1];
         e = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-        *e_out = e;
-        return (e > 0.0f) || (e == 0.0f);
     } else {
         const float ax = V[3 * j], ay = V[3 * j + 1], bx = V[3 * i], by = V[3 * i + 1];
-        e = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-        *e_out = -e;
-        return (e < 0.0f);
+        e = -((bx - ax) * (py - ay) - (by - ay) * (px - ax));
+    }
+    *e_out = e;
+    if (e > 0.0f) return 1;
+    if (e < 0.0f) return 0;
+    {
+        const float dx = V[3 * j] - V[3 * i], dy = V[3 * j + 1] - V[3 * i + 1];
+        return (dy < 0.0f) || (dy == 0.0f && dx > 0.0f);
     }
 }
 

@@ -1,0 +1,84 @@
+"""The C-ABI library loads and exports every symbol that include/*.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not fn.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", fn)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)            # strip comments
+        src = re.sub(r"//[^\n]*", "", src)
+        src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+        src = re.sub(r"typedef\s+enum\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+        src = re.sub(r"enum\s*\{.*?\}\s*;", "", src, flags=re.S)
+        for m in re.finditer(r"\b(foho_\w+)\s*\(", src):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from followmyhold_amd import _lib
+    _lib.build()
+    return ctypes.CDLL(_lib.SO_PATH)
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    for must in ["foho_step_run", "foho_step_workspace_bytes", "foho_step_workspace_region", "foho_last_error",
+                 "foho_version", "foho_step_run_profiled"]:
+        assert must in names
+    assert len(names) >= 8
+
+
+def test_every_declared_symbol_is_exported(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in include/*.h but not exported by libfoho_hip.so: {missing}"
+
+
+def test_host_only_queries_work_without_a_gpu(lib):
+    from followmyhold_amd import _lib as L
+    lib.foho_version.restype = ctypes.c_int
+    assert lib.foho_version() >= 100
+    d = L.FohoDims()
+    d.B, d.H, d.W, d.Vtot, d.Ftot, d.Vmax, d.Fmax, d.Vh_max, d.Vo_max = 2, 512, 512, 22040, 44064, 11020, 22032, 778, 10242
+    d.grid_res, d.frac_cap, d.n_renders = 64, 1 << 18, 2
+    lib.foho_step_workspace_bytes.restype = ctypes.c_size_t
+    n = lib.foho_step_workspace_bytes(ctypes.byref(d))
+    assert 10_000_000 < n < 2_000_000_000
+    lib.foho_step_workspace_region.restype = ctypes.c_int64
+    nb = ctypes.c_int64(0)
+    off = lib.foho_step_workspace_region(ctypes.byref(d), L.WS_REGIONS.index("p2f"), ctypes.byref(nb))
+    assert off >= 0 and nb.value == 2 * 2 * 512 * 512 * 4 and off + nb.value <= n
+    assert lib.foho_step_workspace_region(ctypes.byref(d), 999, ctypes.byref(nb)) == -1
+    # argument validation happens before any launch
+    lib.foho_step_run.restype = ctypes.c_int
+    assert lib.foho_step_run(None, None, 0, None) == -1
+    lib.foho_last_error.restype = ctypes.c_char_p
+    assert b"null" in lib.foho_last_error()
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors must have the C sizes (4-byte fields, 8-byte pointers, natural alignment)."""
+    from followmyhold_amd import _lib as L
+    assert ctypes.sizeof(L.FohoImage) == 8 * 4 + 2 * 4 + 9 * 4 + 3 * 4 + 2 * 4 + 12 * 4
+    assert ctypes.sizeof(L.FohoDims) == 12 * 4
+    assert ctypes.sizeof(L.FohoRenderCfg) == 7 * 4
+    assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4
+    assert ctypes.sizeof(L.FohoStepDesc) == 48 + 21 * 8 + 8
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from followmyhold_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.FohoError):
+        L.lib()

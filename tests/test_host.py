@@ -1,0 +1,168 @@
+"""Host-side logic on CPU: CSR builders, phase recipes, mesh IO, image sharding and the gloo metrics all-reduce."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from followmyhold_amd import engine as E
+from followmyhold_amd import meshio, sharding, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_incidence_csr_reproduces_index_add_order():
+    v, f = synthetic.icosphere(1)
+    off, fc = E.incidence_csr(f, len(v))
+    assert off[-1] == 3 * len(f)
+    for vi in range(len(v)):
+        ent = fc[off[vi]:off[vi + 1]]
+        keys = [((int(e) & 3), int(e) >> 2) for e in ent]
+        assert keys == sorted(keys)                        # corner-major, then face id
+        for c, fa in keys:
+            assert f[fa, c] == vi
+    # normals accumulated in CSR order == three index_add passes
+    vt = torch.from_numpy(v)
+    fn = torch.cross(vt[f[:, 2]] - vt[f[:, 1]], vt[f[:, 0]] - vt[f[:, 1]], dim=1)
+    ref = torch.zeros_like(vt).index_add(0, torch.from_numpy(f[:, 0]), fn).index_add(0, torch.from_numpy(f[:, 1]), fn) \
+        .index_add(0, torch.from_numpy(f[:, 2]), fn)
+    acc = torch.zeros_like(vt)
+    for vi in range(len(v)):
+        for e in fc[off[vi]:off[vi + 1]]:
+            acc[vi] = acc[vi] + fn[int(e) >> 2]
+    assert torch.equal(acc, ref)
+
+
+def test_neighbour_csr_and_unique_edges():
+    v, f = synthetic.icosphere(2)
+    e = E.unique_edges(f)
+    assert len(e) == 3 * len(f) // 2 and len(v) - len(e) + len(f) == 2   # closed genus-0 surface
+    off, idx = E.neighbour_csr(e, len(v))
+    assert off[-1] == 2 * len(e)
+    deg = np.diff(off)
+    assert deg.min() >= 5 and deg.max() <= 6
+    for a, b in e[:50]:
+        assert b in idx[off[a]:off[a + 1]] and a in idx[off[b]:off[b + 1]]
+
+
+def test_synthetic_meshes_have_the_reference_sizes():
+    hv, hf = synthetic.hand_template()
+    assert hv.shape == (778, 3) and hf.shape == (1552, 3)                 # MANO 1538 + 14 wrist-closing faces
+    assert len(E.unique_edges(hf)) == 2328                                # watertight: E = 3F/2
+    assert synthetic.icosphere(4)[1].shape == (5120, 3)
+    ov, of = synthetic.make_object("20k")
+    assert ov.shape == (10242, 3) and of.shape == (20480, 3)
+    ov, of = synthetic.make_object("40k")
+    assert of.shape[0] == 40320 and len(E.unique_edges(of)) == 3 * 40320 // 2
+    m = synthetic.mano_like_model()
+    assert m["posedirs"].shape == (135, 2334) and m["shapedirs"].shape == (778, 3, 10)
+    assert m["J_regressor"].shape == (16, 778) and np.allclose(m["lbs_weights"].sum(1), 1, atol=1e-5)
+
+
+def test_phase_recipes_match_the_reference_weights():
+    """Effective weights inside the total loss (pipelines.py:1343-1349, 1433-1440, 1499-1504 + 1578-1588)."""
+    a, n = E.phase_cfg("A")
+    assert n == 1 and a.render[0].face_set == E.L.FACES_HAND
+    assert (a.render[0].w_normal, a.render[0].w_disp, a.render[0].w_sil) == (1.0, 10.0, 1.0)
+    assert a.w_kps == pytest.approx(1e-2) and a.w_trans_hand == pytest.approx(1e-2) and a.weight_decay == 0.0
+    assert list(a.lr)[:8] == pytest.approx([1e-2] * 4 + [0.5] * 4) and list(a.lr)[8:] == [0.0] * 8
+    b, n = E.phase_cfg("B")
+    assert n == 1 and b.render[0].face_set == E.L.FACES_OBJ and b.render[0].w_sil == 100.0
+    assert b.w_edge == 1.0 and b.w_verts_obj == pytest.approx(1e-3) and b.w_trans_obj == pytest.approx(1e-2)
+    assert list(b.lr)[:8] == [0.0] * 8 and b.weight_decay == pytest.approx(0.01)
+    c, n = E.phase_cfg("C", denoise_i=16)
+    assert n == 2 and c.int_gate_step_ok == 0 and E.phase_cfg("C", denoise_i=17)[0].int_gate_step_ok == 1
+    assert c.render[0].w_normal == pytest.approx(1e-2) and c.render[0].w_sil == 0.0 and c.render[1].w_sil == 10.0
+    assert c.render[1].disp_mask == E.L.MASK_NONE and c.render[0].disp_mask == E.L.MASK_HAND   # PL:1568 vs PL:1497
+    assert c.w_kps == pytest.approx(1e-7) and c.w_trans_hand == pytest.approx(1e-5) and c.w_contact == 10.0
+    assert list(c.lr) == pytest.approx([1e-4] * 4 + [1e-2] * 4 + [5e-2] + [1e-2] * 7)
+    assert c.eps == pytest.approx(1e-4) and c.blur_radius == pytest.approx(np.log(1 / 1e-4 - 1) * 1e-8, rel=1e-6)
+    with pytest.raises(ValueError):
+        E.phase_cfg("D")
+
+
+def test_meshio_roundtrip(tmp_path):
+    v, f = synthetic.icosphere(1, 0.3)
+    for binary in (True, False):
+        p = str(tmp_path / f"m{int(binary)}.ply")
+        meshio.save_ply(p, v, f, binary=binary)
+        v2, f2 = meshio.load_ply(p)
+        assert np.allclose(v2, v, atol=1e-6) and np.array_equal(f2, f)
+    p = str(tmp_path / "pc.ply")
+    meshio.save_ply(p, v)
+    v2, f2 = meshio.load_ply(p)
+    assert np.array_equal(v2, v) and f2.shape == (0, 3)
+    p = str(tmp_path / "m.obj")
+    meshio.save_obj(p, v, f)
+    v2, f2 = meshio.load_mesh(p)
+    assert np.allclose(v2, v, atol=1e-6) and np.array_equal(f2, f)
+    with pytest.raises(ValueError):
+        meshio.load_mesh(str(tmp_path / "x.glb"))
+
+
+def test_image_sharding_is_a_partition():
+    items = [f"{i}_cropped_hoi_1.png" for i in range(64)]
+    parts = [sharding.shard_images(items, r, 8) for r in range(8)]
+    assert all(len(p) == 8 for p in parts)
+    assert sorted(sum(parts, [])) == sorted(items)
+    assert sharding.shard_images(items, 3, 8)[0] == items[3]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from followmyhold_amd import sharding
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+items = [f"{i}_x_1.png" for i in range(5)]
+mine = sharding.shard_images(items, rank, dist.get_world_size())
+class FakeBatch:   # what GuidanceBatch exposes to local_metrics
+    B = len(mine)
+    losses = torch.arange(len(mine) * 24, dtype=torch.float32).reshape(len(mine), 24) + 100 * rank
+    flags = torch.tensor([rank] * len(mine), dtype=torch.int32)
+vec = sharding.local_metrics(FakeBatch, n_steps=3, wall_ms=10.0 * (rank + 1))
+out = sharding.all_reduce_metrics(vec.clone(), dist)
+if rank == 0:
+    print("RESULT", out.tolist(), flush=True)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_metrics_all_reduce_world_size_2_gloo(tmp_path):
+    """N>1 path on CPU: two processes, gloo, 127.0.0.1 rendezvous; sums must equal the serial computation."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
+    got = eval(line[len("RESULT "):])
+    # serial expectation
+    exp = np.zeros(len(sharding.METRIC_NAMES))
+    for r in range(2):
+        n = len(list(range(5))[r::2])
+        losses = np.arange(n * 24, dtype=np.float64).reshape(n, 24) + 100 * r
+        exp[0] += n
+        exp[1] += 3 * n
+        for j, col in enumerate([0, 1, 2, 3, 7, 8, 9, 11, 12, 13]):
+            exp[2 + j] += losses[:, col].sum()
+        exp[12] += 10.0 * (r + 1)
+        exp[13] += n * (r & 1)
+        exp[14] += n * (1 if (r & 6) else 0)
+    assert np.allclose(got, exp)

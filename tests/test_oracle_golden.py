@@ -1,0 +1,140 @@
+"""Pin the oracle (and the host-side mirrors) to golden vectors produced by the REFERENCE's own helpers.
+
+tests/golden/ref_helpers.npz + ref_meta.json were generated in the build container by
+tests/golden/make_golden.py, which imports /root/reference's pipelines.py / schedulers.py / code_utils.py /
+guid_config.py with stub modules for the un-vendored dependencies (fixtures F1-F9).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "ref_helpers.npz"))
+META = json.load(open(os.path.join(HERE, "golden", "ref_meta.json")))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def test_f1_normal_alignment_loss():
+    a, b, m = t("f1_a"), t("f1_b"), t("f1_mask")
+    assert abs(float(R.normal_alignment_loss(a, b, m)) - float(G["f1_loss_mask"])) < 1e-6
+    assert abs(float(R.normal_alignment_loss(a, b)) - float(G["f1_loss_nomask"])) < 1e-6
+
+
+def test_f2_honerf_intersection_is_a_count_without_gradient():
+    sh, so = t("f2_sdf_hand"), t("f2_sdf_obj")
+    assert float(R.honerf_intersection_loss(sh, so)) == pytest.approx(float(G["f2_honerf"]), abs=0)
+    assert META["f2_honerf_requires_grad"] is False
+    assert not R.honerf_intersection_loss(sh.clone().requires_grad_(True), so).requires_grad
+    # the engine consumes it as count/1000 of points inside both meshes
+    n = int(((sh < 0) & (so < 0)).sum())
+    assert n / 1000 == pytest.approx(float(G["f2_honerf"]))
+
+
+def test_f3_dense_grid_points():
+    xyz = R.dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 64)
+    assert list(xyz.shape) == list(G["f3_shape"])
+    assert np.array_equal(xyz[:70], G["f3_first"]) and np.array_equal(xyz[-70:], G["f3_last"])
+    cs = np.array([xyz.astype(np.float64).sum(), (xyz.astype(np.float64) ** 2).sum()])
+    assert np.allclose(cs, G["f3_checksum"], rtol=0, atol=1e-9)
+    small = R.dense_grid_points(np.array([-0.3, 0.1, -0.7], np.float32), np.array([0.4, 0.35, -0.2], np.float32), 8)
+    assert np.array_equal(small, G["f3_small"])  # x-major order, float64 linspace cast to float32
+
+
+def test_f4_render_normal_and_disparity():
+    rgba, z = t("f4_rgba")[0], t("f4_zbuf")[0, ..., 0]
+    nn, dd = R.render_normal_and_disparity(rgba, z)
+    assert np.abs(nn.numpy() - G["f4_normal"][0]).max() < 1e-6
+    assert np.abs(dd.numpy() - G["f4_disp"][0]).max() < 1e-6
+
+
+def test_f5_transforms_and_keypoints():
+    v, T, s, jr = t("f5_verts"), t("f5_T"), t("f5_scale"), t("f5_jreg")
+    out = R.transform_around_center_w_scale(v, T[:3, :3], T[:3, 3], s)
+    assert np.abs(out.numpy() - G["f5_center_scale"]).max() < 1e-6
+    out1 = R.transform_around_center_w_scale(v, T[:3, :3], T[:3, 3], torch.tensor([1.0]))
+    assert np.abs(out1.numpy() - G["f5_center"]).max() < 1e-6
+    assert np.abs(R.transform_hunyuan2moge(v, T).numpy() - G["f5_h2m"]).max() < 1e-6
+    assert np.abs(R.mano_vert_to_3dkps(v, jr).numpy() - G["f5_kps"]).max() < 1e-6
+
+
+def test_f6_get_guidance_params():
+    from followmyhold_amd.engine import OptimizationConfig
+    from followmyhold_amd.guidance_params import get_guidance_params
+    cfg = OptimizationConfig()
+    names = ["noise_pred_obj", "scale_hand", "trans_hand", "rotation_hand", "scale_obj", "trans_obj", "rotation_obj"]
+    base = dict(noise_pred_obj=torch.randn(1, 8, 4).half(), scale_hand=torch.tensor([1.0]), trans_hand=torch.zeros(3),
+                rotation_hand=torch.tensor([1.0, 0, 0, 0]), device="cpu", phase1_hand_lrs=cfg.phase1_hand_lrs,
+                phase2_hand_lrs=cfg.phase2_hand_lrs, noise_obj_lr1=cfg.noise_obj_lr1, noise_obj_lr2=cfg.noise_obj_lr2,
+                obj_lrs=cfg.obj_lrs, obj_2half_lrs=cfg.obj_2half_lrs, scale_obj=torch.tensor([1.0]),
+                trans_obj=torch.zeros(3), rotation_obj=torch.tensor([1.0, 0, 0, 0]))
+    for phase in (1, 1.5, 2):
+        ref = META["f6"][str(phase)]
+        res = get_guidance_params(phase, **base)
+        groups = res[0]
+        assert [g["lr"] for g in groups] == ref["lrs"]
+        assert [list(g["params"][0].shape) for g in groups] == ref["shapes"]
+        assert [str(g["params"][0].dtype) for g in groups] == ref["dtypes"]
+        for n, tt in zip(names, res[1:]):
+            assert bool(tt.requires_grad) == ref["requires_grad"][n], (phase, n)
+            assert bool(tt is base[n]) == ref["is_same_object"][n], (phase, n)
+    with pytest.raises(ValueError):
+        get_guidance_params(3, **base)
+    assert META["f6"]["bad_phase_raises"] is True
+
+
+def test_f7_optimization_config():
+    from foho.configs import OptimizationConfig
+    cfg = OptimizationConfig()
+    assert {k: v for k, v in vars(cfg).items()} == META["f7"]
+    assert cfg() is cfg and META["f7_call_returns_self"]
+
+
+def test_f8_scheduler_step_and_step_final():
+    from followmyhold_amd.scheduler import FlowMatchEulerDiscreteScheduler, retrieve_timesteps
+    s = FlowMatchEulerDiscreteScheduler()
+    assert vars(s.config) == META["f8_config"]
+    ts, n = retrieve_timesteps(s, 20, "cpu", sigmas=np.linspace(0, 1, 20))
+    assert n == 20 and np.array_equal(ts.numpy(), G["f8_timesteps"]) and np.array_equal(s.sigmas.numpy(), G["f8_sigmas"])
+    x, vel = t("f8_lat0"), t("f8_vel")
+    for k in range(3):
+        before = s.step_final(vel[k], ts[k], x)             # inner loops (pipelines.py:1391, :1507) read sigma_k
+        x = s.step(vel[k], ts[k], x).prev_sample             # pipelines.py:1612
+        after = s.step_final(vel[k], ts[k], x)               # the decode after step (pipelines.py:1621) reads sigma_{k+1}
+        assert np.array_equal(before.numpy(), G["f8_final_before"][k])
+        assert np.array_equal(x.numpy(), G["f8_prev"][k])
+        assert np.array_equal(after.numpy(), G["f8_final_after"][k])
+        assert x.dtype == torch.float16
+    with pytest.raises(ValueError):
+        s.step(vel[0], 3, x)
+
+
+def test_f9_task_list_and_path_contract(tmp_path, monkeypatch):
+    from foho.guidance.run import _load_task_list, derive_paths
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for n in ["12_cropped_hoi_1.png", "3_cropped_hoi_0.png", "7_cropped_hoi_1.png"]:
+        (d / n).write_bytes(b"")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    assert _load_task_list(None, str(d)) == sorted(os.listdir(d))
+    tl = tmp_path / "tasks.json"
+    tl.write_text(json.dumps([["a_1.png"], ["b_1.png", "c_0.png"]]))
+    monkeypatch.setenv("SLURM_ARRAY_TASK_ID", "1")
+    assert _load_task_list(str(tl), str(d)) == ["b_1.png", "c_0.png"]
+    monkeypatch.delenv("SLURM_ARRAY_TASK_ID")
+    assert _load_task_list(str(tl), str(d)) == ["a_1.png"]
+    p = derive_paths("12_cropped_hoi_1.png", "I", "M", "G", "H", "A", "T", "L", "O")
+    assert p["index"] == "12" and p["is_right"] == "1"
+    assert p["cropped_hand_mask_path"] == "M/12_cropped_hand_mask.png"
+    assert p["moge_mesh_path"] == "G/12_cropped_hoi/mesh.glb" and p["moge_fov_path"] == "G/12_cropped_hoi/fov.json"
+    assert p["T_h2m_path"] == "T/12_hoi_mesh.npy" and p["aligned_mano_mesh_path"] == "L/12_hamer_aligned_mano.ply"
+    assert p["hunyuan_hoi_mesh_path"] == "H/12_hoi_mesh.ply" and p["hamer_for_guid_path"] == "A/12_kps_for_guidance.npy"
+    assert p["save_path_obj"] == "O/12_obj.ply" and p["save_path_hand"] == "O/12_hand.ply"
