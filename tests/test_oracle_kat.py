@@ -126,7 +126,8 @@ def test_k7_inside_count_of_cube_and_sphere():
     # finer grid: the inside fraction approaches the analytic volume fraction of the ball in the cube
     fine = R.dense_grid_points(np.array([-1.0] * 3, np.float32), np.array([1.0] * 3, np.float32), 48)
     frac = clib.inside(sv, sf.astype(np.int32), fine).mean()
-    assert abs(frac - (4 / 3 * math.pi * 0.7 ** 3) / 8) < 0.01
+    assert abs(frac - (np.linalg.norm(fine, axis=1) < 0.7).mean()) < 0.004      # lattice count of the analytic ball
+    assert abs(frac - (4 / 3 * math.pi * 0.7 ** 3) / 8) < 0.02                   # ~ volume fraction
     # winding independence: the flipped mesh is the same solid
     assert np.array_equal(clib.inside(sv, sf[:, ::-1].astype(np.int32).copy(), grid), ins)
 
