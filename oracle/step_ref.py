@@ -193,3 +193,44 @@ class JointStepper:
         if update:
             self.opt.step()
         return total.detach(), {k: v.detach() for k, v in terms.items()}, aux, grads
+
+
+class PhaseStepper:
+    """Phase A (hand only, torch.optim.Adam, PL:1318) or phase B (object only, torch.optim.AdamW, PL:1384)."""
+
+    PHASE1_HAND_LRS = {"scale": 1e-2, "trans": 1e-2, "rot": 0.5}      # guid_config.py:21
+    OBJ_2HALF_LRS = {"scale": 1e-2, "trans": 1e-2, "rot": 1e-2}       # guid_config.py:23
+
+    def __init__(self, phase, scene, params):
+        assert phase in ("A", "B")
+        self.phase, self.scene = phase, scene
+        self.p = leafify(params, PARAM_KEYS)
+        self.obj_verts = scene["obj_verts"].detach().clone().requires_grad_(phase == "B")
+        self.edges = R.unique_edges(scene["obj_faces"])
+        if phase == "A":
+            l = self.PHASE1_HAND_LRS
+            groups = [{"params": [self.p["scale_hand"]], "lr": l["scale"]}, {"params": [self.p["trans_hand"]], "lr": l["trans"]},
+                      {"params": [self.p["rot_hand"]], "lr": l["rot"]}]
+            self.opt = torch.optim.Adam(groups, eps=1e-4)
+        else:
+            l = self.OBJ_2HALF_LRS
+            groups = [{"params": [self.p["scale_obj"]], "lr": l["scale"]}, {"params": [self.p["trans_obj"]], "lr": l["trans"]},
+                      {"params": [self.p["rot_obj"]], "lr": l["rot"]}]
+            self.opt = torch.optim.AdamW(groups, eps=1e-4)
+
+    def step(self, update=True):
+        self.opt.zero_grad()
+        self.obj_verts.grad = None
+        if self.phase == "A":
+            total, terms, aux = phase_a_loss(self.scene, self.p)
+            keys = ["scale_hand", "trans_hand", "rot_hand"]
+        else:
+            total, terms, aux = phase_b_loss(self.scene, self.p, self.obj_verts, self.edges)
+            keys = ["scale_obj", "trans_obj", "rot_obj"]
+        total.backward()
+        grads = {k: self.p[k].grad.detach().clone() for k in keys}
+        if self.phase == "B":
+            grads["obj_verts"] = self.obj_verts.grad.detach().clone()
+        if update:
+            self.opt.step()
+        return total.detach(), {k: v.detach() for k, v in terms.items()}, aux, grads

@@ -122,3 +122,143 @@ def test_losses_and_gradients(small):
     for k in E.PARAM_NAMES:
         ref = small["after"][k].numpy()
         assert np.abs(p_after[k].numpy() - ref).max() <= 2e-6 + RTOL * np.abs(ref).max() * 1e-2, (k, p_after[k], ref)
+
+
+def _perturbed():
+    return S.make_params(
+        scale_hand=torch.tensor([1.02]), trans_hand=torch.tensor([0.004, -0.003, 0.002]),
+        rot_hand=torch.tensor([0.999, 0.02, -0.01, 0.03]), scale_obj=torch.tensor([0.97]),
+        trans_obj=torch.tensor([-0.002, 0.003, 0.001]), rot_obj=torch.tensor([0.998, -0.03, 0.02, 0.01]))
+
+
+@gpu
+@pytest.mark.parametrize("phase", ["A", "B"])
+def test_phase_a_and_b(phase):
+    """Hand-only (Adam) and object-only (AdamW) phases run on the same kernels with other recipes."""
+    from followmyhold_amd import engine as E
+    sc = make_scene("ico2", 64, 64, seed=1)
+    p = _perturbed()
+    st = S.PhaseStepper(phase, sc, p)
+    total, terms, aux, grads = st.step(update=True)
+    gb = E.GuidanceBatch([_np_scene(sc)], grid_res=16, n_renders=1)
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    cfg, nr = E.phase_cfg(phase, do_update=True)
+    assert nr == 1
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    l = gb.loss_dict(0)
+    assert abs(l["total"] - float(total)) <= RTOL * abs(float(total)), (l, {k: float(v) for k, v in terms.items()})
+    sel = aux["render"]["sel"]
+    p2f = gb.region("p2f", torch.int32, (1, 64 * 64)).cpu().numpy()
+    assert np.array_equal(p2f[0], sel["pix_to_face"].reshape(-1))
+    g = gb.grad_params[0].cpu().numpy()
+    for k, gr in grads.items():
+        if k == "obj_verts":
+            assert rel_err(gb.grad_obj_verts(0).cpu().numpy(), gr.numpy()) < 5 * RTOL
+        else:
+            assert rel_err(g[E.PARAM_SLICES[k]], gr.numpy()) < 5 * RTOL, (k, g[E.PARAM_SLICES[k]], gr)
+    after = gb.get_params(0)
+    for k in E.PARAM_NAMES:
+        ref = st.p[k].detach().numpy()
+        assert np.abs(after[k].numpy() - ref).max() <= 2e-6 + 1e-6 * np.abs(ref).max(), (k, after[k], ref)
+
+
+@gpu
+def test_ragged_batch_matches_single_image_runs():
+    """B=2 with different object sizes: every image of a batch gets the result of its own single-image run."""
+    from followmyhold_amd import engine as E
+    scs = [_np_scene(make_scene("ico2", 64, 64, seed=3)), _np_scene(make_scene("ico4", 64, 64, seed=4))]
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    singles = []
+    for s in scs:
+        gb = E.GuidanceBatch([s], grid_res=16)
+        for _ in range(3):
+            gb.step(cfg)
+        torch.cuda.synchronize()
+        singles.append((gb.losses[0].cpu().numpy(), gb.params[0].cpu().numpy(), gb.region("p2f", torch.int32).cpu().numpy()))
+    gb = E.GuidanceBatch(scs, grid_res=16)
+    for _ in range(3):
+        gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    p2f = gb.region("p2f", torch.int32, (2, 2, 64 * 64)).cpu().numpy()
+    for b in range(2):
+        assert np.allclose(gb.losses[b].cpu().numpy(), singles[b][0], rtol=1e-5, atol=1e-7)
+        assert np.allclose(gb.params[b].cpu().numpy(), singles[b][1], rtol=1e-5, atol=1e-7)
+        assert np.array_equal(p2f[:, b].reshape(-1), singles[b][2])
+
+
+@gpu
+def test_short_trajectory_tracks_the_oracle():
+    """5 consecutive AdamW steps (no teacher forcing): losses stay within 1e-3 of the oracle's trajectory."""
+    from followmyhold_amd import engine as E
+    sc = make_scene("ico2", 64, 64, seed=0)
+    st = S.JointStepper(sc, S.make_params(), denoise_i=19, grid_res=16)
+    gb = E.GuidanceBatch([_np_scene(sc)], grid_res=16)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    for k in range(5):
+        total, _, _, _ = st.step(update=True)
+        gb.step(cfg)
+        torch.cuda.synchronize()
+        assert abs(gb.loss_dict(0)["total"] - float(total)) <= 1e-3 * abs(float(total)), k
+
+
+@gpu
+def test_standalone_raster_and_knn_ops():
+    """foho_raster_fwd / foho_raster_bwd / foho_knn1_fwd against the C oracle and torch autograd."""
+    import ctypes
+    from followmyhold_amd import _lib as L
+    from oracle import clib
+    lib = L.lib()
+    H, W = 48, 64                                     # non-square
+    v, f = __import__("followmyhold_amd.synthetic", fromlist=["x"]).icosphere(2, 0.4)
+    vt = torch.from_numpy(v) + torch.tensor([0.05, -0.02, -2.0])
+    cam = R.Camera(50.0, H, W)
+    ndc = R.world_to_ndc(vt, cam).contiguous()
+    blur = R.blur_radius_from_sigma()
+    ref = clib.render_pass(ndc[torch.from_numpy(f)].numpy(), H, W, blur)
+    dv = ndc.cuda()
+    df = torch.from_numpy(f).int().cuda()
+    lib.foho_raster_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.foho_raster_workspace_bytes(len(v), len(f), H, W)
+    ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
+    p2f = torch.empty(H * W, dtype=torch.int64, device="cuda")
+    zb, di, pr = (torch.empty(H * W, device="cuda") for _ in range(3))
+    ba = torch.empty(H * W, 3, device="cuda")
+    ov = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = ctypes.c_void_p
+    L.check(lib.foho_raster_fwd(P(dv.data_ptr()), P(df.data_ptr()), len(v), len(f), H, W, ctypes.c_float(blur),
+                                ctypes.c_float(1e-8), P(p2f.data_ptr()), P(zb.data_ptr()), P(ba.data_ptr()),
+                                P(di.data_ptr()), P(pr.data_ptr()), P(ov.data_ptr()), P(ws.data_ptr()),
+                                ctypes.c_size_t(nws), stream), "foho_raster_fwd")
+    torch.cuda.synchronize()
+    assert np.array_equal(p2f.cpu().numpy(), ref["pix_to_face"].reshape(-1))
+    assert np.array_equal(zb.cpu().numpy(), ref["zbuf"].reshape(-1))
+    assert np.array_equal(ba.cpu().numpy(), ref["bary"].reshape(-1, 3))
+    assert np.array_equal(di.cpu().numpy(), ref["dists"].reshape(-1))
+    # backward vs autograd of the oracle's differentiable re-evaluation
+    gz, gd = torch.randn(H * W), torch.randn(H * W) * 1e3
+    gb_ = torch.randn(H * W, 3)
+    n2 = ndc.clone().requires_grad_(True)
+    hit = (torch.from_numpy(ref["pix_to_face"]).reshape(-1) >= 0).nonzero(as_tuple=True)[0]
+    pz, bary, sd, _ = R.eval_fragments(n2, torch.from_numpy(f), hit, torch.from_numpy(ref["pix_to_face"]).reshape(-1)[hit], H, W)
+    ((pz * gz[hit]).sum() + (bary * gb_[hit]).sum() + (sd * gd[hit]).sum()).backward()
+    gout = torch.zeros(len(v), 3, device="cuda")
+    dgz, dgb, dgd = gz.cuda(), gb_.cuda(), gd.cuda()          # keep the device copies alive across the call
+    L.check(lib.foho_raster_bwd(P(dv.data_ptr()), P(df.data_ptr()), len(v), len(f), H, W, P(p2f.data_ptr()),
+                                P(dgz.data_ptr()), P(dgb.data_ptr()), P(dgd.data_ptr()),
+                                P(gout.data_ptr()), stream), "foho_raster_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(gout.cpu().numpy(), n2.grad.numpy()) < 2e-4
+    # knn
+    a, b = torch.randn(300, 3), torch.randn(1000, 3)
+    d2 = torch.empty(300, device="cuda")
+    idx = torch.empty(300, dtype=torch.int64, device="cuda")
+    da, db = a.cuda(), b.cuda()
+    L.check(lib.foho_knn1_fwd(P(da.data_ptr()), 300, P(db.data_ptr()), 1000, P(d2.data_ptr()),
+                              P(idx.data_ptr()), stream), "foho_knn1_fwd")
+    torch.cuda.synchronize()
+    rd2, ridx = clib.knn1(a.numpy(), b.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.allclose(d2.cpu().numpy(), rd2, rtol=1e-6)
