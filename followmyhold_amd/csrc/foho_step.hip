@@ -277,3 +277,6 @@ __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (
 #include "k_final.inc"
 #include "host.inc"
 #include "ops.inc"
+#include "k_sdf.inc"
+#include "k_lbs.inc"
+#include "k_icp.inc"

@@ -27,11 +27,10 @@
  *                            torch.optim.Adam/AdamW(eps=1e-4).step() (PL:1357-1358, 1452-1453, 1600-1601)
  *   foho_raster_fwd/_bwd     pytorch3d rasterize_meshes fwd/bwd as called by MeshRasterizer (PL:273-274)
  *   foho_knn1_fwd            pytorch3d.ops.knn_points(K=1) (PL:1529-1538)
- *   foho_inside_grid         kaolin.ops.mesh.check_sign on the joint 65^3 grid (SDF:104, SDF:146-157)
+ *   foho_inside_points       kaolin.ops.mesh.check_sign (SDF:104); the joint 65^3 grid variant is fused in foho_step_run
  *   foho_point_mesh_dist     kaolin.metrics.trianglemesh.point_to_mesh_distance (SDF:101)
  *   foho_lbs_fwd/_bwd        smplx MANOLayer forward (third_party/estimator/hamer/hamer/models/hamer.py:125-130)
- *   foho_icp_nn              scipy cKDTree.query inside icp() (ICP:111-112)
- *   foho_icp_procrustes_sums trimesh.registration.procrustes accumulations (ICP:127)
+ *   foho_icp_run             icp() loop: cKDTree.query + trimmed procrustes + scale clip (ICP:104-142)
  */
 #ifndef FOHO_HIP_H
 #define FOHO_HIP_H
@@ -180,6 +179,42 @@ int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int
                     const float* grad_dists, float* grad_verts_ndc, void* stream);
 /* K=1 nearest neighbour: d2 (N1), idx (N1) int64; ties -> lowest index */
 int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
+
+/* kaolin.metrics.trianglemesh.point_to_mesh_distance (SDF:101): exact squared distance of N points to the
+ * closest triangle of ONE mesh and that triangle's index (ties -> lowest index); face_idx may be NULL. */
+int foho_point_mesh_dist(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
+                         float* d2, int64_t* face_idx, void* stream);
+/* kaolin.ops.mesh.check_sign (SDF:104): inside[n] = 1 when pts[n] is inside the closed mesh (+z ray parity,
+ * rays through edges / vertices counted once). */
+int foho_inside_points(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
+                       uint8_t* inside, void* stream);
+
+/* smplx MANOLayer(pose2rot=False) forward (hamer/models/hamer.py:125-130).  Model arrays (device,
+ * float32): v_template (V,3), shapedirs (V,3,10), posedirs (135,3V), J_regressor (16,V), lbs_weights (V,16),
+ * parents (16) int32.  betas (B,10), rot_mats (B,16,3,3) = [global_orient | hand_pose].  Outputs verts (B,V,3),
+ * joints (B,16,3) posed joints (may be NULL).  use_mfma: 1 = pose-blend contraction on the f32 matrix cores,
+ * 0 = per-vertex dot products, -1 = automatic (matrix cores when B >= 16). */
+size_t foho_lbs_workspace_bytes(int32_t B, int32_t V);
+int foho_lbs_fwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
+                 const float* lbs_weights, const int32_t* parents, int32_t V, const float* betas, const float* rot_mats,
+                 int32_t B, int32_t use_mfma, float* verts, float* joints, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* backward of the last foho_lbs_fwd run on the same workspace: grad_verts (B,V,3), grad_joints (B,16,3) or NULL
+ * -> grad_betas (B,10), grad_rot_mats (B,16,3,3) */
+int foho_lbs_bwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
+                 const float* lbs_weights, const int32_t* parents, int32_t V, const float* rot_mats, int32_t B,
+                 const float* grad_verts, const float* grad_joints, float* grad_betas, float* grad_rot_mats,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* icp() of src/foho/alignment/mesh_align.py:56-175 for one start transform on already-sampled point sets
+ * (float64, device): n_iter iterations of nearest neighbour -> drop the n_outliers largest distances ->
+ * trimesh-style procrustes (reflection=False, scale = !fixed_scale) -> T = next @ T -> scale clipped to
+ * [min_scale, max_scale].  T_out (4x4 row-major) is the transform stored with the lowest mean inlier distance,
+ * cost_out that distance, cost_history (n_iter) optional.  Asynchronous: 2 launches per iteration, no host sync. */
+size_t foho_icp_workspace_bytes(int32_t N, int32_t M);
+int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int32_t n_iter, int32_t n_outliers,
+                 int32_t fixed_scale, double min_scale, double max_scale, double* T_out, double* cost_out,
+                 double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""GPU parity of the stand-alone C-ABI operators (SDF pieces, MANO-shaped LBS fwd/bwd, ICP loop) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from followmyhold_amd import synthetic
+from oracle import clib, icp_ref, lbs_ref
+from oracle import ref_ops as R
+
+gpu = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@gpu
+def test_point_mesh_distance_and_inside_points_bit_exact():
+    """kaolin point_to_mesh_distance / check_sign replacements (kaolin_sdf_ops.py:100-104) on a 17^3 grid."""
+    from followmyhold_amd import ops
+    hv, hf = synthetic.hand_template()
+    ov, of = synthetic.make_object("ico2")
+    ov = ov + np.array([0.02, 0.0, 0.01], np.float32)
+    grid = R.joint_grid(torch.from_numpy(hv), torch.from_numpy(ov), 16)
+    for v, f in ((hv, hf), (ov, of)):
+        d2, fi = ops.point_mesh_dist(torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda(), torch.from_numpy(grid).cuda())
+        rd2, rfi = clib.point_mesh_dist(v, f.astype(np.int32), grid)
+        assert np.array_equal(d2.cpu().numpy(), rd2)
+        assert np.array_equal(fi.cpu().numpy(), rfi)
+        ins = ops.inside_points(torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda(), torch.from_numpy(grid).cuda())
+        rins = clib.inside(v, f.astype(np.int32), grid)
+        assert np.array_equal(ins.cpu().numpy(), rins) and rins.sum() > 10
+        # signed distance as get_sdf_of_meshes builds it (kaolin_sdf_ops.py:100-107)
+        sdf = torch.sqrt(d2) * torch.where(ins, -1.0, 1.0)
+        assert np.allclose(sdf.cpu().numpy(), R.mesh_sdf(torch.from_numpy(v), torch.from_numpy(f), grid), rtol=0, atol=0)
+
+
+@gpu
+def test_fused_intersection_count_equals_full_sdf_route():
+    """The step's column-parity count == honerf_intersection_loss over two full SDFs (pipelines.py:231-239)."""
+    from followmyhold_amd import engine as E
+    from followmyhold_amd import ops
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_scene
+    sc = make_scene("ico2", 64, 64, seed=5)
+    gb = E.GuidanceBatch([{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}], grid_res=24)
+    cfg, _ = E.phase_cfg("C", do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    world = gb.region("world", torch.float32, (-1, 3))
+    hv, ov = world[:778], world[778:]
+    grid = torch.from_numpy(R.joint_grid(hv.cpu(), ov.cpu(), 24)).cuda()
+    ih = ops.inside_points(hv, sc["hand_faces"].cuda(), grid)
+    io = ops.inside_points(ov, sc["obj_faces"].cuda(), grid)
+    assert int(gb.loss_dict(0)["n_intersect"]) == int((ih & io).sum().item())
+
+
+@gpu
+@pytest.mark.parametrize("B,use_mfma", [(3, 0), (3, 1), (32, -1)])
+def test_lbs_forward_and_backward(B, use_mfma):
+    """MANO-shaped LBS: forward vs the smplx restatement, backward vs torch autograd (VALU and matrix-core paths)."""
+    from followmyhold_amd import ops
+    m = synthetic.mano_like_model(1)
+    mt = {k: torch.from_numpy(np.asarray(v)) for k, v in m.items()}
+    g = torch.Generator().manual_seed(B)
+    betas = torch.randn(B, 10, generator=g)
+    aa = torch.randn(B, 16, 3, generator=g) * 0.3
+    rot = torch.stack([torch.stack([torch.from_numpy(synthetic.axis_angle_matrix(a.numpy())).float() for a in row]) for row in aa])
+    bt, rt = betas.clone().requires_grad_(True), rot.clone().requires_grad_(True)
+    v_ref, j_ref = lbs_ref.lbs(bt, rt, mt)
+    gv, gj = torch.randn(v_ref.shape, generator=g), torch.randn(j_ref.shape, generator=g)
+    ((v_ref * gv).sum() + (j_ref * gj).sum()).backward()
+
+    model = ops.LbsModel(m)
+    bd, rd = betas.cuda().requires_grad_(True), rot.cuda().requires_grad_(True)
+    verts, joints = ops.lbs(bd, rd, model, use_mfma=use_mfma)
+    assert rel_err(verts.detach().cpu().numpy(), v_ref.detach().numpy()) < 1e-5
+    assert rel_err(joints.detach().cpu().numpy(), j_ref.detach().numpy()) < 1e-5
+    ((verts * gv.cuda()).sum() + (joints * gj.cuda()).sum()).backward()
+    assert rel_err(bd.grad.cpu().numpy(), bt.grad.numpy()) < 1e-4
+    assert rel_err(rd.grad.cpu().numpy(), rt.grad.numpy()) < 1e-4
+    # zero pose + zero betas -> template (K8)
+    z = torch.zeros(1, 10, device="cuda")
+    I = torch.eye(3, device="cuda").expand(1, 16, 3, 3).contiguous()
+    v0, _ = ops.lbs(z, I, model, use_mfma=0)
+    assert np.abs(v0[0].cpu().numpy() - m["v_template"]).max() < 1e-7
+
+
+@gpu
+@pytest.mark.parametrize("N,M,outliers", [(1000, 5000, 0.2), (2500, 4000, 0.0)])
+def test_icp_loop_matches_the_numpy_reference(N, M, outliers):
+    """Coarse-phase sizes of h2m.py:35-54 (1000 x 5000, 20 % trimmed): same transforms as the float64 restatement."""
+    from followmyhold_amd import ops
+    rng = np.random.default_rng(N)
+    ov, of = synthetic.make_object("20k")
+    tgt_all = ov.astype(np.float64) * 3.0
+    tgt = tgt_all[rng.choice(len(tgt_all), M, replace=False)]
+    src0 = tgt_all[rng.choice(len(tgt_all), N, replace=False)] + rng.normal(size=(N, 3)) * 1e-3
+    Mtx = np.eye(4)
+    Mtx[:3, :3] = 0.9 * synthetic.axis_angle_matrix([0.05, -0.08, 0.04])
+    Mtx[:3, 3] = [0.01, -0.015, 0.02]
+    src = icp_ref.transform_points(src0, np.linalg.inv(Mtx))
+    n_out = int(outliers * N)
+    rec = []
+    T_ref, c_ref = icp_ref.icp_points(src, tgt, n_iter=12, outliers=outliers, min_scale=0.7, max_scale=3.0, record=rec)
+    T, c, hist = ops.icp_points(src, tgt, n_iter=12, n_outliers=n_out, min_scale=0.7, max_scale=3.0, return_history=True)
+    assert np.allclose(hist, [r[0] for r in rec], rtol=1e-9, atol=1e-12)
+    assert abs(c - c_ref) <= 1e-9 * abs(c_ref) and np.allclose(T, T_ref, rtol=1e-8, atol=1e-10)
+    # the alignment actually improves
+    assert hist[-1] < 0.5 * hist[0]
