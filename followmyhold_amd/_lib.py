@@ -63,7 +63,7 @@ LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_ob
               "disp0", "sil0", "normal1", "disp1", "sil1", "n_intersect", "w_int", "mean_d2"]
 WS_REGIONS = ["world", "ndc", "vn", "p2f", "zbuf", "sdist", "prod", "knn_idx", "knn_d2", "gworld", "frac_count",
               "stats", "parity", "bin_count"]
-N_KERNELS = 14
+N_KERNELS = 10
 
 
 def build(force=False):

@@ -20,9 +20,11 @@
 //
 // Data layout in HBM: vertices AoS (V,3) f32, faces (F,3) i32 global ids, per-face NDC copy (F,9) f32 and
 // exact pixel box (F,4) i16 written once per step by the face-setup role; G-buffer per render = 4 planes
-// (face id i32, z f32, signed dist f32, silhouette product f32) = 16 B/px.
+// (face id i32, z f32, signed dist f32, silhouette product f32) = 16 B/px, plus the hit face's colour (12 B,
+// touched for hit pixels only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/foho_hip.h"
@@ -63,12 +65,13 @@ static thread_local ProfState* g_prof = nullptr;
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE = 16;              // raster tile edge (px); one 256-thread workgroup per tile
-constexpr int BIN_CAP = 2048;         // face ids per tile bin; an overflowing tile scans the whole face range
+constexpr int TILE = 8;               // raster tile edge (px); one 256-thread workgroup per 8x8 tile
+constexpr int BTILE = 16;             // tile edge of the per-pixel backward pass (one pixel per lane)
+constexpr int BIN_CAP = 1024;         // face ids per tile bin; an overflowing tile scans the whole face range
 constexpr int BIN_MAX_TILES = 64;     // faces touching more tiles than this go to the per-render global list
 constexpr int RQ_CAP = 6144;          // LDS queue of (face slot, pixel) candidates per chunk of 256 faces
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
-constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
+constexpr int LOSS_BLOCKS = 64;       // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per block
@@ -104,12 +107,12 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc, face_box;
-    size_t p2f, zbuf, sdist, prod;
+    size_t p2f, zbuf, sdist, prod, pcol;
     size_t bin_count, bin_list, glob_list;
     size_t frac, frac_count, rstats, loss_part, stats2;
     size_t face_gcol, face_gndc, g_ndc, g_raw, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, parity, int_count, grid_tab;
-    int tiles_x, tiles_y, ntiles;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, parity, int_count, grid_tab, loss_ticket;
+    int tiles_x, tiles_y, ntiles, btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by one memset per step
 };
 
@@ -123,6 +126,8 @@ static WS make_ws(const foho_dims& d) {
     w.tiles_x = (d.W + TILE - 1) / TILE;
     w.tiles_y = (d.H + TILE - 1) / TILE;
     w.ntiles = w.tiles_x * w.tiles_y;
+    w.btiles_x = (d.W + BTILE - 1) / BTILE;
+    w.nbtiles = w.btiles_x * ((d.H + BTILE - 1) / BTILE);
     auto take = [&](size_t bytes) {
         size_t r = o;
         o = al(o + bytes);
@@ -140,6 +145,7 @@ static WS make_ws(const foho_dims& d) {
     w.face_gndc = take(R * (size_t)d.Ftot * 9 * 4);
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
+    w.loss_ticket = take(R * B * 4);
     w.zero_end = o;
     // --- plain scratch ---
     w.world = take(V3);
@@ -152,6 +158,7 @@ static WS make_ws(const foho_dims& d) {
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
     w.prod = take(R * B * P * 4);
+    w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.bin_list = take(R * B * (size_t)w.ntiles * BIN_CAP * 4);
     w.glob_list = take(R * B * (size_t)d.Fmax * 4);
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
@@ -225,7 +232,7 @@ struct Ctx {
     float* face_ndc;
     short4* face_box;
     int32_t* p2f;
-    float *zbuf, *sdist, *prod;
+    float *zbuf, *sdist, *prod, *pcol;
     unsigned* bin_count;
     int32_t *bin_list, *glob_list;
     FracEntry* frac;
@@ -237,8 +244,9 @@ struct Ctx {
     float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part;
     unsigned long long* parity;
     int32_t* int_count;
+    unsigned* loss_ticket;
     float* grid_tab;  // per image: x[G1], y[G1], z[G1] grid coordinates
-    int tiles_x, tiles_y, ntiles;
+    int tiles_x, tiles_y, ntiles, btiles_x;
 };
 
 __device__ __forceinline__ void face_range(const foho_image& im, int face_set, int& f0, int& f1) {
@@ -270,10 +278,10 @@ __device__ __forceinline__ int mesh_argmin(const MeshInfo& mi, int k) { return (
 __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (int)(~(unsigned)(mi.kmax[k] & 0xffffffffull)); }
 
 #include "k_vertex.inc"
+#include "k_inside.inc"
 #include "k_raster.inc"
 #include "k_loss.inc"
 #include "k_backward.inc"
-#include "k_inside.inc"
 #include "k_final.inc"
 #include "host.inc"
 #include "ops.inc"

@@ -160,7 +160,7 @@ int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* n
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
 /* Same as foho_step_run(FOHO_STAGE_ALL) but brackets every launch with hipEvents on `stream`, synchronises
  * the stream and returns the duration of each kernel in milliseconds (measurement aid for bench.py). */
-#define FOHO_N_KERNELS 14
+#define FOHO_N_KERNELS 10
 int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
 const char* foho_kernel_name(int i);
 
