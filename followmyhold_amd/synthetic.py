@@ -67,6 +67,24 @@ def uv_sphere(n_lat, n_lon, radius=1.0):
     return (np.array(verts) * radius).astype(np.float32), np.array(faces, dtype=np.int64)
 
 
+def torus(n_u, n_v, R=1.0, r=0.45):
+    """Closed genus-1 quad-grid surface, every vertex has valence 6: n_u*n_v vertices, 2*n_u*n_v faces."""
+    u = 2 * math.pi * np.arange(n_u) / n_u
+    v = 2 * math.pi * np.arange(n_v) / n_v
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    x = (R + r * np.cos(vv)) * np.cos(uu)
+    y = (R + r * np.cos(vv)) * np.sin(uu)
+    z = r * np.sin(vv)
+    verts = np.stack([x, y, z], -1).reshape(-1, 3)
+    faces = []
+    for i in range(n_u):
+        for j in range(n_v):
+            a, b = i * n_v + j, ((i + 1) % n_u) * n_v + j
+            c, d = i * n_v + (j + 1) % n_v, ((i + 1) % n_u) * n_v + (j + 1) % n_v
+            faces += [[a, b, d], [a, d, c]]
+    return verts.astype(np.float32), np.array(faces, dtype=np.int64)
+
+
 def _split_edges(v, f, n_split, rng):
     """Split n_split edges of a closed manifold mesh (+1 vertex, +2 faces each)."""
     v = [np.asarray(x, dtype=np.float64) for x in v]
@@ -117,7 +135,8 @@ def displaced_sphere(v, f, radius, seed, amp=0.15):
 
 
 def make_object(kind, seed=2):
-    """'ico4' (cfg 1): 2562/5120;  '20k' (cfg 2,3,5): 10242/20480;  '40k' (cfg 4): 20162/40320."""
+    """'ico4' (cfg 1): 2562/5120;  '20k' (cfg 2,3,5): 10242/20480;  '40k' (cfg 4): 20160/40320 (a torus: no
+    high-valence poles, so no pixel sees more than K=100 faces)."""
     if kind == "ico4":
         return icosphere(4, 0.05)
     if kind == "ico2":
@@ -126,8 +145,8 @@ def make_object(kind, seed=2):
         v, f = icosphere(5)
         return displaced_sphere(v, f, 0.05, seed)
     if kind == "40k":
-        v, f = uv_sphere(127, 160)
-        return displaced_sphere(v, f, 0.05, seed)
+        v, f = torus(160, 126)
+        return (v * 0.036).astype(np.float32), f
     raise ValueError(kind)
 
 

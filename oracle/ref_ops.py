@@ -309,7 +309,8 @@ def mano_vert_to_3dkps(verts, J_regressor):
     """PL:121-135."""
     tips = torch.tensor([744, 320, 443, 554, 671], dtype=torch.int64)
     order = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
-    kp = torch.cat([J_regressor.to(verts.dtype) @ verts, verts[tips]], dim=0)
+    # a two-hand scene (BASELINE config 4) stacks both hands; the (16,778) regressor covers the first one
+    kp = torch.cat([J_regressor.to(verts.dtype) @ verts[:J_regressor.shape[1]], verts[tips]], dim=0)
     return kp[order, :]
 
 

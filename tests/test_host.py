@@ -56,7 +56,7 @@ def test_synthetic_meshes_have_the_reference_sizes():
     ov, of = synthetic.make_object("20k")
     assert ov.shape == (10242, 3) and of.shape == (20480, 3)
     ov, of = synthetic.make_object("40k")
-    assert of.shape[0] == 40320 and len(E.unique_edges(of)) == 3 * 40320 // 2
+    assert of.shape[0] == 40320 and ov.shape[0] == 20160 and len(E.unique_edges(of)) == 3 * 40320 // 2
     m = synthetic.mano_like_model()
     assert m["posedirs"].shape == (135, 2334) and m["shapedirs"].shape == (778, 3, 10)
     assert m["J_regressor"].shape == (16, 778) and np.allclose(m["lbs_weights"].sum(1), 1, atol=1e-5)
