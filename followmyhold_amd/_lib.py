@@ -29,7 +29,8 @@ class FohoImage(ctypes.Structure):
 
 class FohoDims(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("Vtot", c_i), ("Ftot", c_i), ("Vmax", c_i), ("Fmax", c_i),
-                ("Vh_max", c_i), ("Vo_max", c_i), ("grid_res", c_i), ("frac_cap", c_i), ("n_renders", c_i)]
+                ("Vh_max", c_i), ("Vo_max", c_i), ("grid_res", c_i), ("frac_cap", c_i), ("n_renders", c_i),
+                ("Fh_max", c_i), ("Fo_max", c_i)]
 
 
 class FohoRenderCfg(ctypes.Structure):
@@ -62,7 +63,7 @@ N_LOSS = 24
 LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_obj", "verts_obj", "edge", "normal0",
               "disp0", "sil0", "normal1", "disp1", "sil1", "n_intersect", "w_int", "mean_d2"]
 WS_REGIONS = ["world", "ndc", "vn", "p2f", "zbuf", "sdist", "prod", "knn_idx", "knn_d2", "gworld", "frac_count",
-              "stats", "parity", "bin_count"]
+              "stats", "parity", "frag_count"]
 N_KERNELS = 10
 
 

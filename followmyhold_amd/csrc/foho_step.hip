@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "../../include/foho_hip.h"
 #include "foho_common.h"
 
@@ -65,11 +67,9 @@ static thread_local ProfState* g_prof = nullptr;
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE = 8;               // raster tile edge (px); one 256-thread workgroup per 8x8 tile
 constexpr int BTILE = 16;             // tile edge of the per-pixel backward pass (one pixel per lane)
-constexpr int BIN_CAP = 1024;         // face ids per tile bin; an overflowing tile scans the whole face range
-constexpr int BIN_MAX_TILES = 64;     // faces touching more tiles than this go to the per-render global list
-constexpr int RQ_CAP = 6144;          // LDS queue of (face slot, pixel) candidates per chunk of 256 faces
+constexpr int RF = 64;                // faces per workgroup of the scatter rasteriser (= one wave for the setup scan)
+constexpr int RQ_CAP = 2048;          // LDS queue of (face slot, pixel) candidates per enumerate round
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
 constexpr int LOSS_BLOCKS = 64;       // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
@@ -91,14 +91,19 @@ struct FracEntry {
     float sdist;
 };
 
-// raw stats accumulated by hit tiles of the rasteriser
-struct RStats {
+// raw stats accumulated by the hit workgroups of k_resolve.  Same-address device-scope atomics serialise at a few
+// ns each, so the accumulators are spread over NSLOT cache lines (workgroup i -> slot i % NSLOT) and k_loss
+// reduces the slots.
+constexpr int NSLOT = 64;
+struct RSlot {
     unsigned hit_count;
     unsigned rgb_min_inv, rgb_max;    // ordered-uint encoded over hit pixels' 3 channels; minima are stored
     unsigned disp_min_inv, disp_max;  // bit-inverted and accumulated with atomicMax so that 0 = "empty"
+    unsigned pad[11];
+};
+struct RStats {
     unsigned flags;                   // bit1 frac overflow, bit2 >K fragments on a pixel
-    unsigned glob_count;              // entries of the global (screen-filling faces) list
-    unsigned pad;
+    unsigned pad[3];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -106,14 +111,14 @@ struct RStats {
 // ------------------------------------------------------------------------------------------------
 struct WS {
     size_t total;
-    size_t world, ndc, vn_raw, vn, mesh_info, face_ndc, face_box;
+    size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
     size_t p2f, zbuf, sdist, prod, pcol;
-    size_t bin_count, bin_list, glob_list;
-    size_t frac, frac_count, rstats, loss_part, stats2;
+    size_t zkey, fcnt, prodx;
+    size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t face_gcol, face_gndc, g_ndc, g_raw, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, parity, int_count, grid_tab, loss_ticket;
-    int tiles_x, tiles_y, ntiles, btiles_x, nbtiles;
-    size_t zero_begin, zero_end;  // region cleared by one memset per step
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, parity, int_count, loss_ticket;
+    int btiles_x, nbtiles;
+    size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -123,9 +128,6 @@ static WS make_ws(const foho_dims& d) {
     size_t o = 0;
     const size_t P = (size_t)d.H * d.W, R = d.n_renders, B = d.B;
     const size_t V3 = (size_t)d.Vtot * 3 * 4;
-    w.tiles_x = (d.W + TILE - 1) / TILE;
-    w.tiles_y = (d.H + TILE - 1) / TILE;
-    w.ntiles = w.tiles_x * w.tiles_y;
     w.btiles_x = (d.W + BTILE - 1) / BTILE;
     w.nbtiles = w.btiles_x * ((d.H + BTILE - 1) / BTILE);
     auto take = [&](size_t bytes) {
@@ -136,9 +138,12 @@ static WS make_ws(const foho_dims& d) {
     const int G1 = d.grid_res + 1;
     // --- zeroed every step (atomic accumulators) ---
     w.zero_begin = o;
-    w.bin_count = take(R * B * w.ntiles * 4);
+    w.zkey = take(R * B * P * 8);   // ~(z bits << 32 | face id), atomicMax; 0 = no fragment
+    w.fcnt = take(R * B * P * 4);   // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
+    w.prodx = take(R * B * P * 4);  // product of (1 - p) over fractional fragments, stored XOR 1.0f
     w.frac_count = take(R * B * 4);
     w.rstats = take(R * B * sizeof(RStats));
+    w.rslot = take(R * B * NSLOT * sizeof(RSlot));
     w.mesh_info = take(B * 2 * sizeof(MeshInfo));
     w.g_world = take(V3);
     w.face_gcol = take(R * (size_t)d.Ftot * 3 * 4);
@@ -153,14 +158,11 @@ static WS make_ws(const foho_dims& d) {
     w.vn_raw = take(V3);
     w.vn = take(V3);
     w.face_ndc = take((size_t)d.Ftot * 9 * 4);
-    w.face_box = take((size_t)d.Ftot * 8);
     w.p2f = take(R * B * P * 4);
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
     w.prod = take(R * B * P * 4);
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
-    w.bin_list = take(R * B * (size_t)w.ntiles * BIN_CAP * 4);
-    w.glob_list = take(R * B * (size_t)d.Fmax * 4);
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
     w.stats2 = take(R * B * NSTAT * 4);
@@ -173,7 +175,6 @@ static WS make_ws(const foho_dims& d) {
     w.g_kp3d = take(B * 21 * 3 * 4);
     w.vert_part = take(B * VERT_BLOCKS_MAX * 8 * 4);
     w.sim_part = take(B * 2 * VERT_BLOCKS_MAX * SIM_NP * 4);
-    w.grid_tab = take(B * 3 * (size_t)G1 * 4 + B * 8 * 4);
     w.total = o;
     return w;
 }
@@ -204,7 +205,7 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
         case FOHO_WS_FRAC_COUNT: off = w.frac_count; n = R * B * 4; break;
         case FOHO_WS_STATS: off = w.stats2; n = R * B * NSTAT * 4; break;
         case FOHO_WS_PARITY: off = w.parity; n = B * 2 * (size_t)G1 * G1 * 16; break;
-        case FOHO_WS_BIN_COUNT: off = w.bin_count; n = R * B * (size_t)w.ntiles * 4; break;
+        case FOHO_WS_FRAG_COUNT: off = w.fcnt; n = R * B * P * 4; break;
         default: return -1;
     }
     if (nbytes) *nbytes = (int64_t)n;
@@ -230,14 +231,14 @@ struct Ctx {
     float *world, *ndc, *vn_raw, *vn;
     MeshInfo* mesh_info;
     float* face_ndc;
-    short4* face_box;
     int32_t* p2f;
     float *zbuf, *sdist, *prod, *pcol;
-    unsigned* bin_count;
-    int32_t *bin_list, *glob_list;
+    unsigned long long* zkey;
+    unsigned *fcnt, *prodx;
     FracEntry* frac;
     unsigned* frac_count;
     RStats* rstats;
+    RSlot* rslot;
     float *loss_part, *stats2;
     float *face_gcol, *face_gndc, *g_ndc, *g_raw, *g_world, *g_direct;
     int32_t* knn_idx;
@@ -245,8 +246,7 @@ struct Ctx {
     unsigned long long* parity;
     int32_t* int_count;
     unsigned* loss_ticket;
-    float* grid_tab;  // per image: x[G1], y[G1], z[G1] grid coordinates
-    int tiles_x, tiles_y, ntiles, btiles_x;
+    int btiles_x;
 };
 
 __device__ __forceinline__ void face_range(const foho_image& im, int face_set, int& f0, int& f1) {

@@ -249,6 +249,8 @@ class GuidanceBatch:
         d.Fmax = max(m["Fh"] + m["Fo"] for m in self.meta)
         d.Vh_max = max(m["Vh"] for m in self.meta)
         d.Vo_max = max(m["Vo"] for m in self.meta)
+        d.Fh_max = max(m["Fh"] for m in self.meta)
+        d.Fo_max = max(m["Fo"] for m in self.meta)
         d.grid_res, d.frac_cap, d.n_renders = grid_res, frac_cap, n_renders
         self.dims = d
         self._alloc_workspace()

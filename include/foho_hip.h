@@ -74,6 +74,7 @@ typedef struct {
     int32_t grid_res;        /* SDF grid resolution (64 -> 65^3 points; PL:1126, SDF:146)        */
     int32_t frac_cap;        /* capacity of the fractional-coverage fragment list per render     */
     int32_t n_renders;       /* 1 (phase A/B) or 2 (phase C)                                     */
+    int32_t Fh_max, Fo_max;  /* largest per-image hand / object face count (0 = unknown: Fmax is used) */
 } foho_dims;
 
 /* ---- one render = one mesh through renderer + sil_renderer --------------------------------- */
@@ -151,7 +152,7 @@ enum {
 enum {
     FOHO_WS_WORLD = 0, FOHO_WS_NDC, FOHO_WS_VN, FOHO_WS_P2F, FOHO_WS_ZBUF, FOHO_WS_SDIST, FOHO_WS_PROD,
     FOHO_WS_KNN_IDX, FOHO_WS_KNN_D2, FOHO_WS_GWORLD, FOHO_WS_FRAC_COUNT, FOHO_WS_STATS, FOHO_WS_PARITY,
-    FOHO_WS_BIN_COUNT, FOHO_WS_NREGIONS
+    FOHO_WS_FRAG_COUNT, FOHO_WS_NREGIONS
 };
 
 size_t foho_step_workspace_bytes(const foho_dims* dims);

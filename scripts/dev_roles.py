@@ -12,8 +12,8 @@ for _ in range(5): gb.step(cfg)
 acc = {}
 for _ in range(20):
     for k, v in gb.step_profiled(cfg).items(): acc[k] = acc.get(k, 0) + v / 20
-print(os.environ.get("FOHO_DEBUG_SKIP_ROLES", "0"), {k: round(v * 1e3, 1) for k, v in acc.items() if k in ("k_stage2", "k_raster", "k_xform", "k_bbox")})
+print(os.environ.get("FOHO_DEBUG_SKIP_ROLES", "0"), {k: round(v * 1e3, 1) for k, v in acc.items() if k in ("k_stage2", "k_resolve", "k_xform", "k_loss")})
 ''' % ROOT
-for m in [0, 1, 2, 4, 8, 16, 31]:
+for m in [0, 1, 2, 4, 8, 16, 32, 64, 96]:
     env = dict(os.environ, FOHO_DEBUG_SKIP_ROLES=str(m))
     print(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1])
