@@ -37,15 +37,16 @@ def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
 def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo):
     P, V, F = H * W, Vh + Vo, Fh + Fo
     table = {
-        "k_raster": 2 * 16 * P + 36 * (Fh + F) + 12 * V + 24 * F,  # write the 16 B/px G-buffer of 2 renders, read face NDC,
-                                                                     # normals; + the inside test's face pass (ids + vertices)
+        "k_xform": 36 * V,
+        # vertex normals, KNN, keypoints, edge loss; scatter rasteriser reads the faces' NDC vertices (hand faces feed
+        # both renders); inside test's face pass (ids + vertices)
+        "k_stage2": 48 * V + 60 * F + 12 * Fo + 36 * (Fh + F) + 24 * F,
+        "k_resolve": 2 * 16 * P + 12 * V,                           # write the 16 B/px G-buffer of 2 renders, read normals
         "k_loss": 2 * (16 + 17) * P,                                # read G-buffer + targets (12+4+1 B/px) of 2 renders
         "k_pix_bwd": 2 * (16 + 17) * P + 48 * (Fh + F),             # read G-buffer + targets, accumulate 48 B/face x 2 renders
-        "k_bbox": 12 * V,
-        "k_xform": 36 * V,
-        "k_stage2": 48 * V + 60 * F + 12 * Fo,
         "k_vert_gather": 96 * F + 36 * V,
         "k_vert_bwd": 72 * V + 12 * F,
+        "k_final": 0,
     }
     return table.get(name)
 
@@ -111,21 +112,29 @@ def main():
     gb.reset_optimizer()
 
     graph = None if args.no_graph else gb.capture(cfg)
-    for _ in range(50):      # setup: let clocks / caches settle before the counted warm-up (state is reset below)
-        graph.replay() if graph is not None else gb.step(cfg)
-    torch.cuda.synchronize(dev)
-    gb.set_params(0, scale_hand=[1.0], trans_hand=[0, 0, 0], rot_hand=[1, 0, 0, 0], scale_obj=[1.0], trans_obj=[0, 0, 0],
-                  rot_obj=[1, 0, 0, 0])
-    for b_ in range(1, gb.B):
-        gb.params[b_] = gb.params[0]
-    gb.reset_optimizer()
+    ident = gb.params.clone()
+    ident[:] = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
+
+    def new_denoise_step():
+        """Every CFG.joint_iters = 50 iterations the reference starts a new denoising step with a fresh AdamW
+        (PL:1478).  The pose parameters are put back to the scene's start point as well, so that the measured
+        workload stays the configs[1] scene instead of whatever the synthetic optimisation drifts to (with the
+        reference's learning rates the synthetic object shrinks away after ~150 iterations, which would make the
+        rasteriser's job easier than the benchmark claims)."""
+        gb.params.copy_(ident)
+        gb.reset_optimizer()
 
     def run_steps(n):
-        for _ in range(n):
+        for i in range(n):
+            if i % 50 == 0:
+                new_denoise_step()
             if graph is not None:
                 graph.replay()
             else:
                 gb.step(cfg)
+
+    run_steps(50)            # setup: let clocks / caches settle before the counted warm-up
+    torch.cuda.synchronize(dev)
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
@@ -156,18 +165,20 @@ def main():
         "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
                                f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
-                   "hip_graph": graph is not None},
+                   "hip_graph": graph is not None, "restart_every": 50},
         "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[-2]),
     }
 
     if rank == 0:
         # ---- roofline of the dominant kernel: hipEvents around every launch, averaged over the timed step count
         acc = {}
-        nprof = max(5, min(args.steps, 20))
+        nprof = 20
+        run_steps(25)            # profile in the middle of a 50-iteration window
+        cfg_frozen, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
         for _ in range(nprof):
-            for k, v in gb.step_profiled(cfg).items():
+            for k, v in gb.step_profiled(cfg_frozen).items():
                 acc[k] = acc.get(k, 0.0) + v / nprof
-        dom = max((k for k in acc if k != "k_zero"), key=lambda k: acc[k])
+        dom = max(acc, key=lambda k: acc[k])
         kb = kernel_bytes(dom, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
         bstep = algorithmic_bytes(H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
         if kb is None:

@@ -48,20 +48,24 @@ extern "C" int foho_version(void) { return 101; }
 // optional per-kernel timing (foho_step_run_profiled): one hipEvent after every launch
 struct ProfState {
     hipEvent_t ev[32];
+    const char* name[32];
     int n;
 };
 static thread_local ProfState* g_prof = nullptr;
 
-#define CHECK_LAUNCH(name)                                                                   \
+#define CHECK_LAUNCH(kname_)                                                                   \
     do {                                                                                     \
         hipError_t e_ = hipGetLastError();                                                   \
         if (e_ != hipSuccess) {                                                              \
             char b_[200];                                                                    \
-            snprintf(b_, sizeof(b_), "%s: %s", name, hipGetErrorString(e_));                 \
+            snprintf(b_, sizeof(b_), "%s: %s", kname_, hipGetErrorString(e_));                 \
             foho_set_error(b_);                                                              \
             return FOHO_ERR_LAUNCH;                                                          \
         }                                                                                    \
-        if (g_prof && g_prof->n < 32) (void)hipEventRecord(g_prof->ev[g_prof->n++], stream); \
+        if (g_prof && g_prof->n < 32) {                                                      \
+            g_prof->name[g_prof->n] = kname_;                                                  \
+            (void)hipEventRecord(g_prof->ev[g_prof->n++], stream);                           \
+        }                                                                                    \
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -78,11 +82,9 @@ constexpr int SIM_NP = 20;            // similarity-backward partial sums per bl
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
 constexpr int BWD_SLOTS = 512;        // LDS hash slots (distinct faces per tile <= 256)
 
-struct MeshInfo {  // per (image, mesh)
+struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
     unsigned long long kmin_inv[3];  // ~(ordered value << 32 | index), atomicMax  -> min value, lowest index
     unsigned long long kmax[3];      //  (ordered value << 32 | ~index), atomicMax -> max value, lowest index
-    unsigned tmin_inv[3];        // AABB of the transformed vertices (SDF grid), ordered-uint encoded;
-    unsigned tmax[3];            // minima stored inverted so that zero-initialisation means "empty"
 };
 
 struct FracEntry {
@@ -116,7 +118,7 @@ struct WS {
     size_t zkey, fcnt, prodx;
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t face_gcol, face_gndc, g_ndc, g_raw, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, parity, int_count, loss_ticket;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, parity, int_count, loss_ticket, final_ticket;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -144,15 +146,17 @@ static WS make_ws(const foho_dims& d) {
     w.frac_count = take(R * B * 4);
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
-    w.mesh_info = take(B * 2 * sizeof(MeshInfo));
     w.g_world = take(V3);
     w.face_gcol = take(R * (size_t)d.Ftot * 3 * 4);
     w.face_gndc = take(R * (size_t)d.Ftot * 9 * 4);
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
     w.loss_ticket = take(R * B * 4);
+    w.final_ticket = take(B * 4);
     w.zero_end = o;
     // --- plain scratch ---
+    w.mesh_info = take(B * 2 * sizeof(MeshInfo));
+    w.xf_part = take(B * 2 * VERT_BLOCKS_MAX * 8 * 4);
     w.world = take(V3);
     w.ndc = take(V3);
     w.vn_raw = take(V3);
@@ -242,10 +246,10 @@ struct Ctx {
     float *loss_part, *stats2;
     float *face_gcol, *face_gndc, *g_ndc, *g_raw, *g_world, *g_direct;
     int32_t* knn_idx;
-    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part;
+    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part;
     unsigned long long* parity;
     int32_t* int_count;
-    unsigned* loss_ticket;
+    unsigned *loss_ticket, *final_ticket;
     int btiles_x;
 };
 
@@ -281,8 +285,8 @@ __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (
 #include "k_inside.inc"
 #include "k_raster.inc"
 #include "k_loss.inc"
-#include "k_backward.inc"
 #include "k_final.inc"
+#include "k_backward.inc"
 #include "host.inc"
 #include "ops.inc"
 #include "k_sdf.inc"

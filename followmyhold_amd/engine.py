@@ -260,6 +260,7 @@ class GuidanceBatch:
         nbytes = int(self.lib.foho_step_workspace_bytes(ctypes.byref(self.dims)))
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._desc = None
+        self._bbox_dirty = True   # the AABB of verts_in lives in the workspace (FOHO_STAGE_BBOX)
 
     def set_n_renders(self, n):
         if n != self.dims.n_renders:
@@ -307,6 +308,17 @@ class GuidanceBatch:
         m = self.meta[b]
         lo = m["v_off"] + m["Vh"]
         self.verts_in[lo:lo + m["Vo"]] = torch.as_tensor(verts, dtype=torch.float32, device=self.device)
+        self.refresh_bbox()       # eagerly, so that an already captured graph sees the new centre
+
+    def refresh_bbox(self, stream=None):
+        """Recompute the AABB of the input meshes (centre of the similarity transform, PL:111).  Needed once and after
+        every change of verts_in; the per-iteration step (STAGE_STEP) reuses it."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        cfg, _ = phase_cfg("C", do_update=False)
+        L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(L.STAGE_BBOX), ctypes.c_void_p(stream)),
+                "foho_step_run(BBOX)")
+        self._bbox_dirty = False
 
     def grad_obj_verts(self, b):
         m = self.meta[b]
@@ -314,10 +326,13 @@ class GuidanceBatch:
         return self.grad_verts_in[lo:lo + m["Vo"]]
 
     # ------------------------------------------------------------------ the step
-    def step(self, cfg, stages=L.STAGE_ALL, stream=None):
+    def step(self, cfg, stages=L.STAGE_STEP, stream=None):
         """One iteration for every image of the batch; asynchronous on the current stream."""
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self._bbox_dirty and (stages & L.STAGE_VERTEX):
+            stages |= L.STAGE_BBOX
+            self._bbox_dirty = False
         L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(stages), ctypes.c_void_p(stream)),
                 "foho_step_run")
 
@@ -354,13 +369,16 @@ class GuidanceBatch:
     def step_profiled(self, cfg):
         """One iteration with a hipEvent after every kernel; returns {kernel name: milliseconds}."""
         lib = self.lib
+        if self._bbox_dirty:
+            self.refresh_bbox()
         lib.foho_step_run_profiled.restype = ctypes.c_int
         lib.foho_kernel_name.restype = ctypes.c_char_p
         ms = (ctypes.c_float * L.N_KERNELS)()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         L.check(lib.foho_step_run_profiled(ctypes.byref(self.desc()), ctypes.byref(cfg), ctypes.c_void_p(stream), ms),
                 "foho_step_run_profiled")
-        return {lib.foho_kernel_name(i).decode(): float(ms[i]) for i in range(L.N_KERNELS)}
+        names = [lib.foho_kernel_name(i).decode() for i in range(L.N_KERNELS)]
+        return {n: float(ms[i]) for i, n in enumerate(names) if n}
 
 
 def hip_render_fn(device="cuda"):

@@ -145,7 +145,11 @@ enum {
 /* stage mask of foho_step_run (tests and profiling run prefixes of the step) */
 enum {
     FOHO_STAGE_VERTEX = 1, FOHO_STAGE_RASTER = 2, FOHO_STAGE_LOSS = 4, FOHO_STAGE_BACKWARD = 8,
-    FOHO_STAGE_INSIDE = 16, FOHO_STAGE_FINAL = 32, FOHO_STAGE_ALL = 63
+    FOHO_STAGE_INSIDE = 16, FOHO_STAGE_FINAL = 32,
+    FOHO_STAGE_BBOX = 64,            /* AABB of verts_in (centre of the similarity transform, PL:111): needed once
+                                        and again whenever the caller rewrites verts_in                        */
+    FOHO_STAGE_STEP = 63,            /* one optimisation step with a cached AABB                               */
+    FOHO_STAGE_ALL = 127
 };
 
 /* named workspace regions, for parity tests that inspect intermediates */
@@ -159,8 +163,9 @@ size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
 int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
-/* Same as foho_step_run(FOHO_STAGE_ALL) but brackets every launch with hipEvents on `stream`, synchronises
- * the stream and returns the duration of each kernel in milliseconds (measurement aid for bench.py). */
+/* Same as foho_step_run(FOHO_STAGE_STEP) but brackets every launch with hipEvents on `stream`, synchronises
+ * the stream and returns the duration of each launch in milliseconds (measurement aid for bench.py);
+ * foho_kernel_name(i) names the i-th launch of the calling thread's last profiled run ("" past the end). */
 #define FOHO_N_KERNELS 10
 int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
 const char* foho_kernel_name(int i);
