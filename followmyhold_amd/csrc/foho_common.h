@@ -18,49 +18,93 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // ---------------------------------------------------------------- wave / block reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // valid in lane 0
+// Cross-lane reductions use DPP moves (VALU speed) instead of ds_bpermute shuffles, whose ~100-cycle LDS-crossbar
+// round trip per step made a 12-value block reduction cost microseconds: butterfly inside each row of 16 lanes
+// (quad_perm, row_ror), then row_bcast:15 / row_bcast:31 fold the four rows into lane 63, which is broadcast with
+// v_readlane.  Lanes disabled by EXEC or by the row mask contribute the identity.  Results are wave-uniform.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ int dpp_mov(int ident, int x) {
+    return __builtin_amdgcn_update_dpp(ident, x, CTRL, RMASK, 0xf, false);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+#define FOHO_DPP_REDUCE(T, x, ident, OP, MOV)                     \
+    do {                                                          \
+        T t_;                                                     \
+        t_ = MOV(0xB1, 0xf, ident, x); x = OP(x, t_); /* quad_perm [1,0,3,2] */ \
+        t_ = MOV(0x4E, 0xf, ident, x); x = OP(x, t_); /* quad_perm [2,3,0,1] */ \
+        t_ = MOV(0x124, 0xf, ident, x); x = OP(x, t_); /* row_ror:4 */          \
+        t_ = MOV(0x128, 0xf, ident, x); x = OP(x, t_); /* row_ror:8 */          \
+        t_ = MOV(0x142, 0xa, ident, x); x = OP(x, t_); /* row_bcast:15 -> rows 1, 3 */ \
+        t_ = MOV(0x143, 0xc, ident, x); x = OP(x, t_); /* row_bcast:31 -> rows 2, 3 */ \
+    } while (0)
+
+#define FOHO_MOV_F(C, R, id, x) __int_as_float(dpp_mov<C, R>(__float_as_int(id), __float_as_int(x)))
+#define FOHO_MOV_U(C, R, id, x) (unsigned)dpp_mov<C, R>((int)(id), (int)(x))
+#define FOHO_OP_ADD(a, b) ((a) + (b))
+#define FOHO_OP_MINF(a, b) fminf(a, b)
+#define FOHO_OP_MAXF(a, b) fmaxf(a, b)
+#define FOHO_OP_MAXU(a, b) (((a) > (b)) ? (a) : (b))
+
+__device__ __forceinline__ float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+    FOHO_DPP_REDUCE(float, v, 0.0f, FOHO_OP_ADD, FOHO_MOV_F);
+    return lane63(v);
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
-    return v;
+    FOHO_DPP_REDUCE(float, v, INFINITY, FOHO_OP_MINF, FOHO_MOV_F);
+    return lane63(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-    return v;
+    FOHO_DPP_REDUCE(float, v, -INFINITY, FOHO_OP_MAXF, FOHO_MOV_F);
+    return lane63(v);
 }
-__device__ __forceinline__ float wave_sum_all(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+__device__ __forceinline__ float wave_sum_all(float v) { return wave_sum(v); }
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+    FOHO_DPP_REDUCE(unsigned, v, 0u, FOHO_OP_ADD, FOHO_MOV_U);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v) {
+    FOHO_DPP_REDUCE(unsigned, v, 0u, FOHO_OP_MAXU, FOHO_MOV_U);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// doubles move as two 32-bit halves
+template <int CTRL, int RMASK>
+__device__ __forceinline__ double dpp_mov_d(double ident, double x) {
+    const long long xi = __double_as_longlong(x), ii = __double_as_longlong(ident);
+    const unsigned lo = (unsigned)dpp_mov<CTRL, RMASK>((int)(unsigned)ii, (int)(unsigned)xi);
+    const unsigned hi = (unsigned)dpp_mov<CTRL, RMASK>((int)(unsigned)(ii >> 32), (int)(unsigned)(xi >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#define FOHO_MOV_D(C, R, id, x) dpp_mov_d<C, R>(id, x)
+__device__ __forceinline__ double wave_sum(double v) {
+    FOHO_DPP_REDUCE(double, v, 0.0, FOHO_OP_ADD, FOHO_MOV_D);
+    const long long vi = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)vi, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(vi >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// block-wide sum of NV floats per thread; result valid in thread 0.  `red` = NV * (blockDim/64) floats of LDS.
+// block-wide sum of NV floats per thread for 256-thread workgroups; result valid in thread 0.  `red` = NV * 4
+// floats of LDS.  Everything is unrolled over compile-time bounds so that thread 0's LDS reads are issued
+// back-to-back (a loop over a run-time wave count serialised NV * 4 dependent ds_read round trips).
 template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
-    const int nw = blockDim.x >> 6;
+    constexpr int NW = 4;
+    const int wv = wave_id();
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        float s = wave_sum(v[k]);
-        if (lane_id() == 0) red[k * nw + wave_id()] = s;
+        const float s = wave_sum(v[k]);
+        if (lane_id() == 0) red[k * NW + wv] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        float t[NV][NW];
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            float s = 0.f;
-            for (int w = 0; w < nw; w++) s += red[k * nw + w];
-            v[k] = s;
-        }
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int w = 0; w < NW; w++) t[k][w] = red[k * NW + w];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = ((t[k][0] + t[k][1]) + t[k][2]) + t[k][3];
     }
     __syncthreads();
 }
@@ -72,21 +116,20 @@ struct ValIdx {
 };
 __device__ __forceinline__ ValIdx vi_min(ValIdx a, ValIdx b) { return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 __device__ __forceinline__ ValIdx vi_max(ValIdx a, ValIdx b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+template <int CTRL, int RMASK>
+__device__ __forceinline__ ValIdx dpp_mov_vi(ValIdx ident, ValIdx x) {
+    return ValIdx{__int_as_float(dpp_mov<CTRL, RMASK>(__float_as_int(ident.v), __float_as_int(x.v))), dpp_mov<CTRL, RMASK>(ident.i, x.i)};
+}
+#define FOHO_MOV_VI(C, R, id, x) dpp_mov_vi<C, R>(id, x)
 __device__ __forceinline__ ValIdx wave_vi_min(ValIdx a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ValIdx b{__shfl_down(a.v, o, 64), __shfl_down(a.i, o, 64)};
-        a = vi_min(a, b);
-    }
-    return a;
+    const ValIdx ident{INFINITY, 0x7fffffff};
+    FOHO_DPP_REDUCE(ValIdx, a, ident, vi_min, FOHO_MOV_VI);
+    return ValIdx{lane63(a.v), __builtin_amdgcn_readlane(a.i, 63)};
 }
 __device__ __forceinline__ ValIdx wave_vi_max(ValIdx a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ValIdx b{__shfl_down(a.v, o, 64), __shfl_down(a.i, o, 64)};
-        a = vi_max(a, b);
-    }
-    return a;
+    const ValIdx ident{-INFINITY, 0x7fffffff};
+    FOHO_DPP_REDUCE(ValIdx, a, ident, vi_max, FOHO_MOV_VI);
+    return ValIdx{lane63(a.v), __builtin_amdgcn_readlane(a.i, 63)};
 }
 
 // order-preserving float <-> uint32 (for atomicMin/atomicMax on signed floats)

@@ -69,13 +69,30 @@ static thread_local ProfState* g_prof = nullptr;
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
+// optional in-kernel time stamps (make STAMPS=1): DBG(i) stores the 100 MHz wall clock of thread 0 into slot i;
+// foho_debug_stamps() copies the 64 slots to the host.  Compiled out of the production library.
+// ------------------------------------------------------------------------------------------------
+#ifdef FOHO_STAMPS
+__device__ unsigned long long g_dbg[64];
+#define DBG(i)                                                  \
+    do {                                                        \
+        if (threadIdx.x == 0) g_dbg[i] = wall_clock64();        \
+    } while (0)
+extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 64 * 8); }
+#else
+#define DBG(i) \
+    do {       \
+    } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
 constexpr int BTILE = 16;             // tile edge of the per-pixel backward pass (one pixel per lane)
 constexpr int RF = 64;                // faces per workgroup of the scatter rasteriser (= one wave for the setup scan)
 constexpr int RQ_CAP = 2048;          // LDS queue of (face slot, pixel) candidates per enumerate round
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
-constexpr int LOSS_BLOCKS = 64;       // blocks of the per-pixel loss pass per (render, image)
+constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per block

@@ -1,0 +1,30 @@
+"""In-kernel time stamps of the bench scene at iteration 25 (needs `make -C followmyhold_amd/csrc STAMPS=1`)."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from followmyhold_amd import _lib as L
+L.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")
+from followmyhold_amd import engine as E, synthetic
+sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512, seed=0)
+gb = E.GuidanceBatch([sc]); cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+for _ in range(25): gb.step(cfgu)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 64)()
+graph = gb.capture(cfgu)
+for rep in range(4):
+    if rep < 2:
+        gb.step(cfgu)
+    else:
+        graph.replay()
+    torch.cuda.synchronize()
+    gb.lib.foho_debug_stamps(out)
+    a = np.array(out[:], dtype=np.int64)
+    d = lambda i, j: (a[j] - a[i]) / 100.0
+    print("loss  blk0: slots %.2f loop %.2f blocksum %.2f publish+ticket %.2f | last blk: since blk0 start %.2f, finalize %.2f" % (
+        d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(0, 5), d(5, 6)))
+    print("pixbwd mid tile: loads+or %.2f body %.2f barrier %.2f flush %.2f" % (d(20, 21), d(21, 22), d(22, 23), d(23, 24)))
+    print("gather mid blk : csr %.2f rest %.2f" % (d(30, 31), d(31, 32)))
+    print("vbwd  mid blk: body %.2f blocksum %.2f prefetch+fence+ticket %.2f | last blk: since mid start %.2f rows %.2f blocksum %.2f rest %.2f" % (
+        d(10, 11), d(11, 12), d(12, 13), d(10, 14), d(14, 15), d(15, 16), d(16, 17)))
+    print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> gather mid start %.2f | gather mid end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
+        "eager" if rep < 2 else "graph", d(6, 20), d(24, 30), d(32, 10), d(0, 17)))
