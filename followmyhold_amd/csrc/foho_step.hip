@@ -70,15 +70,15 @@ static thread_local ProfState* g_prof = nullptr;
 
 // ------------------------------------------------------------------------------------------------
 // optional in-kernel time stamps (make STAMPS=1): DBG(i) stores the 100 MHz wall clock of thread 0 into slot i;
-// foho_debug_stamps() copies the 64 slots to the host.  Compiled out of the production library.
+// foho_debug_stamps() copies the 1024 slots to the host.  Compiled out of the production library.
 // ------------------------------------------------------------------------------------------------
 #ifdef FOHO_STAMPS
-__device__ unsigned long long g_dbg[64];
+__device__ unsigned long long g_dbg[1024];
 #define DBG(i)                                                  \
     do {                                                        \
         if (threadIdx.x == 0) g_dbg[i] = wall_clock64();        \
     } while (0)
-extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 64 * 8); }
+extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 1024 * 8); }
 #else
 #define DBG(i) \
     do {       \
@@ -135,7 +135,7 @@ struct WS {
     size_t zkey, fcnt, prodx;
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t face_gcol, face_gndc, g_ndc, g_raw, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, parity, int_count, loss_ticket, final_ticket;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -164,8 +164,8 @@ static WS make_ws(const foho_dims& d) {
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
     w.g_world = take(V3);
-    w.face_gcol = take(R * (size_t)d.Ftot * 3 * 4);
-    w.face_gndc = take(R * (size_t)d.Ftot * 9 * 4);
+    w.face_gcol = take((size_t)d.Ftot * 3 * 4);  // dL/d(face colour), summed over the renders
+    w.face_gndc = take((size_t)d.Ftot * 9 * 4);  // dL/d(face NDC vertices), summed over the renders
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
     w.loss_ticket = take(R * B * 4);
@@ -195,6 +195,7 @@ static WS make_ws(const foho_dims& d) {
     w.kp3d = take(B * 21 * 3 * 4);
     w.g_kp3d = take(B * 21 * 3 * 4);
     w.vert_part = take(B * VERT_BLOCKS_MAX * 8 * 4);
+    w.g_special = take(B * 2 * 6 * 4 * 4);  // moge-space gradient of the 6 arg-min / arg-max vertices of each mesh
     w.sim_part = take(B * 2 * VERT_BLOCKS_MAX * SIM_NP * 4);
     w.total = o;
     return w;
@@ -263,7 +264,7 @@ struct Ctx {
     float *loss_part, *stats2;
     float *face_gcol, *face_gndc, *g_ndc, *g_raw, *g_world, *g_direct;
     int32_t* knn_idx;
-    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part;
+    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special;
     unsigned long long* parity;
     int32_t* int_count;
     unsigned *loss_ticket, *final_ticket;

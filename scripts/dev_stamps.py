@@ -9,7 +9,7 @@ sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512
 gb = E.GuidanceBatch([sc]); cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
 for _ in range(25): gb.step(cfgu)
 torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 64)()
+out = (ctypes.c_ulonglong * 1024)()
 graph = gb.capture(cfgu)
 for rep in range(4):
     if rep < 2:
@@ -28,3 +28,13 @@ for rep in range(4):
         d(10, 11), d(11, 12), d(12, 13), d(10, 14), d(14, 15), d(15, 16), d(16, 17)))
     print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> gather mid start %.2f | gather mid end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
         "eager" if rep < 2 else "graph", d(6, 20), d(24, 30), d(32, 10), d(0, 17)))
+    print("vbwd hand blk0: csr loop %.2f projection %.2f contact %.2f kps %.2f similarity+rest %.2f" % (d(500, 40), d(40, 41), d(41, 42), d(42, 43), d(43, 501)))
+    if rep == 3:
+        nb = 44
+        t0 = a[100:100 + 2 * nb:2].min()
+        print("gather blocks start (us since first):", np.round((a[100:100 + 2 * nb:2] - t0) / 100.0, 1).tolist())
+        print("gather blocks end:", np.round((a[101:101 + 2 * nb:2] - t0) / 100.0, 1).tolist())
+        t1 = a[500:500 + 2 * nb:2].min()
+        print("gather first start -> vbwd first start %.2f" % ((t1 - t0) / 100.0))
+        print("vbwd blocks start:", np.round((a[500:500 + 2 * nb:2] - t1) / 100.0, 1).tolist())
+        print("vbwd blocks body end:", np.round((a[501:501 + 2 * nb:2] - t1) / 100.0, 1).tolist())
