@@ -44,8 +44,7 @@ def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo):
         "k_resolve": 2 * 16 * P + 12 * V,                           # write the 16 B/px G-buffer of 2 renders, read normals
         "k_loss": 2 * (16 + 17) * P,                                # read G-buffer + targets (12+4+1 B/px) of 2 renders
         "k_pix_bwd": 2 * (16 + 17) * P + 48 * (Fh + F),             # read G-buffer + targets, accumulate 48 B/face x 2 renders
-        "k_vert_gather": 96 * F + 36 * V,
-        "k_vert_bwd": 72 * V + 12 * F,
+        "k_vert_bwd": 108 * V + 12 * F,
         "k_final": 0,
     }
     return table.get(name)

@@ -84,6 +84,27 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Inclusive segmented sum inside each row of 16 lanes (DPP row_shr); `head` = 1 on the first lane of a segment.
+// Afterwards the LAST lane of every segment holds the segment total.  Whole wave must call it.
+template <int N>
+__device__ __forceinline__ void row_segscan(float (&v)[N], int head) {
+    int flag = head;
+#define FOHO_SEG_STEP(CTRL)                                                                             \
+    {                                                                                                   \
+        const int fl_d = dpp_mov<CTRL, 0xf>(1, flag); /* lanes without a source see a segment boundary */ \
+        _Pragma("unroll") for (int k = 0; k < N; k++) {                                                 \
+            const float t = __int_as_float(dpp_mov<CTRL, 0xf>(0, __float_as_int(v[k])));                \
+            if (!flag) v[k] += t;                                                                       \
+        }                                                                                               \
+        flag |= fl_d;                                                                                   \
+    }
+    FOHO_SEG_STEP(0x111)  // row_shr:1
+    FOHO_SEG_STEP(0x112)  // row_shr:2
+    FOHO_SEG_STEP(0x114)  // row_shr:4
+    FOHO_SEG_STEP(0x118)  // row_shr:8
+#undef FOHO_SEG_STEP
+}
+
 // block-wide sum of NV floats per thread for 256-thread workgroups; result valid in thread 0.  `red` = NV * 4
 // floats of LDS.  Everything is unrolled over compile-time bounds so that thread 0's LDS reads are issued
 // back-to-back (a loop over a run-time wave count serialised NV * 4 dependent ds_read round trips).
@@ -330,12 +351,19 @@ __device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, floa
         const float d01 = seg_d2(xf, yf, x0, y0, x1, y1);
         const float d02 = seg_d2(xf, yf, x0, y0, x2, y2);
         const float d12 = seg_d2(xf, yf, x1, y1, x2, y2);
-        if (d01 <= d02 && d01 <= d12)
-            seg_d2_bwd(xf, yf, x0, y0, x1, y1, gd, gv + 0, gv + 3);
-        else if (d02 <= d01 && d02 <= d12)
-            seg_d2_bwd(xf, yf, x0, y0, x2, y2, gd, gv + 0, gv + 6);
-        else
-            seg_d2_bwd(xf, yf, x1, y1, x2, y2, gd, gv + 3, gv + 6);
+        // nearest edge: 0 = (v0,v1), 1 = (v0,v2), 2 = (v1,v2).  End points and destinations are chosen with selects and
+        // constant indices -- handing seg_d2_bwd a run-time pointer into gv[] would move the array to scratch memory.
+        const int sel = (d01 <= d02 && d01 <= d12) ? 0 : ((d02 <= d01 && d02 <= d12) ? 1 : 2);
+        const float ax = (sel == 2) ? x1 : x0, ay = (sel == 2) ? y1 : y0;
+        const float bx = (sel == 0) ? x1 : x2, by = (sel == 0) ? y1 : y2;
+        float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f};
+        seg_d2_bwd(xf, yf, ax, ay, bx, by, gd, ga, gb);
+        gv[0] += (sel != 2) ? ga[0] : 0.0f;
+        gv[1] += (sel != 2) ? ga[1] : 0.0f;
+        gv[3] += (sel == 0) ? gb[0] : ((sel == 2) ? ga[0] : 0.0f);
+        gv[4] += (sel == 0) ? gb[1] : ((sel == 2) ? ga[1] : 0.0f);
+        gv[6] += (sel != 0) ? gb[0] : 0.0f;
+        gv[7] += (sel != 0) ? gb[1] : 0.0f;
     }
 }
 

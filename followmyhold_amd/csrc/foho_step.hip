@@ -78,6 +78,10 @@ __device__ unsigned long long g_dbg[1024];
     do {                                                        \
         if (threadIdx.x == 0) g_dbg[i] = wall_clock64();        \
     } while (0)
+extern "C" void foho_debug_clear(void) {
+    static unsigned long long z[1024];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
+}
 extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 1024 * 8); }
 #else
 #define DBG(i) \
@@ -97,7 +101,7 @@ constexpr int NPART = 12;             // partial sums per loss block
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per block
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
-constexpr int BWD_SLOTS = 512;        // LDS hash slots (distinct faces per tile <= 256)
+constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 16x16 tile <= 768)
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
     unsigned long long kmin_inv[3];  // ~(ordered value << 32 | index), atomicMax  -> min value, lowest index
@@ -134,7 +138,7 @@ struct WS {
     size_t p2f, zbuf, sdist, prod, pcol;
     size_t zkey, fcnt, prodx;
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
-    size_t face_gcol, face_gndc, g_ndc, g_raw, g_world, g_direct;
+    size_t g_ndc, g_nrm, g_world, g_direct;
     size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
@@ -164,8 +168,8 @@ static WS make_ws(const foho_dims& d) {
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
     w.g_world = take(V3);
-    w.face_gcol = take((size_t)d.Ftot * 3 * 4);  // dL/d(face colour), summed over the renders
-    w.face_gndc = take((size_t)d.Ftot * 9 * 4);  // dL/d(face NDC vertices), summed over the renders
+    w.g_ndc = take(V3);  // dL/d(vertex NDC position), accumulated by k_pix_bwd over all renders
+    w.g_nrm = take(V3);  // dL/d(unit vertex normal) = sum of the colour gradients of the incident faces
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
     w.loss_ticket = take(R * B * 4);
@@ -187,8 +191,6 @@ static WS make_ws(const foho_dims& d) {
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
     w.stats2 = take(R * B * NSTAT * 4);
-    w.g_ndc = take(V3);
-    w.g_raw = take(V3);
     w.g_direct = take(V3);
     w.knn_idx = take((size_t)d.Vtot * 4);
     w.knn_d2 = take((size_t)d.Vtot * 4);
@@ -262,7 +264,7 @@ struct Ctx {
     RStats* rstats;
     RSlot* rslot;
     float *loss_part, *stats2;
-    float *face_gcol, *face_gndc, *g_ndc, *g_raw, *g_world, *g_direct;
+    float *g_ndc, *g_nrm, *g_world, *g_direct;
     int32_t* knn_idx;
     float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special;
     unsigned long long* parity;
@@ -270,6 +272,13 @@ struct Ctx {
     unsigned *loss_ticket, *final_ticket;
     int btiles_x;
 };
+
+// render r of a by-value kernel argument: a run-time index would make the compiler copy the array to scratch memory
+__device__ __forceinline__ foho_render_cfg pick_render(const foho_render_cfg (&rr)[2], int r) {
+    foho_render_cfg o = rr[0];
+    if (r != 0) o = rr[1];
+    return o;
+}
 
 __device__ __forceinline__ void face_range(const foho_image& im, int face_set, int& f0, int& f1) {
     if (face_set == FOHO_FACES_HAND) {

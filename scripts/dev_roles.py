@@ -19,7 +19,7 @@ print("zmin", fv[:, :, 2].min(), "hand box px: mean %.1f max %.0f sum %.0f | obj
     area[:Fh].mean(), area[:Fh].max(), area[:Fh].sum(), area[Fh:].mean(), area[Fh:].max(), area[Fh:].sum()))
 print("per-block T: hand(8) max %.0f  obj(64) max %.0f" % (max(area[i:i + 8].sum() for i in range(0, Fh, 8)),
       max(area[Fh + i:Fh + i + 64].sum() for i in range(0, len(area) - Fh, 64))))
-masks = [0, 2, 32, 2 | 32, 59, 61, 31]
+masks = [0, 128, 256, 512, 128 | 256, 128 | 256 | 512]
 res = {m: [] for m in masks}
 for rep in range(5):
     for m in masks:
@@ -29,5 +29,5 @@ for rep in range(5):
             for k, v in gb.step_profiled(cfg).items(): acc[k] = acc.get(k, 0) + v / 10
         res[m].append(acc)
 for m in masks:
-    ks = ["k_xform", "k_stage2", "k_resolve", "k_loss", "k_pix_bwd", "k_vert_gather", "k_vert_bwd", "k_final"]
+    ks = ["k_xform", "k_stage2", "k_resolve", "k_loss", "k_pix_bwd", "k_vert_bwd", "k_final"]
     print(m, {k: "%.1f/%.1f" % (min(a[k] for a in res[m]) * 1e3, sum(a[k] for a in res[m]) / len(res[m]) * 1e3) for k in ks if k in res[m][0]})

@@ -12,6 +12,7 @@ torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 1024)()
 graph = gb.capture(cfgu)
 for rep in range(4):
+    gb.lib.foho_debug_clear()
     if rep < 2:
         gb.step(cfgu)
     else:
@@ -23,18 +24,28 @@ for rep in range(4):
     print("loss  blk0: slots %.2f loop %.2f blocksum %.2f publish+ticket %.2f | last blk: since blk0 start %.2f, finalize %.2f" % (
         d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(0, 5), d(5, 6)))
     print("pixbwd mid tile: loads+or %.2f body %.2f barrier %.2f flush %.2f" % (d(20, 21), d(21, 22), d(22, 23), d(23, 24)))
-    print("gather mid blk : csr %.2f rest %.2f" % (d(30, 31), d(31, 32)))
     print("vbwd  mid blk: body %.2f blocksum %.2f prefetch+fence+ticket %.2f | last blk: since mid start %.2f rows %.2f blocksum %.2f rest %.2f" % (
         d(10, 11), d(11, 12), d(12, 13), d(10, 14), d(14, 15), d(15, 16), d(16, 17)))
-    print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> gather mid start %.2f | gather mid end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
-        "eager" if rep < 2 else "graph", d(6, 20), d(24, 30), d(32, 10), d(0, 17)))
+    print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
+        "eager" if rep < 2 else "graph", d(6, 20), d(24, 10), d(0, 17)))
     print("vbwd hand blk0: csr loop %.2f projection %.2f contact %.2f kps %.2f similarity+rest %.2f" % (d(500, 40), d(40, 41), d(41, 42), d(42, 43), d(43, 501)))
     if rep == 3:
-        nb = 44
-        t0 = a[100:100 + 2 * nb:2].min()
-        print("gather blocks start (us since first):", np.round((a[100:100 + 2 * nb:2] - t0) / 100.0, 1).tolist())
-        print("gather blocks end:", np.round((a[101:101 + 2 * nb:2] - t0) / 100.0, 1).tolist())
-        t1 = a[500:500 + 2 * nb:2].min()
-        print("gather first start -> vbwd first start %.2f" % ((t1 - t0) / 100.0))
-        print("vbwd blocks start:", np.round((a[500:500 + 2 * nb:2] - t1) / 100.0, 1).tolist())
-        print("vbwd blocks body end:", np.round((a[501:501 + 2 * nb:2] - t1) / 100.0, 1).tolist())
+        st, en = a[100:560], a[560:1020]
+        hit = (en > st) & (st > 0)
+        t0 = st[st > 0].min()
+        dur = (en - st)[hit] / 100.0
+        print("pixbwd render 1, tiles 300..759: %d with hits; body us: min %.1f mean %.1f max %.1f; start since first: max %.1f; end since first: max %.1f" % (
+            hit.sum(), dur.min(), dur.mean(), dur.max(), (st[st > 0].max() - t0) / 100.0, (en[hit].max() - t0) / 100.0))
+        print("  longest bodies:", np.round(np.sort(dur)[-10:], 1).tolist())
+        p2f = gb.region("p2f", torch.int32, (2, 512, 512))[1].cpu().numpy()
+        order = np.argsort(-(en - st) * hit)[:8]
+        for o in order:
+            t = o + 300; ty, tx = divmod(t, 32)
+            blk = p2f[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
+            print("  tile %d (%d,%d): body %.1f us, hits %d, distinct faces %d, hand faces %d" % (t, tx, ty, (en[o] - st[o]) / 100.0, (blk >= 0).sum(),
+                  len(np.unique(blk[blk >= 0])), ((blk >= 0) & (blk < 1552)).sum()))
+        order = np.argsort((en - st) + (~hit) * 10**9)[:4]
+        for o in order:
+            t = o + 300; ty, tx = divmod(t, 32)
+            blk = p2f[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
+            print("  fast tile %d: body %.1f us, hits %d, distinct faces %d" % (t, (en[o] - st[o]) / 100.0, (blk >= 0).sum(), len(np.unique(blk[blk >= 0]))))
