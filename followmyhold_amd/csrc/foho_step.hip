@@ -136,7 +136,8 @@ struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
     size_t p2f, zbuf, sdist, prod, pcol;
-    size_t zkey, fcnt, prodx;
+    size_t zkey, fcnt, psum, plog;
+    size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t g_ndc, g_nrm, g_world, g_direct;
     size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket;
@@ -161,9 +162,6 @@ static WS make_ws(const foho_dims& d) {
     const int G1 = d.grid_res + 1;
     // --- zeroed every step (atomic accumulators) ---
     w.zero_begin = o;
-    w.zkey = take(R * B * P * 8);   // ~(z bits << 32 | face id), atomicMax; 0 = no fragment
-    w.fcnt = take(R * B * P * 4);   // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
-    w.prodx = take(R * B * P * 4);  // product of (1 - p) over fractional fragments, stored XOR 1.0f
     w.frac_count = take(R * B * 4);
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
@@ -175,6 +173,14 @@ static WS make_ws(const foho_dims& d) {
     w.loss_ticket = take(R * B * 4);
     w.final_ticket = take(B * 4);
     w.zero_end = o;
+    // --- scatter planes of the rasteriser: all-zero outside [k_stage2, k_resolve]; k_resolve puts back to zero what
+    // it consumed, FOHO_STAGE_BBOX clears everything (first use / after an aborted step)
+    w.clean_begin = o;
+    w.zkey = take(R * B * P * 8);  // ~(z bits << 32 | face id), atomicMax; 0 = no fragment
+    w.fcnt = take(R * B * P * 4);  // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
+    w.psum = take(R * B * P * 4);  // sum of (1 - p) over the fractional fragments (exact product for one fragment)
+    w.plog = take(R * B * P * 4);  // sum of log(1 - p) over the fractional fragments (product for several)
+    w.clean_end = o;
     // --- plain scratch ---
     w.mesh_info = take(B * 2 * sizeof(MeshInfo));
     w.xf_part = take(B * 2 * VERT_BLOCKS_MAX * 8 * 4);
@@ -258,7 +264,8 @@ struct Ctx {
     int32_t* p2f;
     float *zbuf, *sdist, *prod, *pcol;
     unsigned long long* zkey;
-    unsigned *fcnt, *prodx;
+    unsigned* fcnt;
+    float *psum, *plog;
     FracEntry* frac;
     unsigned* frac_count;
     RStats* rstats;
