@@ -92,7 +92,7 @@ extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFrom
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-constexpr int BTILE = 16;             // tile edge of the per-pixel backward pass (one pixel per lane)
+constexpr int BTX = 32, BTY = 8;      // pixel tile of k_resolve / k_pix_bwd (one pixel per lane; 32 px = one 128-B line of a 4-B plane)
 constexpr int RF = 64;                // faces per workgroup of the scatter rasteriser (= one wave for the setup scan)
 constexpr int RQ_CAP = 2048;          // LDS queue of (face slot, pixel) candidates per enumerate round
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
@@ -101,7 +101,7 @@ constexpr int NPART = 12;             // partial sums per loss block
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per block
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
-constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 16x16 tile <= 768)
+constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
     unsigned long long kmin_inv[3];  // ~(ordered value << 32 | index), atomicMax  -> min value, lowest index
@@ -135,7 +135,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol;
+    size_t p2f, zbuf, sdist, prod, pcol, tile_hit;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -152,8 +152,8 @@ static WS make_ws(const foho_dims& d) {
     size_t o = 0;
     const size_t P = (size_t)d.H * d.W, R = d.n_renders, B = d.B;
     const size_t V3 = (size_t)d.Vtot * 3 * 4;
-    w.btiles_x = (d.W + BTILE - 1) / BTILE;
-    w.nbtiles = w.btiles_x * ((d.H + BTILE - 1) / BTILE);
+    w.btiles_x = (d.W + BTX - 1) / BTX;
+    w.nbtiles = w.btiles_x * ((d.H + BTY - 1) / BTY);
     auto take = [&](size_t bytes) {
         size_t r = o;
         o = al(o + bytes);
@@ -193,6 +193,7 @@ static WS make_ws(const foho_dims& d) {
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
     w.prod = take(R * B * P * 4);
+    w.tile_hit = take(R * B * (size_t)w.nbtiles);  // 1 = the tile holds at least one hit pixel
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
@@ -263,6 +264,7 @@ struct Ctx {
     float* face_ndc;
     int32_t* p2f;
     float *zbuf, *sdist, *prod, *pcol;
+    uint8_t* tile_hit;
     unsigned long long* zkey;
     unsigned* fcnt;
     float *psum, *plog;

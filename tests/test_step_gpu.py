@@ -89,10 +89,12 @@ def test_raster_face_indices_bit_exact(small):
         assert (p2f[r] >= 0).sum() > 20
         mism = int((p2f[r] != ref).sum())
         assert mism == 0, f"render {r}: {mism} face-index mismatches"
-        assert np.array_equal(zb[r], sel["zbuf"].reshape(-1))
-        assert np.array_equal(sd[r], sel["dists"].reshape(-1))
+        hit = ref >= 0                                       # z / dist / product planes are defined for hit pixels only
+        assert np.array_equal(zb[r][hit], sel["zbuf"].reshape(-1)[hit])
+        assert np.array_equal(sd[r][hit], sel["dists"].reshape(-1)[hit])
     sil_ref = aux["render"]["sil"].detach().numpy().reshape(-1)
-    assert np.abs((1.0 - prod[1]) - sil_ref).max() < 1e-6
+    hit = aux["render"]["sel"]["pix_to_face"].reshape(-1) >= 0
+    assert np.abs((1.0 - prod[1][hit]) - sil_ref[hit]).max() < 1e-6 and np.abs(sil_ref[~hit]).max() == 0.0
 
 
 @gpu
