@@ -42,7 +42,7 @@ def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo):
         # both renders); inside test's face pass (ids + vertices)
         "k_stage2": 48 * V + 60 * F + 12 * Fo + 36 * (Fh + F) + 24 * F,
         "k_resolve": 2 * 16 * P + 12 * V,                           # write the 16 B/px G-buffer of 2 renders, read normals
-        "k_loss": 2 * (16 + 17) * P,                                # read G-buffer + targets (12+4+1 B/px) of 2 renders
+        "k_loss": (2 * 16 + 17) * P,                                # read the G-buffers of 2 renders + the targets (12+4+1 B/px) once
         "k_pix_bwd": 2 * (16 + 17) * P + 48 * (Fh + F),             # read G-buffer + targets, accumulate 48 B/face x 2 renders
         "k_vert_bwd": 108 * V + 12 * F,
         "k_final": 0,
@@ -189,6 +189,12 @@ def main():
                            "kernel_ms": acc[dom],
                            "algorithmic_bytes_per_launch": kb * ipg}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
+        out["kernels"] = {}
+        for k, v in acc.items():           # every launch of the step against the HBM roofline (algorithmic bytes / duration)
+            kbk = kernel_bytes(k, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"]) or 0
+            gbs = kbk * ipg / (v * 1e-3) / 1e9
+            out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipg / 1e6, 3), "GBs": round(gbs, 1),
+                                 "frac": round(gbs / HBM_PEAK_GBS, 4)}
         out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
         out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
 

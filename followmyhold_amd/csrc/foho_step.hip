@@ -5,23 +5,25 @@
 // batch of B independent images, as a short chain of kernels on one HIP stream with no host
 // synchronisation:
 //
-//   k_bbox         AABB of the input meshes (centre of the similarity transform, PL:111)  [k_vertex.inc]
-//   k_xform        similarity transform about the AABB centre + FoV projection (PL:108-118, 242-250)
-//   k_stage2       vertex normals | face setup + 16x16-px binning | K=1 NN | keypoints | edge/verts^2 | SDF grid
-//   k_raster       per-tile z-buffer in LDS (ds_min_u64 keys), silhouette product (RUN:95-116) [k_raster.inc]
-//   k_loss         normal / disparity / BCE partial sums, min-max path sums, tie counts    [k_loss.inc]
-//   k_stats        reduce the partials of one render; keypoint loss
-//   k_pix_bwd      per-pixel backward of loss heads + shading + rasteriser, LDS hash by face [k_backward.inc]
-//   k_frac_bwd     silhouette backward over the fractional-coverage fragment list
-//   k_vert_gather  faces -> vertices (CSR), vertex-normal backward part 1
-//   k_vert_bwd     vertex-normal backward part 2, projection backward, similarity partial sums
-//   k_inside_*     +z ray parity of the joint (res+1)^3 grid via atomicXor on column bit masks [k_inside.inc]
-//   k_final        loss assembly, parameter gradients, Adam/AdamW update (PL:1578-1601)    [k_final.inc]
+//   (k_bbox*)      FOHO_STAGE_BBOX, once: AABB of the input meshes = centre of the similarity transform (PL:111)
+//   k_xform        similarity transform about the AABB centre + FoV projection (PL:108-118, 242-250); clears
+//                  the step's accumulators                                                   [k_vertex.inc]
+//   k_stage2       roles: scatter rasteriser (z-key atomics, RUN:95-116) | K=1 NN | inside test (+z ray parity
+//                  via atomicXor on column bit masks) | vertex normals | keypoints | edge / verts^2
+//                                                                       [k_raster.inc, k_inside.inc, k_vertex.inc]
+//   k_resolve      z-keys -> G-buffer, hit-tile flags, colour / disparity min-max              [k_raster.inc]
+//   k_loss         normal / disparity / BCE partial sums of all renders, render statistics (last workgroup),
+//                  keypoint loss, intersection popcount                                        [k_loss.inc]
+//   k_pix_bwd      per-pixel backward of loss heads + shading + rasteriser, reduced per vertex in LDS, and
+//                  the silhouette backward over the fractional-coverage fragment list        [k_backward.inc]
+//   k_vert_bwd     vertex-normal / projection / contact / keypoint backward, similarity partial sums; the
+//                  last workgroup runs the final stage: loss assembly, parameter gradients, Adam/AdamW
+//                  (PL:1578-1601)                                              [k_backward.inc, k_final.inc]
 //
-// Data layout in HBM: vertices AoS (V,3) f32, faces (F,3) i32 global ids, per-face NDC copy (F,9) f32 and
-// exact pixel box (F,4) i16 written once per step by the face-setup role; G-buffer per render = 4 planes
-// (face id i32, z f32, signed dist f32, silhouette product f32) = 16 B/px, plus the hit face's colour (12 B,
-// touched for hit pixels only).
+// Data layout in HBM: vertices AoS (V,3) f32, faces (F,3) i32 global ids, per-face NDC copy (F,9) f32 written by
+// the rasteriser's setup; per render scatter planes (z-key u64, fragment counter, two product sums; all-zero
+// between steps) and a G-buffer (face id i32 for every pixel; z, signed dist, silhouette product, colour for
+// hit pixels only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
