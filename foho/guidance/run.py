@@ -80,9 +80,14 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
     try:
         from hy3dgen.shapegen.pipelines import Hunyuan3DDiTFlowMatchingPipeline_main
     except ImportError as e:
+        if os.environ.get("FOHO_MESH_LEVEL_GUIDANCE") == "1":
+            return _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path,
+                                        cropped_hand_mask_path, moge_mesh_path, T_h2m_path, hunyuan_hoi_mesh_path,
+                                        save_path_obj, save_path_hand, config, device)
         raise RuntimeError("Hunyuan3D-2 (hy3dgen) is not installed: the DiT/VAE that produce the object latent are "
-                           "outside the MI355X hot path (SURVEY.md 8(a) A20). Use followmyhold_amd.engine.GuidanceBatch "
-                           "directly for mesh-level guidance.") from e
+                           "outside the MI355X hot path (SURVEY.md 8(a) A20). Set FOHO_MESH_LEVEL_GUIDANCE=1 to run "
+                           "phases A/B/C on the fixed Hunyuan mesh, or use followmyhold_amd.engine.GuidanceBatch "
+                           "directly.") from e
     from PIL import Image
     image = Image.open(cropped_obj_img_path).convert("RGBA")
     pipeline = Hunyuan3DDiTFlowMatchingPipeline_main.from_pretrained("tencent/Hunyuan3D-2")
@@ -102,6 +107,23 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
         print(f"Empty mesh for {cropped_obj_img_path}")
         return None, None
     return obj_mesh, hand_mesh
+
+
+def _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path, cropped_hand_mask_path,
+                         moge_mesh_path, T_h2m_path, hunyuan_hoi_mesh_path, save_path_obj, save_path_hand, config, device):
+    """Guidance on a fixed object mesh (no diffusion model): every input file of PL:1217-1256 is read, the MoGe mesh
+    is rendered into the target maps on the GPU, phases A/B/C run with the reference's iteration schedule and the
+    two output meshes are written.  Returns ((obj_verts, obj_faces), (hand_verts, hand_faces))."""
+    from followmyhold_amd import engine as E
+    from followmyhold_amd import inputs
+    p = dict(cropped_hand_mask_path=cropped_hand_mask_path, cropped_obj_mask_path=cropped_obj_mask_path,
+             moge_mesh_path=moge_mesh_path, moge_fov_path=os.path.join(os.path.dirname(moge_mesh_path), "fov.json"),
+             T_h2m_path=T_h2m_path, aligned_mano_mesh_path=aligned_mano_mesh_path,
+             hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path, hamer_for_guid_path=hamer_for_guid_path)
+    scene = inputs.load_scene_from_files(p, inputs.load_j_regressor(), E.hip_render_fn(device))
+    scene["fov"] = float(fovx)
+    gb = inputs.run_mesh_guidance([scene], config, device=device)
+    return inputs.export_meshes(gb, 0, save_path_obj, save_path_hand)
 
 
 def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str, hunyuan_hoi_mesh_dir: str,

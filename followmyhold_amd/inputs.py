@@ -1,0 +1,288 @@
+"""On-disk formats at the edges of the guidance path and the mesh-level guidance driver.
+
+What the reference reads per image (third_party_patches/hy3dgen/shapegen/pipelines.py:1217-1256, file names from
+src/foho/guidance/run.py:210-222) and how it is read here:
+
+  {idx}_kps_for_guidance.npy      pickled dict, key 'mano_2d_kps' (21,2) in image space (hamer.py:275-279)
+  {idx}_hamer_aligned_mano.ply    MANO mesh aligned to the Hunyuan space (778 V + wrist-closing faces)
+  {idx}_cropped_{hand,obj}_mask.png   8-bit masks, > 0 means inside
+  {idx}_hoi_mesh.npy              4x4 float64 Hunyuan -> MoGe similarity (h2m.py:38; np.save appends .npy)
+  {idx}_hoi_mesh.ply              Hunyuan hand-object mesh
+  {idx}_cropped_hoi/mesh.glb      MoGe image mesh (binary glTF 2.0), rendered ONCE per image into the target
+                                  normal / disparity maps (render_normal_and_disparity, PL:272-289) and masked
+  {idx}_cropped_hoi/fov.json      {"fov_x": degrees}
+
+`run_mesh_guidance` drives phases A, B, C (PL:1320-1601) on a FIXED object mesh: the diffusion latent -> FlexiCubes
+route that moves the object's vertices in the reference lives outside this repository's scope,
+everything else -- inputs, targets, schedule of iterations, optimiser restarts, outputs -- follows the reference.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+
+from . import meshio
+
+# ------------------------------------------------------------------------------------------------ binary glTF 2.0
+_GLB_MAGIC, _CHUNK_JSON, _CHUNK_BIN = 0x46546C67, 0x4E4F534A, 0x004E4942
+_COMPONENT = {5120: ("b", 1), 5121: ("B", 1), 5122: ("h", 2), 5123: ("H", 2), 5125: ("I", 4), 5126: ("f", 4)}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _accessor(gltf, binary, idx):
+    acc = gltf["accessors"][idx]
+    fmt, size = _COMPONENT[acc["componentType"]]
+    ncomp = _NCOMP[acc["type"]]
+    count = acc["count"]
+    if "bufferView" not in acc:
+        return np.zeros((count, ncomp), dtype=np.dtype(fmt))
+    bv = gltf["bufferViews"][acc["bufferView"]]
+    if bv.get("buffer", 0) != 0:
+        raise ValueError("only the embedded BIN buffer of a .glb is supported")
+    start = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = bv.get("byteStride", 0) or size * ncomp
+    dt = np.dtype(fmt).newbyteorder("<")
+    if stride == size * ncomp:
+        a = np.frombuffer(binary, dtype=dt, count=count * ncomp, offset=start).reshape(count, ncomp)
+    else:
+        a = np.stack([np.frombuffer(binary, dtype=dt, count=ncomp, offset=start + i * stride) for i in range(count)])
+    return a
+
+
+def _node_matrix(node):
+    if "matrix" in node:
+        return np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T  # glTF stores column-major
+    m = np.eye(4)
+    if "scale" in node:
+        m = np.diag(list(node["scale"]) + [1.0]) @ m
+    if "rotation" in node:
+        x, y, z, w = node["rotation"]
+        r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        rm = np.eye(4)
+        rm[:3, :3] = r
+        m = rm @ m
+    if "translation" in node:
+        t = np.eye(4)
+        t[:3, 3] = node["translation"]
+        m = t @ m
+    return m
+
+
+def load_glb(path):
+    """Triangle geometry of a binary glTF 2.0 file: (verts (V,3) float32, faces (F,3) int64), all primitives of all
+    scene nodes concatenated with their node transforms applied (the MoGe mesh is a single primitive)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    magic, version, length = struct.unpack_from("<III", data, 0)
+    if magic != _GLB_MAGIC or version != 2:
+        raise ValueError(f"{path}: not a binary glTF 2.0 file")
+    off, gltf, binary = 12, None, b""
+    while off + 8 <= min(length, len(data)):
+        clen, ctype = struct.unpack_from("<II", data, off)
+        chunk = data[off + 8:off + 8 + clen]
+        if ctype == _CHUNK_JSON:
+            gltf = json.loads(chunk.decode("utf-8"))
+        elif ctype == _CHUNK_BIN:
+            binary = chunk
+        off += 8 + clen
+    if gltf is None:
+        raise ValueError(f"{path}: no JSON chunk")
+    verts, faces, voff = [], [], 0
+
+    def visit(ni, parent):
+        nonlocal voff
+        node = gltf["nodes"][ni]
+        m = parent @ _node_matrix(node)
+        if "mesh" in node:
+            for prim in gltf["meshes"][node["mesh"]]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue
+                p = _accessor(gltf, binary, prim["attributes"]["POSITION"]).astype(np.float64)
+                p = p @ m[:3, :3].T + m[:3, 3]
+                if "indices" in prim:
+                    idx = _accessor(gltf, binary, prim["indices"]).reshape(-1).astype(np.int64)
+                else:
+                    idx = np.arange(len(p), dtype=np.int64)
+                verts.append(p.astype(np.float32))
+                faces.append(idx.reshape(-1, 3) + voff)
+                voff += len(p)
+        for c in node.get("children", []):
+            visit(c, m)
+
+    scenes = gltf.get("scenes")
+    roots = scenes[gltf.get("scene", 0)]["nodes"] if scenes else range(len(gltf.get("nodes", [])))
+    for r in roots:
+        visit(r, np.eye(4))
+    if not verts:
+        raise ValueError(f"{path}: no triangle primitive")
+    return np.concatenate(verts, 0), np.concatenate(faces, 0)
+
+
+def save_glb(path, verts, faces):
+    """Minimal single-primitive .glb writer (fixtures for the tests, same layout trimesh / utils3d emit)."""
+    v = np.ascontiguousarray(verts, dtype="<f4")
+    f = np.ascontiguousarray(faces, dtype="<u4").reshape(-1)
+    vb, fb = v.tobytes(), f.tobytes()
+    pad = (-len(vb)) % 4
+    binary = vb + b"\0" * pad + fb
+    gltf = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "mode": 4}]}],
+        "buffers": [{"byteLength": len(binary)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(vb), "target": 34962},
+                        {"buffer": 0, "byteOffset": len(vb) + pad, "byteLength": len(fb), "target": 34963}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": int(len(v)), "type": "VEC3",
+                       "min": v.min(0).tolist(), "max": v.max(0).tolist()},
+                      {"bufferView": 1, "componentType": 5125, "count": int(len(f)), "type": "SCALAR"}],
+    }
+    js = json.dumps(gltf, separators=(",", ":")).encode("utf-8")
+    js += b" " * ((-len(js)) % 4)
+    binary += b"\0" * ((-len(binary)) % 4)
+    total = 12 + 8 + len(js) + 8 + len(binary)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<III", _GLB_MAGIC, 2, total))
+        fh.write(struct.pack("<II", len(js), _CHUNK_JSON) + js)
+        fh.write(struct.pack("<II", len(binary), _CHUNK_BIN) + binary)
+
+
+# ------------------------------------------------------------------------------------------------ small files
+def load_mask(path):
+    """8-bit PNG mask -> bool (H,W); the reference thresholds cv2.imread(..., GRAYSCALE) > 0 (PL:1230-1237)."""
+    from PIL import Image
+    return np.array(Image.open(path).convert("L")) > 0
+
+
+def save_mask(path, mask):
+    from PIL import Image
+    Image.fromarray(np.asarray(mask).astype(np.uint8) * 255).save(path)
+
+
+def load_kps_for_guidance(path):
+    """{idx}_kps_for_guidance.npy: pickled dict written by the modified HaMeR demo (hamer.py:275-279)."""
+    d = np.load(path, allow_pickle=True).item()
+    return np.asarray(d["mano_2d_kps"], dtype=np.float32).reshape(21, 2)
+
+
+def load_j_regressor(path=None):
+    """(16, 778) MANO joint regressor.  The reference torch.load()s ./third_party/estimator/hamer/J_regressor_hamer.pt
+    (PL:1218); $FOHO_J_REGRESSOR may point to a .pt or .npy copy."""
+    import torch
+    from foho.configs import third_party_root
+    path = path or os.environ.get("FOHO_J_REGRESSOR") or os.path.join(third_party_root(), "estimator", "hamer",
+                                                                       "J_regressor_hamer.pt")
+    if path.endswith(".npy"):
+        return np.load(path).astype(np.float32)
+    jr = torch.load(path, map_location="cpu")
+    return np.asarray(jr.to_dense() if hasattr(jr, "to_dense") and jr.is_sparse else jr, dtype=np.float32)
+
+
+def load_fov(path):
+    with open(path, "r", encoding="utf-8") as f:
+        return float(json.load(f)["fov_x"])
+
+
+# ------------------------------------------------------------------------------------------------ one image
+def load_scene_from_files(p, J_regressor, render_fn, n_hand_verts=778):
+    """Scene dict for `engine.GuidanceBatch` from the reference's per-image files.  `p` = `foho.guidance.run.derive_paths`
+    output; `render_fn(verts, faces, H, W, fov) -> (normal, disp, pix_to_face)` renders the MoGe mesh into the target
+    maps (engine.hip_render_fn on the GPU)."""
+    hand_mask, obj_mask = load_mask(p["cropped_hand_mask_path"]), load_mask(p["cropped_obj_mask_path"])
+    H, W = hand_mask.shape
+    fov = load_fov(p["moge_fov_path"])
+    T = np.load(p["T_h2m_path"]).astype(np.float64).reshape(4, 4)
+    mano_v, mano_f = meshio.load_ply(p["aligned_mano_mesh_path"])
+    hand_moge = mano_v.astype(np.float64) @ T[:3, :3].T + T[:3, 3]          # transform_hunyuan2moge (PL:242-250, 1241)
+    obj_v, obj_f = meshio.load_ply(p["hunyuan_hoi_mesh_path"])
+    mv, mf = load_glb(p["moge_mesh_path"])
+    normal, disp, _ = render_fn(mv, mf, H, W, fov)
+    hoi = (hand_mask | obj_mask).astype(np.float32)                         # PL:1243, 1252-1253
+    jr = np.asarray(J_regressor, dtype=np.float32)
+    if jr.shape[1] != n_hand_verts:
+        raise ValueError("J_regressor must be (16, number of MANO vertices)")
+    return dict(
+        hand_verts=hand_moge.astype(np.float32), hand_faces=mano_f.astype(np.int64),
+        obj_verts=obj_v.astype(np.float32), obj_faces=obj_f.astype(np.int64), T_h2m=T.astype(np.float32),
+        J_regressor=jr, kps_2d=load_kps_for_guidance(p["hamer_for_guid_path"]),
+        moge_normal=(normal * hoi[..., None]).astype(np.float32), moge_disp=(disp * hoi).astype(np.float32),
+        hand_mask=hand_mask, obj_mask=obj_mask, fov=fov, H=int(H), W=int(W))
+
+
+def save_scene_files(scene, moge_verts, moge_faces, dirs, index, hand_verts_hunyuan=None):
+    """Write one image's inputs in the reference's formats and names (fixture generator for the tests and a
+    specification of the formats).  `dirs` holds mask_dir, moge_out_dir, hunyuan_hoi_mesh_dir, hamer_out_dir,
+    h2m_rt_dir, aligned_mano_dir, cropped_obj_img_dir."""
+    from PIL import Image
+    j = os.path.join
+    for d in dirs.values():
+        os.makedirs(d, exist_ok=True)
+    os.makedirs(j(dirs["moge_out_dir"], f"{index}_cropped_hoi"), exist_ok=True)
+    H, W = scene["H"], scene["W"]
+    Image.fromarray(np.zeros((H, W, 3), np.uint8)).save(j(dirs["cropped_obj_img_dir"], f"{index}_cropped_hoi_1.png"))
+    save_mask(j(dirs["mask_dir"], f"{index}_cropped_hand_mask.png"), scene["hand_mask"])
+    save_mask(j(dirs["mask_dir"], f"{index}_cropped_obj_mask.png"), scene["obj_mask"])
+    save_glb(j(dirs["moge_out_dir"], f"{index}_cropped_hoi", "mesh.glb"), moge_verts, moge_faces)
+    with open(j(dirs["moge_out_dir"], f"{index}_cropped_hoi", "fov.json"), "w", encoding="utf-8") as f:
+        json.dump({"fov_x": scene["fov"]}, f)
+    T = np.asarray(scene["T_h2m"], np.float64)
+    np.save(j(dirs["h2m_rt_dir"], f"{index}_hoi_mesh"), T)                 # np.save appends .npy (h2m.py:38)
+    if hand_verts_hunyuan is None:                                         # MoGe -> Hunyuan space
+        Ti = np.linalg.inv(T)
+        hand_verts_hunyuan = np.asarray(scene["hand_verts"], np.float64) @ Ti[:3, :3].T + Ti[:3, 3]
+    meshio.save_ply(j(dirs["aligned_mano_dir"], f"{index}_hamer_aligned_mano.ply"), hand_verts_hunyuan.astype(np.float32),
+                    scene["hand_faces"])
+    meshio.save_ply(j(dirs["hunyuan_hoi_mesh_dir"], f"{index}_hoi_mesh.ply"), scene["obj_verts"], scene["obj_faces"])
+    np.save(j(dirs["hamer_out_dir"], f"{index}_kps_for_guidance.npy"),
+            {"mano_2d_kps": np.asarray(scene["kps_2d"], np.float32), "mano_3d_kps": np.zeros((21, 3), np.float32),
+             "cam_t": np.zeros(3, np.float32)}, allow_pickle=True)
+
+
+# ------------------------------------------------------------------------------------------------ driver
+def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None):
+    """Phases A (hand), B (object), C (joint) of PL:1293-1610 for a batch of scenes on fixed object meshes.
+
+    Iteration counts and the guidance window come from the reference's OptimizationConfig: phase A at denoising
+    step `handopt_start_step`, phase B at `guidance_start_step`, phase C at every later step, each with a fresh
+    optimiser (PL:1318, 1384, 1478).  Returns the GuidanceBatch (parameters, losses, world-space vertices)."""
+    import torch
+    from . import engine as E
+    cfg0 = config if config is not None else E.OptimizationConfig()
+    gb = E.GuidanceBatch(scenes, device=device, n_renders=2)
+    n_steps = int(cfg0.num_inference_steps)
+    a_step, b_step = int(cfg0.handopt_start_step), int(cfg0.guidance_start_step)
+
+    def loop(phase, iters, denoise_i):
+        cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=denoise_i, do_update=True)
+        gb.set_n_renders(n_renders)
+        gb.reset_optimizer()
+        graph = gb.capture(cfg) if capture else None
+        gb.reset_optimizer()
+        for _ in range(int(iters)):
+            graph.replay() if graph is not None else gb.step(cfg)
+        torch.cuda.synchronize(gb.device)
+        gb.raise_on_flags()
+        if log is not None:
+            log(phase, denoise_i, [gb.loss_dict(b)["total"] for b in range(gb.B)])
+
+    loop("A", cfg0.optimization_steps_hand, a_step)
+    loop("B", cfg0.optimization_steps_scale, b_step)
+    for i in range(b_step + 1, n_steps):
+        loop("C", cfg0.optimization_steps_joint, i)
+    return gb
+
+
+def export_meshes(gb, b, save_path_obj, save_path_hand):
+    """{idx}_obj.ply / {idx}_hand.ply (run.py:221-222): the optimised meshes in the MoGe world."""
+    import torch
+    m = gb.meta[b]
+    world = gb.region("world", torch.float32, (-1, 3)).detach().cpu().numpy()
+    faces = gb.faces.detach().cpu().numpy().astype(np.int64)
+    hv = world[m["v_off"]:m["v_off"] + m["Vh"]]
+    ov = world[m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]]
+    hf = faces[m["f_off"]:m["f_off"] + m["Fh"]] - m["v_off"]
+    of = faces[m["f_off"] + m["Fh"]:m["f_off"] + m["Fh"] + m["Fo"]] - m["v_off"] - m["Vh"]
+    meshio.save_ply(save_path_obj, ov, of)
+    meshio.save_ply(save_path_hand, hv, hf)
+    return (ov, of), (hv, hf)
