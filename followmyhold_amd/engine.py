@@ -396,6 +396,7 @@ def hip_render_fn(device="cuda"):
                      hand_mask=np.zeros((H, W), bool), obj_mask=np.zeros((H, W), bool), fov=fov, H=H, W=W)
         gb = GuidanceBatch([dummy], device=device, n_renders=1, grid_res=2)
         cfg, _ = phase_cfg("B", do_update=False)
+        cfg.world_space_input = 1     # the reference renders the target mesh as it is (PL:1247-1256)
         gb.step(cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)
         torch.cuda.synchronize()
         gb.raise_on_flags()

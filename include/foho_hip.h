@@ -102,6 +102,9 @@ typedef struct {
     float lr[16];                    /* 0 = frozen (phase A freezes the object, phase B the hand) */
     float beta1, beta2, eps, weight_decay;
     int32_t do_update;               /* 0: gradients only                                          */
+    int32_t world_space_input;       /* 1: the similarity transform is skipped (vertices are used as they are, after
+                                        T_h2m for the object) -- rendering target maps of a fixed mesh (PL:1247-1256),
+                                        where the reference does not apply transform_mesh_around_center either      */
 } foho_step_cfg;
 
 /* ---- buffers of one batched step -------------------------------------------------------------- */

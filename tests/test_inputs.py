@@ -133,3 +133,30 @@ def test_file_based_mesh_level_guidance(tmp_path, monkeypatch):
     t0 = os.path.getmtime(out_obj)
     G.run(project_root=str(tmp_path), task_list_file=None, **d)
     assert os.path.getmtime(out_obj) == t0
+
+
+def _image_mesh(n, fov=60.0):
+    """MoGe-style image mesh (utils3d.image_mesh, src/foho/geometry/moge.py:137-158): one vertex per pixel of an n x n
+    depth map, two faces per pixel quad."""
+    ys, xs = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    t = np.tan(np.radians(fov) / 2)
+    z = 0.5 + 0.1 * np.sin(xs / n * 6.0) * np.cos(ys / n * 5.0)
+    x = (xs + 0.5 - n / 2) / (n / 2) * t * z * 0.9
+    y = -(ys + 0.5 - n / 2) / (n / 2) * t * z * 0.9
+    v = np.stack([x, y, -z], -1).reshape(-1, 3).astype(np.float32)
+    i = (ys[:-1, :-1] * n + xs[:-1, :-1]).reshape(-1)
+    f = np.concatenate([np.stack([i, i + n, i + 1], 1), np.stack([i + 1, i + n, i + n + 1], 1)], 0).astype(np.int64)
+    return v, f
+
+
+@gpu
+def test_image_mesh_target_render_matches_oracle():
+    """the once-per-image render of the MoGe image mesh (large F, screen-filling) into the
+    target maps -- face indices bit-exact, maps equal to the oracle's."""
+    from followmyhold_amd import engine as E
+    v, f = _image_mesh(96)
+    n_ref, d_ref, p_ref = oracle_render_fn(v, f, 128, 128, 60.0)
+    n_hip, d_hip, p_hip = E.hip_render_fn("cuda")(v, f, 128, 128, 60.0)
+    assert (p_ref >= 0).mean() > 0.7
+    assert np.array_equal(p_hip, p_ref)
+    assert np.abs(d_hip - d_ref).max() < 1e-5 and np.abs(n_hip - n_ref).max() < 1e-4
