@@ -341,13 +341,14 @@ class GuidanceBatch:
         return dict(zip(L.LOSS_NAMES, l))
 
     def raise_on_flags(self):
-        """bit1: fractional-fragment list overflow, bit2: a pixel saw more than K=100 faces -> results would
-        differ from the reference's K=100 silhouette; fail loudly instead."""
+        """bit1: fractional-fragment list overflow, bit2: a pixel holds at least 100 fractional-coverage fragments, the only
+        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones;
+        fail loudly instead of deviating."""
         f = self.flags.detach().cpu().numpy()
         if (f & 2).any():
             raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
         if (f & 4).any():
-            raise L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
+            raise L.FohoError("a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced")
         return f
 
     # ------------------------------------------------------------------ HIP graph + per-kernel timing
