@@ -101,7 +101,10 @@ constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette raste
 constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
-constexpr int SIM_NP = 20;            // similarity-backward partial sums per block
+constexpr int SIM_NP = 20;            // similarity-backward partial sums per workgroup (18 used)
+constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd
+constexpr int VP_CAP = 1024;          // (vertex, incident face) pairs staged in LDS per round of k_vert_bwd
+constexpr int SIM_ROWS_MAX = VERT_BLOCKS_MAX * (256 / VB);  // partial rows per (image, mesh)
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
 constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
 
@@ -207,7 +210,7 @@ static WS make_ws(const foho_dims& d) {
     w.g_kp3d = take(B * 21 * 3 * 4);
     w.vert_part = take(B * VERT_BLOCKS_MAX * 8 * 4);
     w.g_special = take(B * 2 * 6 * 4 * 4);  // moge-space gradient of the 6 arg-min / arg-max vertices of each mesh
-    w.sim_part = take(B * 2 * VERT_BLOCKS_MAX * SIM_NP * 4);
+    w.sim_part = take(B * 2 * (size_t)SIM_ROWS_MAX * SIM_NP * 4);
     w.total = o;
     return w;
 }
