@@ -31,7 +31,6 @@ for rep in range(4):
     for nm, o in (("hand", 50), ("obj", 60)):
         print("raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f (T=%d candidates)" % (
             nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), a[o + 8]))
-    print("vbwd hand blk0: csr loop %.2f projection %.2f contact %.2f kps %.2f similarity+rest %.2f" % (d(500, 40), d(40, 41), d(41, 42), d(42, 43), d(43, 501)))
     if rep == 3:
         st, en = a[100:560], a[560:1020]
         hit = (en > st) & (st > 0)
