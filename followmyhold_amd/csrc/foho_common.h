@@ -243,6 +243,10 @@ __device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf
 
 // d(seg_d2)/d(a,b) with the projection parameter held constant (envelope; pytorch3d
 // PointLineDistanceBackward).  Accumulates g * d(dist)/d(.) into ga[2], gb[2].
+// a / b through v_rcp_f32 (1 ulp) for GRADIENT arithmetic only: parity there is 1e-4 relative, and the correctly
+// rounded division costs ~10 instructions.  Everything that decides a face index, a depth or a tie stays exact.
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 __device__ __forceinline__ void seg_d2_bwd(float px, float py, float ax, float ay, float bx, float by, float g,
                                            float* ga, float* gb) {
     const float bax = bx - ax, bay = by - ay;
@@ -252,7 +256,7 @@ __device__ __forceinline__ void seg_d2_bwd(float px, float py, float ax, float a
         gb[1] += g * 2.0f * (by - py);
         return;
     }
-    float t = (bax * (px - ax) + bay * (py - ay)) / l2;
+    float t = fdiv(bax * (px - ax) + bay * (py - ay), l2);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float dx = (ax + t * bax) - px, dy = (ay + t * bay) - py;
     ga[0] += g * 2.0f * dx * (1.0f - t);
@@ -271,15 +275,15 @@ __device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, floa
     const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
     const float e0 = edge_fn(xf, yf, x1, y1, x2, y2), e1 = edge_fn(xf, yf, x2, y2, x0, y0),
                 e2 = edge_fn(xf, yf, x0, y0, x1, y1);
-    const float a0 = e0 / area, a1 = e1 / area, a2 = e2 / area;
+    const float a0 = fdiv(e0, area), a1 = fdiv(e1, area), a2 = fdiv(e2, area);
     const float t0 = a0 * z1 * z2, t1 = z0 * a1 * z2, t2 = z0 * z1 * a2;
     const float tsum = t0 + t1 + t2;
     const float den = fmaxf(tsum, K_EPS);
-    const float w0 = t0 / den, w1 = t1 / den, w2 = t2 / den;
+    const float w0 = fdiv(t0, den), w1 = fdiv(t1, den), w2 = fdiv(t2, den);
     const float cp0 = fmaxf(w0, 0.0f), cp1 = fmaxf(w1, 0.0f), cp2 = fmaxf(w2, 0.0f);
     const float csum = cp0 + cp1 + cp2;
     const float s = fmaxf(csum, 1e-5f);
-    const float c0 = cp0 / s, c1 = cp1 / s, c2 = cp2 / s;
+    const float c0 = fdiv(cp0, s), c1 = fdiv(cp1, s), c2 = fdiv(cp2, s);
     const bool inside = (w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f);
 
     if (g_z != 0.0f || g_cin[0] != 0.0f || g_cin[1] != 0.0f || g_cin[2] != 0.0f) {
@@ -290,26 +294,26 @@ __device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, floa
         float gcp0, gcp1, gcp2;
         if (csum >= 1e-5f) {
             const float dot = gc0 * c0 + gc1 * c1 + gc2 * c2;
-            gcp0 = (gc0 - dot) / s;
-            gcp1 = (gc1 - dot) / s;
-            gcp2 = (gc2 - dot) / s;
+            gcp0 = fdiv(gc0 - dot, s);
+            gcp1 = fdiv(gc1 - dot, s);
+            gcp2 = fdiv(gc2 - dot, s);
         } else {
-            gcp0 = gc0 / s;
-            gcp1 = gc1 / s;
-            gcp2 = gc2 / s;
+            gcp0 = fdiv(gc0, s);
+            gcp1 = fdiv(gc1, s);
+            gcp2 = fdiv(gc2, s);
         }
         const float gw0 = (w0 >= 0.0f) ? gcp0 : 0.0f, gw1 = (w1 >= 0.0f) ? gcp1 : 0.0f, gw2 = (w2 >= 0.0f) ? gcp2 : 0.0f;
         // w = t / den
         float gt0, gt1, gt2;
         if (tsum >= K_EPS) {
             const float dot = gw0 * w0 + gw1 * w1 + gw2 * w2;
-            gt0 = (gw0 - dot) / den;
-            gt1 = (gw1 - dot) / den;
-            gt2 = (gw2 - dot) / den;
+            gt0 = fdiv(gw0 - dot, den);
+            gt1 = fdiv(gw1 - dot, den);
+            gt2 = fdiv(gw2 - dot, den);
         } else {
-            gt0 = gw0 / den;
-            gt1 = gw1 / den;
-            gt2 = gw2 / den;
+            gt0 = fdiv(gw0, den);
+            gt1 = fdiv(gw1, den);
+            gt2 = fdiv(gw2, den);
         }
         const float ga0 = gt0 * z1 * z2, ga1 = gt1 * z0 * z2, ga2 = gt2 * z0 * z1;
         gz1 += gt0 * a0 * z2;
@@ -318,8 +322,8 @@ __device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, floa
         gz2 += gt1 * z0 * a1;
         gz0 += gt2 * z1 * a2;
         gz1 += gt2 * z0 * a2;
-        const float ge0 = ga0 / area, ge1 = ga1 / area, ge2 = ga2 / area;
-        const float garea = -(ga0 * a0 + ga1 * a1 + ga2 * a2) / area;
+        const float ge0 = fdiv(ga0, area), ge1 = fdiv(ga1, area), ge2 = fdiv(ga2, area);
+        const float garea = -fdiv(ga0 * a0 + ga1 * a1 + ga2 * a2, area);
         // e0 = E(p; v1, v2)
         gv[3] += ge0 * (yf - y2);
         gv[4] += ge0 * (x2 - xf);
