@@ -130,6 +130,41 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
     __syncthreads();
 }
 
+// sum over the 16 lanes of a DPP row (butterfly: every lane of the row ends up with the row total)
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __int_as_float(dpp_mov<0xB1, 0xf>(0, __float_as_int(x)));   // quad_perm [1,0,3,2]
+    x += __int_as_float(dpp_mov<0x4E, 0xf>(0, __float_as_int(x)));   // quad_perm [2,3,0,1]
+    x += __int_as_float(dpp_mov<0x124, 0xf>(0, __float_as_int(x)));  // row_ror:4
+    x += __int_as_float(dpp_mov<0x128, 0xf>(0, __float_as_int(x)));  // row_ror:8
+    return x;
+}
+
+// Block-wide sums of NV values for 256-thread workgroups, result in LDS: out[k] (k < NV) after the call.  Four DPP
+// steps reduce inside each row of 16 lanes, the 16 row totals go through LDS and lane k adds them up -- the
+// row_bcast / readlane tail of a full wave reduction costs more than the LDS round trip when NV is large.
+// `red` = NV * 16 floats.
+template <int NV>
+__device__ __forceinline__ void block_sum_lds(const float (&v)[NV], float* red, float* out) {
+    const int row = threadIdx.x >> 4;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const float s = row16_sum(v[k]);
+        if ((threadIdx.x & 15) == 0) red[k * 16 + row] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const float* r = red + threadIdx.x * 16;
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) t[j] = r[j];
+        float s = t[0];
+#pragma unroll
+        for (int j = 1; j < 16; j++) s += t[j];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 // (value, index) arg-min / arg-max; ties keep the lower index (torch.min(dim) on CPU returns the first)
 struct ValIdx {
     float v;

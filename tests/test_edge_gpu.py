@@ -71,13 +71,19 @@ def test_hand_only_scene_without_object():
     gb = E.GuidanceBatch([sc0], grid_res=16, n_renders=1)
     cfg, _ = E.phase_cfg("A", do_update=True)
     for g in (ref, gb):
-        for _ in range(3):
-            g.step(cfg)
+        g.step(cfg)
     torch.cuda.synchronize()
     gb.raise_on_flags()
-    # phase A only looks at the hand: the result must not depend on the presence of an object mesh
-    assert np.allclose(gb.params.cpu().numpy()[:, :8], ref.params.cpu().numpy()[:, :8], atol=1e-6)
-    assert abs(gb.loss_dict(0)["total"] - ref.loss_dict(0)["total"]) <= 1e-5 * abs(ref.loss_dict(0)["total"])
+    # phase A only looks at the hand: loss, gradient and the first update must not depend on the presence of an object
+    # mesh (one iteration: over several, Adam amplifies the 1e-7 noise of the atomic gradient sums)
+    ga_, gb_ = ref.grad_params.cpu().numpy()[0, :8], gb.grad_params.cpu().numpy()[0, :8]
+    assert np.linalg.norm(ga_ - gb_) <= 1e-4 * np.linalg.norm(ga_)
+    assert abs(gb.loss_dict(0)["total"] - ref.loss_dict(0)["total"]) <= 1e-6 * abs(ref.loss_dict(0)["total"])
+    assert np.allclose(gb.params.cpu().numpy()[:, :8], ref.params.cpu().numpy()[:, :8], atol=2e-5)
+    for _ in range(5):
+        gb.step(cfg)
+    torch.cuda.synchronize()
+    assert np.isfinite(gb.params.cpu().numpy()).all() and int(gb.flags[0]) == 0
 
 
 @gpu
