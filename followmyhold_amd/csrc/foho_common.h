@@ -67,6 +67,18 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
     FOHO_DPP_REDUCE(unsigned, v, 0u, FOHO_OP_MAXU, FOHO_MOV_U);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// inclusive prefix sum over the 64 lanes of a wave (DPP: shifts inside each row of 16, then row_bcast:15 adds row r's
+// total to row r+1 for rows 1 and 3, row_bcast:31 adds the total of the first 32 lanes to the last 32).  Whole wave.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
+    x += (unsigned)dpp_mov<0x111, 0xf>(0, (int)x);  // row_shr:1
+    x += (unsigned)dpp_mov<0x112, 0xf>(0, (int)x);  // row_shr:2
+    x += (unsigned)dpp_mov<0x114, 0xf>(0, (int)x);  // row_shr:4
+    x += (unsigned)dpp_mov<0x118, 0xf>(0, (int)x);  // row_shr:8
+    x += (unsigned)dpp_mov<0x142, 0xa>(0, (int)x);  // row_bcast:15 -> rows 1, 3
+    x += (unsigned)dpp_mov<0x143, 0xc>(0, (int)x);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // doubles move as two 32-bit halves
 template <int CTRL, int RMASK>
 __device__ __forceinline__ double dpp_mov_d(double ident, double x) {
@@ -204,7 +216,11 @@ __device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
     float range = 2.0f;
     if (S1 > S2) range = ((float)S1 * range) / (float)S2;
     const float offset = range / 2.0f;
-    return -offset + (range * (float)i + offset) / (float)S1;
+    const float num = range * (float)i + offset;
+    // dividing by a power of two is exact, so multiplying by its (exact) reciprocal gives the same bits without the
+    // ~10-instruction correctly rounded division; 512x512 images take this path (wave-uniform branch)
+    const float q = ((S1 & (S1 - 1)) == 0) ? num * (1.0f / (float)S1) : num / (float)S1;
+    return -offset + q;
 }
 
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
