@@ -4,6 +4,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+from followmyhold_amd import _lib as L_
+L_.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")  # ablation hooks live in the STAMPS build
 from followmyhold_amd import engine as E, synthetic
 sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512, seed=0)
 gb = E.GuidanceBatch([sc]); cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
