@@ -73,8 +73,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=0, help="independent image groups, one HIP stream + hipGraph each "
+                    "(0 = auto: 1 below 4 images per GPU, 2 below 16, else 4)")
     ap.add_argument("--obj", default="20k", choices=["ico4", "20k", "40k"])
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--joint-graph", action="store_true", help="one hipGraph with a branch per stream instead of one graph "
+                    "per stream (measured slower on ROCm 7.2)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -114,13 +118,13 @@ def main():
     render_fn = E.hip_render_fn(dev)
     # image-sharded: global image index = rank * ipg + j (seed per image)
     scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=rank * ipg + j) for j in range(ipg)]
-    gb = E.GuidanceBatch(scenes, device=dev)
+    n_streams = args.streams if args.streams > 0 else (1 if ipg < 4 else (2 if ipg < 16 else 4))
+    group = E.GuidanceGroup(scenes, n_streams, device=dev)
+    gb = group.batches[0]
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
-    gb.reset_optimizer()
-
-    graph = None if args.no_graph else gb.capture(cfg)
-    ident = gb.params.clone()
-    ident[:] = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
+    if not args.no_graph:
+        group.capture(cfg, joint=args.joint_graph)
+    ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
 
     def new_denoise_step():
         """Every CFG.joint_iters = 50 iterations the reference starts a new denoising step with a fresh AdamW
@@ -128,17 +132,13 @@ def main():
         workload stays the configs[1] scene instead of whatever the synthetic optimisation drifts to (with the
         reference's learning rates the synthetic object shrinks away after ~150 iterations, which would make the
         rasteriser's job easier than the benchmark claims)."""
-        gb.params.copy_(ident)
-        gb.reset_optimizer()
+        group.restart(ident)
 
     def run_steps(n):
         for i in range(n):
             if i % 50 == 0:
                 new_denoise_step()
-            if graph is not None:
-                graph.replay()
-            else:
-                gb.step(cfg)
+            group.step(cfg)
 
     run_steps(50)            # setup: let clocks / caches settle before the counted warm-up
     torch.cuda.synchronize(dev)
@@ -155,13 +155,15 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     # end-of-batch metrics all-reduce (the only collective of the path)
-    metrics = sharding.local_metrics(gb, n_steps=args.steps, wall_ms=dt * 1e3)
+    metrics = sum(sharding.local_metrics(g, n_steps=args.steps, wall_ms=dt * 1e3 if i == 0 else 0.0)
+                  for i, g in enumerate(group.batches))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         metrics = sharding.all_reduce_metrics(metrics, dist)
     dt = float(tmax.item())
-    flags = gb.raise_on_flags()
+    for g in group.batches:
+        g.raise_on_flags()
 
     m0 = gb.meta[0]
     value = world * ipg * args.steps / dt
@@ -172,7 +174,7 @@ def main():
         "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
                                f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
-                   "hip_graph": graph is not None, "restart_every": 50},
+                   "hip_graph": not args.no_graph, "streams": len(group.batches), "restart_every": 50},
         "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[-2]),
     }
 
@@ -181,6 +183,7 @@ def main():
         acc = {}
         nprof = 20
         run_steps(25)            # profile in the middle of a 50-iteration window
+        torch.cuda.synchronize(dev)
         cfg_frozen, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
         for _ in range(nprof):
             for k, v in gb.step_profiled(cfg_frozen).items():
@@ -190,18 +193,19 @@ def main():
         bstep = algorithmic_bytes(H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
         if kb is None:
             kb = bstep
-        achieved = kb * ipg / (acc[dom] * 1e-3) / 1e9
+        ipb = gb.B               # images in the profiled batch (the first stream's)
+        achieved = kb * ipb / (acc[dom] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom) if ipg == 1 else None,
                            "traffic_source": "profiles/r01_rocprofv3_pmc_fetch_write_b1.csv (2*FETCH_SIZE+WRITE_SIZE, KiB)",
                            "kernel_ms": acc[dom],
-                           "algorithmic_bytes_per_launch": kb * ipg}
+                           "algorithmic_bytes_per_launch": kb * ipb}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
         out["kernels"] = {}
         for k, v in acc.items():           # every launch of the step against the HBM roofline (algorithmic bytes / duration)
             kbk = kernel_bytes(k, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"]) or 0
-            gbs = kbk * ipg / (v * 1e-3) / 1e9
-            out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipg / 1e6, 3), "GBs": round(gbs, 1),
+            gbs = kbk * ipb / (v * 1e-3) / 1e9
+            out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipb / 1e6, 3), "GBs": round(gbs, 1),
                                  "frac": round(gbs / HBM_PEAK_GBS, 4)}
         out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
         out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
