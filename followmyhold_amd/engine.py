@@ -357,10 +357,13 @@ class GuidanceBatch:
         NaN break, intersection-weight gate and Adam state all live on the device)."""
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
+        state = [t.clone() for t in (self.params, self.adam_m, self.adam_v, self.adam_t, self.flags)]
         with torch.cuda.stream(s):
-            self.step(cfg)  # warm-up launch outside capture (module load)
+            self.step(cfg)  # warm-up launch outside capture (module load); its optimiser update is undone below
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
+        for t, saved in zip((self.params, self.adam_m, self.adam_v, self.adam_t, self.flags), state):
+            t.copy_(saved)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(steps_per_graph):
