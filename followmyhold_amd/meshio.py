@@ -138,10 +138,14 @@ def save_obj(path, verts, faces):
 
 
 def load_mesh(path):
-    """Dispatch on the extension like trimesh.load(process=False) for the two formats the path uses."""
+    """Dispatch on the extension like trimesh.load(process=False) / pytorch3d's IO for the formats the path uses
+    (.glb: the MoGe image mesh, PL:1247-1250)."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".ply":
         return load_ply(path)
     if ext == ".obj":
         return load_obj(path)
-    raise ValueError(f"unsupported mesh format '{ext}' ({path}); supported: .ply, .obj")
+    if ext == ".glb":
+        from .inputs import load_glb
+        return load_glb(path)
+    raise ValueError(f"unsupported mesh format '{ext}' ({path}); supported: .ply, .obj, .glb")

@@ -99,8 +99,13 @@ def test_meshio_roundtrip(tmp_path):
     meshio.save_obj(p, v, f)
     v2, f2 = meshio.load_mesh(p)
     assert np.allclose(v2, v, atol=1e-6) and np.array_equal(f2, f)
+    from followmyhold_amd import inputs
+    p = str(tmp_path / "m.glb")
+    inputs.save_glb(p, v, f)
+    v2, f2 = meshio.load_mesh(p)
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)
     with pytest.raises(ValueError):
-        meshio.load_mesh(str(tmp_path / "x.glb"))
+        meshio.load_mesh(str(tmp_path / "x.stl"))
 
 
 def test_image_sharding_is_a_partition():
