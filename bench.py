@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--joint-graph", action="store_true", help="one hipGraph with a branch per stream instead of one graph "
                     "per stream (measured slower on ROCm 7.2)")
+    ap.add_argument("--steps-per-graph", type=int, default=0, help="cap on the iterations captured per hipGraph (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -122,8 +123,17 @@ def main():
     group = E.GuidanceGroup(scenes, n_streams, device=dev)
     gb = group.batches[0]
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    # iterations per hipGraph: the reference's inner loop is 50 iterations per denoising step, and nothing in the step
+    # needs the host, so a slice of that loop is ONE graph replay (no host work between iterations)
+    spg = 1
+    if not args.no_graph and not args.joint_graph:
+        for cand in (50, 25, 10, 5):
+            if args.steps % cand == 0:
+                spg = cand
+                break
+        spg = min(spg, args.steps_per_graph) if args.steps_per_graph > 0 else spg
     if not args.no_graph:
-        group.capture(cfg, joint=args.joint_graph)
+        group.capture(cfg, joint=args.joint_graph, steps_per_graph=spg)
     ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
 
     def new_denoise_step():
@@ -135,10 +145,12 @@ def main():
         group.restart(ident)
 
     def run_steps(n):
-        for i in range(n):
-            if i % 50 == 0:
-                new_denoise_step()
-            group.step(cfg)
+        done = 0
+        while done < n:
+            new_denoise_step()                  # every 50 iterations
+            k = min(50, n - done)
+            group.run(cfg, k)
+            done += k
 
     run_steps(50)            # setup: let clocks / caches settle before the counted warm-up
     torch.cuda.synchronize(dev)
@@ -174,7 +186,8 @@ def main():
         "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
                                f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
-                   "hip_graph": not args.no_graph, "streams": len(group.batches), "restart_every": 50},
+                   "hip_graph": not args.no_graph, "steps_per_graph": spg, "streams": len(group.batches),
+                   "restart_every": 50},
         "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[-2]),
     }
 

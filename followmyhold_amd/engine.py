@@ -400,17 +400,17 @@ class GuidanceGroup:
         self.device = torch.device(device)
         self.batches = [GuidanceBatch(c, device=device, **kw) for c in chunks]
         self.streams = [torch.cuda.Stream(self.device) for _ in chunks]
-        self.graphs, self.joint, self.main = [], None, None
+        self.graphs, self.joint, self.main, self.multi, self.steps_per_graph = [], None, None, [], 1
 
     @property
     def B(self):
         return sum(gb.B for gb in self.batches)
 
-    def capture(self, cfg, joint=False):
+    def capture(self, cfg, joint=False, steps_per_graph=1):
         """joint=False (default): one hipGraph per stream, replayed one after the other from the host.  joint=True: ONE
         hipGraph whose branches are the batches (forked from / joined to the capture stream), a single replay per
         step -- measured slower on ROCm 7.2 (8 images: 33.7k vs 37.6k steps/s), the branches do not overlap as well."""
-        self.graphs, self.joint = [], None
+        self.graphs, self.joint, self.multi = [], None, []
         if joint and len(self.batches) > 1:
             main = torch.cuda.Stream(self.device)
             for gb, st in zip(self.batches, self.streams):      # warm-up launches outside the capture (module load)
@@ -430,7 +430,22 @@ class GuidanceGroup:
             for gb, st in zip(self.batches, self.streams):
                 with torch.cuda.stream(st):
                     self.graphs.append(gb.capture(cfg))
+                    if steps_per_graph > 1:   # a whole inner loop (or a slice of it) as one replay: no host work in between
+                        self.multi.append(gb.capture(cfg, steps_per_graph=steps_per_graph))
+            self.steps_per_graph = steps_per_graph if steps_per_graph > 1 else 1
         torch.cuda.synchronize(self.device)
+
+    def run(self, cfg, n):
+        """n iterations of every batch: multi-iteration graphs while they fit, single-iteration replays for the rest."""
+        k = getattr(self, "steps_per_graph", 1)
+        done = 0
+        while k > 1 and self.multi and n - done >= k:
+            for g, st in zip(self.multi, self.streams):
+                with torch.cuda.stream(st):
+                    g.replay()
+            done += k
+        for _ in range(n - done):
+            self.step(cfg)
 
     def step(self, cfg):
         """One iteration of every batch: graph replay when captured, eager launches otherwise."""
