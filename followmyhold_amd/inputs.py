@@ -257,9 +257,11 @@ def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None
         cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=denoise_i, do_update=True)
         gb.set_n_renders(n_renders)
         gb.reset_optimizer()
-        graph = gb.capture(cfg) if capture else None
+        iters_ = int(iters)
+        spg = max([d for d in range(1, 51) if iters_ % d == 0]) if iters_ > 0 else 1   # iterations per hipGraph replay
+        graph = gb.capture(cfg, steps_per_graph=spg) if capture else None
         gb.reset_optimizer()
-        for _ in range(int(iters)):
+        for _ in range(iters_ // spg if graph is not None else iters_):
             graph.replay() if graph is not None else gb.step(cfg)
         torch.cuda.synchronize(gb.device)
         gb.raise_on_flags()
