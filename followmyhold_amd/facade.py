@@ -330,3 +330,31 @@ def get_sdf_of_meshes(mesh1: Meshes, mesh2: Meshes, device, resolution=64):
     grid, _, _ = generate_dense_grid_points(bmin, bmax, 5, "ij", resolution)
     grid = torch.from_numpy(grid).to(a.device)
     return mesh2sdf(mesh1, grid, device, resolution), mesh2sdf(mesh2, grid, device, resolution)
+
+
+class FlexiCubes:
+    """kaolin.non_commercial.FlexiCubes as the pipeline uses it (pipelines.py:1142-1143, 1393, 1509): default weights, no
+    training mode -- Dual Marching Cubes on the regular grid, differentiable w.r.t. the SDF (libfoho_hip: k_flexi.inc)."""
+
+    _CORNERS = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+
+    def __init__(self, device="cuda", **_):
+        self.device = torch.device(device)
+
+    def construct_voxel_grid(self, res):
+        """((res+1)^3, 3) grid points in [-0.5, 0.5]^3 (x-major) and the (res^3, 8) corner indices of the cubes."""
+        G = res + 1
+        lin = torch.linspace(-0.5, 0.5, G, device=self.device)
+        xs, ys, zs = torch.meshgrid(lin, lin, lin, indexing="ij")
+        verts = torch.stack([xs, ys, zs], -1).reshape(-1, 3)
+        i, j, k = torch.meshgrid(*([torch.arange(res, device=self.device)] * 3), indexing="ij")
+        base = ((i * G + j) * G + k).reshape(-1)
+        offs = torch.tensor([(cx * G + cy) * G + cz for cx, cy, cz in self._CORNERS], device=self.device)
+        return verts, base[:, None] + offs[None, :]
+
+    def __call__(self, x_nx3, s_n, cube_fx8, res, beta_fx12=None, alpha_fx8=None, gamma_f=None, training=False, **_):
+        if beta_fx12 is not None or alpha_fx8 is not None or gamma_f is not None or training:
+            raise NotImplementedError("only the default-weight call of pipelines.py:1393 / 1509 is implemented")
+        if cube_fx8 is not None and cube_fx8.shape[0] != res ** 3:
+            raise ValueError("cube_fx8 must be the regular grid of construct_voxel_grid(res)")
+        return ops.flexicubes(x_nx3, s_n, int(res))

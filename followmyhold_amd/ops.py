@@ -183,3 +183,59 @@ def icp_points(source_points, target_points, n_iter, n_outliers=0, fixed_scale=F
     torch.cuda.synchronize(src.device)
     out = (T.cpu().numpy().reshape(4, 4), float(cost.item()))
     return out + (hist.cpu().numpy()[:n_iter],) if return_history else out
+
+
+# ------------------------------------------------------------------------------------------------ iso-surfacing
+class _FlexiFn(torch.autograd.Function):
+    """kaolin FlexiCubes.__call__ with default weights (pipelines.py:1393, 1509): differentiable w.r.t. the SDF and the
+    grid positions through the edge crossings."""
+
+    @staticmethod
+    def forward(ctx, x, s, res, verts_cap, faces_cap):
+        _need_cuda(x, s)
+        lib = L.lib()
+        xx, ss = _f32(x), _f32(s).reshape(-1)
+        G = res + 1
+        if xx.shape != (G ** 3, 3) or ss.numel() != G ** 3:
+            raise L.FohoError(f"flexicubes: expected {(G ** 3, 3)} grid positions and {G ** 3} SDF values")
+        dev = xx.device
+        lib.foho_flexi_workspace_bytes.restype = ctypes.c_size_t
+        nws = lib.foho_flexi_workspace_bytes(res)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        counts = torch.zeros(3, dtype=torch.int32, device=dev)
+        while True:
+            verts = torch.empty(verts_cap, 3, device=dev)
+            faces = torch.empty(faces_cap, 3, dtype=torch.int64, device=dev)
+            ldev = torch.empty(verts_cap, device=dev)
+            L.check(lib.foho_flexi_fwd(P(xx.data_ptr()), P(ss.data_ptr()), res, P(verts.data_ptr()), verts_cap,
+                                       P(faces.data_ptr()), faces_cap, P(ldev.data_ptr()), P(counts.data_ptr()),
+                                       P(ws.data_ptr()), ctypes.c_size_t(nws), _stream(xx)), "foho_flexi_fwd")
+            nv, nf, over = counts.tolist()           # the output sizes are data dependent: one host sync per extraction
+            if not over:
+                break
+            verts_cap, faces_cap = max(verts_cap, nv), max(faces_cap, nf)
+        ctx.save_for_backward(xx, ss)
+        ctx.res, ctx.ws, ctx.nv = res, ws, nv
+        ctx.need_x = x.requires_grad
+        f_out, l_out = faces[:nf], ldev[:nv]
+        ctx.mark_non_differentiable(f_out, l_out)
+        return verts[:nv], f_out, l_out
+
+    @staticmethod
+    def backward(ctx, g_verts, _gf, _gl):
+        xx, ss = ctx.saved_tensors
+        lib = L.lib()
+        g = _f32(g_verts)
+        gs = torch.zeros_like(ss)
+        gx = torch.zeros_like(xx) if ctx.need_x else None
+        L.check(lib.foho_flexi_bwd(P(xx.data_ptr()), P(ss.data_ptr()), ctx.res, P(g.data_ptr()), ctx.nv, P(gs.data_ptr()),
+                                   P(gx.data_ptr()) if gx is not None else None, P(ctx.ws.data_ptr()),
+                                   ctypes.c_size_t(ctx.ws.numel()), _stream(xx)), "foho_flexi_bwd")
+        return gx, gs, None, None, None
+
+
+def flexicubes(x, s, res, verts_cap=None, faces_cap=None):
+    """(verts (V,3), faces (F,3) int64, l_dev (V,)) of the zero level set of s on the regular (res+1)^3 grid x."""
+    verts_cap = verts_cap or 16 * res * res
+    faces_cap = faces_cap or 32 * res * res
+    return _FlexiFn.apply(x, s, int(res), int(verts_cap), int(faces_cap))

@@ -225,6 +225,20 @@ int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int
                  int32_t fixed_scale, double min_scale, double max_scale, double* T_out, double* cost_out,
                  double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- iso-surfacing between the diffusion latent and the guidance path ----------------
+ * kaolin FlexiCubes.__call__(x_nx3, s_n, cube_fx8, res) with default weights, as called at pipelines.py:1393 / 1509
+ * = Dual Marching Cubes on the regular (res+1)^3 grid: x (G^3,3) grid positions and s (G^3) SDF (negative inside),
+ * grid point (i,j,k) at (i*G + j)*G + k (generate_dense_grid_points, PL:341-360).  Outputs: verts (up to verts_cap x 3),
+ * faces (up to faces_cap x 3, int64, outward orientation), l_dev per vertex (optional), counts (device int32[3]:
+ * vertices, triangles, overflow bits -- bit0 vertex capacity, bit1 face capacity).  Vertex order: (cube, patch); face
+ * order: (axis, i, j, k) of the sign-change grid edge.  The workspace keeps what foho_flexi_bwd needs. */
+size_t foho_flexi_workspace_bytes(int32_t res);
+int foho_flexi_fwd(const float* x, const float* s, int32_t res, float* verts, int32_t verts_cap, int64_t* faces,
+                   int32_t faces_cap, float* l_dev, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_s (G^3) and optional grad_x (G^3,3) must be zeroed by the caller; accumulated with float atomics. */
+int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* grad_verts, int32_t n_verts, float* grad_s,
+                   float* grad_x, const void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

