@@ -224,6 +224,7 @@ class GuidanceBatch:
         self.inc_off, self.inc_fc = t(inc_off, torch.int32), t(inc_fc, torch.int32)
         self.nbr_off, self.nbr_idx = t(nbr_off, torch.int32), t(nbr_idx, torch.int32)
         self.J = t(np.asarray(scenes[0]["J_regressor"], np.float32), torch.float32)
+        self._images_host = images
         img_bytes = b"".join(bytes(im) for im in images)
         self.images = torch.frombuffer(bytearray(img_bytes), dtype=torch.uint8).to(dev)
         self.tgt_normal = t(np.stack([s["moge_normal"] for s in scenes]), torch.float32)
@@ -320,6 +321,65 @@ class GuidanceBatch:
                 "foho_step_run(BBOX)")
         self._bbox_dirty = False
 
+    def update_object(self, verts, faces):
+        """New object mesh with a NEW TOPOLOGY (the FlexiCubes output of this iteration, PL:1393 / 1509) for a one-image
+        batch -- the reference's batch size.  The topology tables (vertex -> incident faces in pytorch3d's index_add
+        order, unique edges, neighbour lists) are rebuilt on the GPU with sorts; one host read-back for the edge count.
+        The next step recomputes the cached AABB and clears the rasteriser's planes (FOHO_STAGE_BBOX)."""
+        if self.B != 1:
+            raise L.FohoError("update_object: topology updates are implemented for one-image batches")
+        dev = self.device
+        v = torch.as_tensor(verts, dtype=torch.float32, device=dev).detach().reshape(-1, 3).contiguous()
+        f = torch.as_tensor(faces, device=dev).detach().to(torch.int64).reshape(-1, 3)
+        m = self.meta[0]
+        Vh, Fh = m["Vh"], m["Fh"]
+        Vo, Fo = int(v.shape[0]), int(f.shape[0])
+        Vtot, Ftot = Vh + Vo, Fh + Fo
+        self.verts_in = torch.cat([self.verts_in[:Vh], v], 0).contiguous()
+        faces_all = torch.cat([self.faces[:Fh].to(torch.int64), f + Vh], 0)
+        self.faces = faces_all.to(torch.int32).contiguous()
+        # vertex -> (face << 2 | corner), ordered by (vertex, corner, face): unique keys, one sort
+        vv = faces_all.t().reshape(-1)
+        corner = torch.arange(3, device=dev).repeat_interleave(Ftot)
+        face = torch.arange(Ftot, device=dev).repeat(3)
+        order = torch.argsort((vv * 3 + corner) * Ftot + face)
+        self.inc_fc = ((face[order] << 2) | corner[order]).to(torch.int32).contiguous()
+        off = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.bincount(vv, minlength=Vtot).cumsum(0)
+        self.inc_off = off.to(torch.int32).contiguous()
+        # unique undirected edges of the OBJECT mesh (pytorch3d edges_packed) and the neighbour lists over them
+        fo = f + Vh
+        e = torch.cat([fo[:, [0, 1]], fo[:, [1, 2]], fo[:, [2, 0]]], 0)
+        key = torch.unique(e.min(1).values * Vtot + e.max(1).values)
+        ea, eb = key // Vtot, key % Vtot
+        n_edges = int(key.numel())
+        src, dst = torch.cat([ea, eb]), torch.cat([eb, ea])
+        order = torch.argsort(src * Vtot + dst)
+        noff = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
+        noff[1:] = torch.bincount(src, minlength=Vtot).cumsum(0)
+        self.nbr_off = noff.to(torch.int32).contiguous()
+        self.nbr_idx = (dst[order] if n_edges else torch.zeros(1, dtype=torch.int64, device=dev)).to(torch.int32).contiguous()
+        # image record, sizes, outputs
+        im = self._images_host[0]
+        im.Vo, im.Fo, im.n_edges = Vo, Fo, n_edges
+        self.images = torch.frombuffer(bytearray(bytes(im)), dtype=torch.uint8).to(dev)
+        m.update(Vo=Vo, Fo=Fo, n_edges=n_edges)
+        self.Vtot, self.Ftot = Vtot, Ftot
+        d = self.dims
+        d.Vtot, d.Ftot, d.Vmax, d.Fmax, d.Vo_max, d.Fo_max = Vtot, Ftot, Vtot, Ftot, Vo, Fo
+        self.grad_verts_in = torch.zeros(Vtot, 3, device=dev)
+        need = int(self.lib.foho_step_workspace_bytes(ctypes.byref(d)))
+        if need > self.workspace.numel():
+            self.workspace = torch.zeros(int(need * 1.25), dtype=torch.uint8, device=dev)   # head-room: sizes drift slowly
+        self._desc = None
+        self._bbox_dirty = True     # the workspace layout moved with the sizes: AABB + clean scatter planes again
+
+    def objective(self, verts, faces, cfg):
+        """Differentiable scalar: total loss of one iteration on the object mesh (verts, faces); backward() delivers
+        dL/d verts (so that an upstream FlexiCubes / VAE receives its gradient, PL:1600).  The pose parameters are
+        updated by the iteration when cfg.do_update is set, exactly like gb.step()."""
+        return _ObjectiveFn.apply(verts, faces, self, cfg)
+
     def grad_obj_verts(self, b):
         m = self.meta[b]
         lo = m["v_off"] + m["Vh"]
@@ -383,6 +443,19 @@ class GuidanceBatch:
                 "foho_step_run_profiled")
         names = [lib.foho_kernel_name(i).decode() for i in range(L.N_KERNELS)]
         return {n: float(ms[i]) for i, n in enumerate(names) if n}
+
+
+class _ObjectiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces, gb, cfg):
+        gb.update_object(verts, faces)
+        gb.step(cfg)
+        ctx.gb = gb
+        return gb.losses[0, 0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.gb.grad_obj_verts(0) * g, None, None, None
 
 
 class GuidanceGroup:
