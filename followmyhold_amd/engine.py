@@ -486,9 +486,14 @@ class GuidanceGroup:
         self.graphs, self.joint, self.multi = [], None, []
         if joint and len(self.batches) > 1:
             main = torch.cuda.Stream(self.device)
+            saved = [[t.clone() for t in (gb.params, gb.adam_m, gb.adam_v, gb.adam_t, gb.flags)] for gb in self.batches]
             for gb, st in zip(self.batches, self.streams):      # warm-up launches outside the capture (module load)
                 with torch.cuda.stream(st):
                     gb.step(cfg)
+            torch.cuda.synchronize(self.device)
+            for gb, sv in zip(self.batches, saved):             # ... whose optimiser update is undone
+                for t, s0 in zip((gb.params, gb.adam_m, gb.adam_v, gb.adam_t, gb.flags), sv):
+                    t.copy_(s0)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=main):

@@ -320,3 +320,40 @@ def test_graph_replay_equals_eager_launches():
     fc = gb_.region("frac_count", torch.int32).cpu().numpy()
     assert fc[0] == 0 and 0 < fc[1] < gb_.dims.frac_cap     # only the hand+object render carries the silhouette
     assert int(gb_.adam_t[0]) == 43 and np.isfinite(gb_.loss_dict(0)["total"])
+
+
+@gpu
+def test_multi_iteration_graph_and_stream_groups_equal_plain_stepping():
+    """A slice of the inner loop captured as ONE hipGraph, and images split over several streams (GuidanceGroup), give
+    what plain eager stepping of one batch gives (2 iterations: beyond that Adam amplifies the atomic-sum noise)."""
+    from followmyhold_amd import engine as E
+    scenes = [_np_scene(make_scene("ico2", 64, 64, seed=s)) for s in (11, 12, 13)]
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    ref = E.GuidanceBatch(scenes, grid_res=16)
+    for _ in range(2):
+        ref.step(cfg)
+    torch.cuda.synchronize()
+    ref_p, ref_l = ref.params.cpu().numpy(), ref.losses[:, 0].cpu().numpy()
+    # (a) two iterations in one graph
+    ga = E.GuidanceBatch(scenes, grid_res=16)
+    g2 = ga.capture(cfg, steps_per_graph=2)
+    assert int(ga.adam_t[0]) == 0                        # capture leaves the optimiser state untouched
+    g2.replay()
+    torch.cuda.synchronize()
+    assert int(ga.adam_t[0]) == 2
+    assert np.allclose(ga.params.cpu().numpy(), ref_p, atol=2e-4)
+    assert np.allclose(ga.losses[:, 0].cpu().numpy(), ref_l, rtol=1e-3)
+    # (b) three images on two streams (batches of 2 + 1), separate graphs and the joint graph
+    for joint in (False, True):
+        grp = E.GuidanceGroup(scenes, n_streams=2, grid_res=16)
+        assert [b.B for b in grp.batches] == [2, 1] and grp.B == 3
+        grp.capture(cfg, joint=joint, steps_per_graph=1 if joint else 2)
+        grp.run(cfg, 2)
+        grp.synchronize()
+        torch.cuda.synchronize()
+        p = np.concatenate([b.params.cpu().numpy() for b in grp.batches])
+        l = np.concatenate([b.losses[:, 0].cpu().numpy() for b in grp.batches])
+        assert np.allclose(p, ref_p, atol=2e-4), joint
+        assert np.allclose(l, ref_l, rtol=1e-3), joint
+        for b in grp.batches:
+            b.raise_on_flags()
