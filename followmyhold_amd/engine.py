@@ -321,10 +321,11 @@ class GuidanceBatch:
                 "foho_step_run(BBOX)")
         self._bbox_dirty = False
 
-    def update_object(self, verts, faces):
+    def update_object(self, verts, faces, assume_manifold=True):
         """New object mesh with a NEW TOPOLOGY (the FlexiCubes output of this iteration, PL:1393 / 1509) for a one-image
         batch -- the reference's batch size.  The topology tables (vertex -> incident faces in pytorch3d's index_add
-        order, unique edges, neighbour lists) are rebuilt on the GPU with sorts; one host read-back for the edge count.
+        order, unique edges, neighbour lists) are rebuilt on the GPU: by foho_topology_tables (k_topo.inc) for closed
+        manifold meshes -- what FlexiCubes emits --, by general torch sorts otherwise; one host read-back (validity flag).
         The next step recomputes the cached AABB and clears the rasteriser's planes (FOHO_STAGE_BBOX)."""
         if self.B != 1:
             raise L.FohoError("update_object: topology updates are implemented for one-image batches")
@@ -338,27 +339,30 @@ class GuidanceBatch:
         self.verts_in = torch.cat([self.verts_in[:Vh], v], 0).contiguous()
         faces_all = torch.cat([self.faces[:Fh].to(torch.int64), f + Vh], 0)
         self.faces = faces_all.to(torch.int32).contiguous()
-        # vertex -> (face << 2 | corner), ordered by (vertex, corner, face): unique keys, one sort
-        vv = faces_all.t().reshape(-1)
-        corner = torch.arange(3, device=dev).repeat_interleave(Ftot)
-        face = torch.arange(Ftot, device=dev).repeat(3)
-        order = torch.argsort((vv * 3 + corner) * Ftot + face)
-        self.inc_fc = ((face[order] << 2) | corner[order]).to(torch.int32).contiguous()
-        off = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
-        off[1:] = torch.bincount(vv, minlength=Vtot).cumsum(0)
-        self.inc_off = off.to(torch.int32).contiguous()
-        # unique undirected edges of the OBJECT mesh (pytorch3d edges_packed) and the neighbour lists over them
-        fo = f + Vh
-        e = torch.cat([fo[:, [0, 1]], fo[:, [1, 2]], fo[:, [2, 0]]], 0)
-        key = torch.unique(e.min(1).values * Vtot + e.max(1).values)
-        ea, eb = key // Vtot, key % Vtot
-        n_edges = int(key.numel())
-        src, dst = torch.cat([ea, eb]), torch.cat([eb, ea])
-        order = torch.argsort(src * Vtot + dst)
-        noff = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
-        noff[1:] = torch.bincount(src, minlength=Vtot).cumsum(0)
-        self.nbr_off = noff.to(torch.int32).contiguous()
-        self.nbr_idx = (dst[order] if n_edges else torch.zeros(1, dtype=torch.int64, device=dev)).to(torch.int32).contiguous()
+        n_edges = -1
+        if assume_manifold and Fo > 0 and Fo % 2 == 0:
+            # dual-marching-cubes output is a closed oriented 2-manifold: tables straight from the incidence lists
+            # (foho_topology_tables, k_topo.inc); the flag tells when the assumption does not hold
+            lib = self.lib
+            lib.foho_topology_workspace_bytes.restype = ctypes.c_size_t
+            nws = lib.foho_topology_workspace_bytes(Vtot)
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            self.inc_off = torch.empty(Vtot + 1, dtype=torch.int32, device=dev)
+            self.inc_fc = torch.empty(3 * Ftot, dtype=torch.int32, device=dev)
+            self.nbr_off = torch.empty(Vtot + 1, dtype=torch.int32, device=dev)
+            self.nbr_idx = torch.empty(max(3 * Fo, 1), dtype=torch.int32, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            P = ctypes.c_void_p
+            L.check(lib.foho_topology_tables(P(self.faces.data_ptr()), Vtot, Vh, Ftot, P(self.inc_off.data_ptr()),
+                                             P(self.inc_fc.data_ptr()), P(self.nbr_off.data_ptr()), P(self.nbr_idx.data_ptr()),
+                                             P(flag.data_ptr()), P(ws.data_ptr()), ctypes.c_size_t(nws), P(stream)),
+                    "foho_topology_tables")
+            if int(flag.item()) == 0:
+                n_edges = 3 * Fo // 2
+        if n_edges < 0:
+            self._topology_by_sort(faces_all, f, Vh, Vtot, Ftot)
+            n_edges = self._n_edges
         # image record, sizes, outputs
         im = self._images_host[0]
         im.Vo, im.Fo, im.n_edges = Vo, Fo, n_edges
@@ -373,6 +377,31 @@ class GuidanceBatch:
             self.workspace = torch.zeros(int(need * 1.25), dtype=torch.uint8, device=dev)   # head-room: sizes drift slowly
         self._desc = None
         self._bbox_dirty = True     # the workspace layout moved with the sizes: AABB + clean scatter planes again
+
+    def _topology_by_sort(self, faces_all, f, Vh, Vtot, Ftot):
+        """General path (any mesh): torch sorts on the device."""
+        dev = self.device
+        # vertex -> (face << 2 | corner), ordered by (vertex, corner, face): unique keys, one sort
+        vv = faces_all.t().reshape(-1)
+        corner = torch.arange(3, device=dev).repeat_interleave(Ftot)
+        face = torch.arange(Ftot, device=dev).repeat(3)
+        order = torch.argsort((vv * 3 + corner) * Ftot + face)
+        self.inc_fc = ((face[order] << 2) | corner[order]).to(torch.int32).contiguous()
+        off = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.bincount(vv, minlength=Vtot).cumsum(0)
+        self.inc_off = off.to(torch.int32).contiguous()
+        # unique undirected edges of the OBJECT mesh (pytorch3d edges_packed) and the neighbour lists over them
+        fo = f + Vh
+        e = torch.cat([fo[:, [0, 1]], fo[:, [1, 2]], fo[:, [2, 0]]], 0)
+        key = torch.unique(e.min(1).values * Vtot + e.max(1).values)
+        ea, eb = key // Vtot, key % Vtot
+        self._n_edges = int(key.numel())
+        src, dst = torch.cat([ea, eb]), torch.cat([eb, ea])
+        order = torch.argsort(src * Vtot + dst)
+        noff = torch.zeros(Vtot + 1, dtype=torch.int64, device=dev)
+        noff[1:] = torch.bincount(src, minlength=Vtot).cumsum(0)
+        self.nbr_off = noff.to(torch.int32).contiguous()
+        self.nbr_idx = (dst[order] if self._n_edges else torch.zeros(1, dtype=torch.int64, device=dev)).to(torch.int32).contiguous()
 
     def objective(self, verts, faces, cfg):
         """Differentiable scalar: total loss of one iteration on the object mesh (verts, faces); backward() delivers

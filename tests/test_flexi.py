@@ -179,3 +179,36 @@ def test_sdf_to_loss_chain_matches_the_oracle_chain():
     t1, _, _ = S.phase_c_loss(dict(sc, obj_faces=F1), p, V1, R.unique_edges(F1), denoise_i=19, grid_res=16)
     assert abs(gb.loss_dict(0)["total"] - float(t1)) <= 1e-4 * abs(float(t1))
     assert np.isfinite(s1.grad.cpu().numpy()).all() and float(s1.grad.abs().sum()) > 0
+
+
+@gpu
+def test_device_topology_tables_equal_the_host_builders():
+    """foho_topology_tables (closed manifold fast path) against the numpy builders the engine uses at construction; a mesh
+    with a boundary is detected and handled by the general sort path."""
+    from followmyhold_amd import engine as E, synthetic
+    from helpers import make_scene
+    sc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in make_scene("ico2", 64, 64, seed=0).items()}
+    gb = E.GuidanceBatch([sc], grid_res=16)
+    for kind in ("ico4", "20k"):
+        ov, of = synthetic.make_object(kind)
+        gb.update_object(ov * 0.05, of)
+        Vh, Fh = gb.meta[0]["Vh"], gb.meta[0]["Fh"]
+        faces = gb.faces.cpu().numpy().astype(np.int64)
+        inc_off, inc_fc = E.incidence_csr(faces, gb.Vtot)
+        edges = E.unique_edges(of) + Vh
+        nbr_off, nbr_idx = E.neighbour_csr(edges, gb.Vtot)
+        assert gb.meta[0]["n_edges"] == len(edges) == 3 * len(of) // 2
+        assert np.array_equal(gb.inc_off.cpu().numpy(), inc_off) and np.array_equal(gb.inc_fc.cpu().numpy(), inc_fc)
+        assert np.array_equal(gb.nbr_off.cpu().numpy(), nbr_off)
+        assert np.array_equal(gb.nbr_idx.cpu().numpy()[:len(nbr_idx)], nbr_idx)
+    # open mesh (one face removed): not a closed manifold -> the flag sends it to the sort path, same tables as the host's
+    ov, of = synthetic.make_object("ico4")
+    of = of[:-2]
+    gb.update_object(ov * 0.05, of)
+    Vh = gb.meta[0]["Vh"]
+    edges = E.unique_edges(of) + Vh
+    nbr_off, nbr_idx = E.neighbour_csr(edges, gb.Vtot)
+    assert gb.meta[0]["n_edges"] == len(edges) != 3 * len(of) // 2
+    assert np.array_equal(gb.nbr_off.cpu().numpy(), nbr_off) and np.array_equal(gb.nbr_idx.cpu().numpy()[:len(nbr_idx)], nbr_idx)
+    inc_off, inc_fc = E.incidence_csr(gb.faces.cpu().numpy().astype(np.int64), gb.Vtot)
+    assert np.array_equal(gb.inc_fc.cpu().numpy(), inc_fc)
