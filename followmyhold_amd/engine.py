@@ -169,27 +169,28 @@ class GuidanceBatch:
     moge_normal (H,W,3), moge_disp (H,W), hand_mask (H,W) bool, obj_mask (H,W) bool, fov (deg), H, W.
     """
 
-    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2):
+    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2, topology="auto"):
+        """topology: "auto" builds the tables on the device (foho_topology_tables; closed manifold object meshes) and falls
+        back to the host builders when the validity flag says so; "host" always uses the numpy builders; "render" builds
+        the incidence lists only (target-map renders need no edge tables)."""
         self.lib = L.lib()
         self.device = torch.device(device)
         self.B = B = len(scenes)
         H, W = int(scenes[0]["H"]), int(scenes[0]["W"])
         assert all(int(s["H"]) == H and int(s["W"]) == W for s in scenes), "one image size per batch"
         self.H, self.W = H, W
-        verts, faces, images, edges_all = [], [], [], []
+        verts, faces, images = [], [], []
         v_off = f_off = 0
         self.meta = []
-        nbr_off_parts, nbr_idx_parts = [], []
         for s in scenes:
             hv, ov = np.asarray(s["hand_verts"], np.float32), np.asarray(s["obj_verts"], np.float32)
             hf, of = np.asarray(s["hand_faces"], np.int64), np.asarray(s["obj_faces"], np.int64)
             Vh, Vo, Fh, Fo = len(hv), len(ov), len(hf), len(of)
             verts += [hv, ov]
             faces += [hf + v_off, of + v_off + Vh]
-            e = unique_edges(of) if Fo else np.zeros((0, 2), np.int64)
             im = L.FohoImage()
             im.v_off, im.Vh, im.Vo, im.f_off, im.Fh, im.Fo = v_off, Vh, Vo, f_off, Fh, Fo
-            im.n_edges = len(e)
+            im.n_edges = 0
             jr = np.asarray(s["J_regressor"], np.float32)
             im.jcols = jr.shape[1]
             im.k00, im.k11 = fov_focal(float(s["fov"]))
@@ -204,25 +205,41 @@ class GuidanceBatch:
             for k in range(12):
                 im.T_h2m[k] = float(M[k])
             images.append(im)
-            edges_all.append(e + v_off + Vh)
-            self.meta.append(dict(v_off=v_off, Vh=Vh, Vo=Vo, f_off=f_off, Fh=Fh, Fo=Fo, n_edges=len(e)))
+            self.meta.append(dict(v_off=v_off, Vh=Vh, Vo=Vo, f_off=f_off, Fh=Fh, Fo=Fo, n_edges=0))
             v_off += Vh + Vo
             f_off += Fh + Fo
         self.Vtot, self.Ftot = v_off, f_off
         verts = np.concatenate(verts, 0)
         faces = np.concatenate(faces, 0)
-        inc_off, inc_fc = incidence_csr(faces, self.Vtot)
-        edges = np.concatenate(edges_all, 0) if edges_all else np.zeros((0, 2), np.int64)
-        nbr_off, nbr_idx = neighbour_csr(edges, self.Vtot)
-        if len(nbr_idx) == 0:
-            nbr_idx = np.zeros(1, np.int32)
-
         dev = self.device
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
         self.verts_in = t(verts, torch.float32)
         self.faces = t(faces, torch.int32)
-        self.inc_off, self.inc_fc = t(inc_off, torch.int32), t(inc_fc, torch.int32)
-        self.nbr_off, self.nbr_idx = t(nbr_off, torch.int32), t(nbr_idx, torch.int32)
+        obj_flag = np.zeros(self.Vtot, np.uint8)
+        for m in self.meta:
+            obj_flag[m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]] = 1
+        ok = False
+        if topology in ("auto", "render") and self.Ftot > 0:
+            ok = self._device_topology(t(obj_flag, torch.uint8) if topology == "auto" else None)
+            if ok and topology == "auto":
+                ok = all(m["Fo"] % 2 == 0 for m in self.meta)
+        if ok:
+            for m, im in zip(self.meta, images):
+                m["n_edges"] = im.n_edges = (3 * m["Fo"] // 2) if topology == "auto" else 0
+        else:   # general meshes (boundaries, non-manifold edges): sort-based builders on the host
+            inc_off, inc_fc = incidence_csr(faces, self.Vtot)
+            edges_all = []
+            for m, im in zip(self.meta, images):
+                lo = m["f_off"] + m["Fh"]
+                e = unique_edges(faces[lo:lo + m["Fo"]]) if m["Fo"] else np.zeros((0, 2), np.int64)
+                m["n_edges"] = im.n_edges = len(e)
+                edges_all.append(e)
+            edges = np.concatenate(edges_all, 0) if edges_all else np.zeros((0, 2), np.int64)
+            nbr_off, nbr_idx = neighbour_csr(edges, self.Vtot)
+            if len(nbr_idx) == 0:
+                nbr_idx = np.zeros(1, np.int32)
+            self.inc_off, self.inc_fc = t(inc_off, torch.int32), t(inc_fc, torch.int32)
+            self.nbr_off, self.nbr_idx = t(nbr_off, torch.int32), t(nbr_idx, torch.int32)
         self.J = t(np.asarray(scenes[0]["J_regressor"], np.float32), torch.float32)
         self._images_host = images
         img_bytes = b"".join(bytes(im) for im in images)
@@ -339,26 +356,14 @@ class GuidanceBatch:
         self.verts_in = torch.cat([self.verts_in[:Vh], v], 0).contiguous()
         faces_all = torch.cat([self.faces[:Fh].to(torch.int64), f + Vh], 0)
         self.faces = faces_all.to(torch.int32).contiguous()
+        self.Vtot, self.Ftot = Vtot, Ftot          # _device_topology sizes its tables from these
         n_edges = -1
         if assume_manifold and Fo > 0 and Fo % 2 == 0:
             # dual-marching-cubes output is a closed oriented 2-manifold: tables straight from the incidence lists
             # (foho_topology_tables, k_topo.inc); the flag tells when the assumption does not hold
-            lib = self.lib
-            lib.foho_topology_workspace_bytes.restype = ctypes.c_size_t
-            nws = lib.foho_topology_workspace_bytes(Vtot)
-            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-            self.inc_off = torch.empty(Vtot + 1, dtype=torch.int32, device=dev)
-            self.inc_fc = torch.empty(3 * Ftot, dtype=torch.int32, device=dev)
-            self.nbr_off = torch.empty(Vtot + 1, dtype=torch.int32, device=dev)
-            self.nbr_idx = torch.empty(max(3 * Fo, 1), dtype=torch.int32, device=dev)
-            flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            P = ctypes.c_void_p
-            L.check(lib.foho_topology_tables(P(self.faces.data_ptr()), Vtot, Vh, Ftot, P(self.inc_off.data_ptr()),
-                                             P(self.inc_fc.data_ptr()), P(self.nbr_off.data_ptr()), P(self.nbr_idx.data_ptr()),
-                                             P(flag.data_ptr()), P(ws.data_ptr()), ctypes.c_size_t(nws), P(stream)),
-                    "foho_topology_tables")
-            if int(flag.item()) == 0:
+            flags = torch.zeros(Vtot, dtype=torch.uint8, device=dev)
+            flags[Vh:] = 1
+            if self._device_topology(flags):
                 n_edges = 3 * Fo // 2
         if n_edges < 0:
             self._topology_by_sort(faces_all, f, Vh, Vtot, Ftot)
@@ -377,6 +382,32 @@ class GuidanceBatch:
             self.workspace = torch.zeros(int(need * 1.25), dtype=torch.uint8, device=dev)   # head-room: sizes drift slowly
         self._desc = None
         self._bbox_dirty = True     # the workspace layout moved with the sizes: AABB + clean scatter planes again
+
+    def _device_topology(self, obj_flag):
+        """foho_topology_tables on self.faces: incidence lists (+ neighbour lists at the same offsets when obj_flag marks the
+        object vertices).  Returns False when the validity flag asks for the general path (one host read-back)."""
+        lib, dev = self.lib, self.device
+        Vtot, Ftot = int(self.Vtot), int(self.faces.shape[0])
+        lib.foho_topology_workspace_bytes.restype = ctypes.c_size_t
+        nws = lib.foho_topology_workspace_bytes(Vtot)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        inc_off = torch.empty(Vtot + 1, dtype=torch.int32, device=dev)
+        inc_fc = torch.empty(3 * Ftot, dtype=torch.int32, device=dev)
+        nbr_idx = torch.empty(3 * Ftot if obj_flag is not None else 1, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        P = ctypes.c_void_p
+        L.check(lib.foho_topology_tables(P(self.faces.data_ptr()), Vtot, Ftot, P(obj_flag.data_ptr()) if obj_flag is not None else None,
+                                         P(inc_off.data_ptr()), P(inc_fc.data_ptr()), P(nbr_idx.data_ptr()), P(flag.data_ptr()),
+                                         P(ws.data_ptr()), ctypes.c_size_t(nws),
+                                         P(torch.cuda.current_stream(dev).cuda_stream)), "foho_topology_tables")
+        if int(flag.item()) != 0:
+            return False
+        self.inc_off, self.inc_fc = inc_off, inc_fc
+        if obj_flag is not None:
+            self.nbr_off, self.nbr_idx = inc_off, nbr_idx  # neighbour lists share the incidence offsets
+        else:                                              # no edge tables: every neighbour list is empty
+            self.nbr_off, self.nbr_idx = torch.zeros(Vtot + 1, dtype=torch.int32, device=dev), nbr_idx
+        return True
 
     def _topology_by_sort(self, faces_all, f, Vh, Vtot, Ftot):
         """General path (any mesh): torch sorts on the device."""
@@ -593,7 +624,7 @@ def hip_render_fn(device="cuda"):
                      J_regressor=np.zeros((16, 1), np.float32), kps_2d=np.zeros((21, 2), np.float32),
                      moge_normal=np.zeros((H, W, 3), np.float32), moge_disp=np.zeros((H, W), np.float32),
                      hand_mask=np.zeros((H, W), bool), obj_mask=np.zeros((H, W), bool), fov=fov, H=H, W=W)
-        gb = GuidanceBatch([dummy], device=device, n_renders=1, grid_res=2)
+        gb = GuidanceBatch([dummy], device=device, n_renders=1, grid_res=2, topology="render")
         cfg, _ = phase_cfg("B", do_update=False)
         cfg.world_space_input = 1     # the reference renders the target mesh as it is (PL:1247-1256)
         gb.step(cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)

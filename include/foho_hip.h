@@ -239,16 +239,17 @@ int foho_flexi_fwd(const float* x, const float* s, int32_t res, float* verts, in
 int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* grad_verts, int32_t n_verts, float* grad_s,
                    float* grad_x, const void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- topology tables of a packed hand + object mesh, rebuilt on the device every time the object's connectivity
- * changes (the FlexiCubes output of an iteration, pipelines.py:1393 / 1509): inc_off (V+1) / inc_fc (3F) = vertex ->
- * incident (face << 2 | corner) in pytorch3d's index_add order (verts_normals_packed, PL:83); nbr_off (V+1) / nbr_idx
- * (3 F_obj) = vertex -> neighbours over the unique edges of the object mesh (edges_packed / mesh_edge_loss, PL:1575).
- * Valid for closed, consistently oriented 2-manifold object meshes (n_edges = 3 F_obj / 2); *flag != 0 afterwards means
- * the mesh is not one (bit1) or a valence exceeds 48 (bit0) and the caller must build the tables with a general sort. */
+/* ---- topology tables of a packed mesh, built on the device (at set-up, and every time the object's connectivity
+ * changes: the FlexiCubes output of an iteration, pipelines.py:1393 / 1509).  faces (F,3) with vertex ids in [0,V).
+ * inc_off (V+1) / inc_fc (3F) = vertex -> incident (face << 2 | corner) in pytorch3d's index_add order
+ * (verts_normals_packed, PL:83).  With obj_flag (V bytes, 1 = object vertex): nbr_idx (3F) = vertex -> neighbours over
+ * the unique edges (edges_packed / mesh_edge_loss, PL:1575) at the SAME offsets inc_off, valid when the flagged vertices
+ * form closed, consistently oriented 2-manifolds (then n_edges = 3 F_obj / 2); *flag != 0 afterwards means they do not
+ * (bit1) or a valence exceeds 48 (bit0) and the caller must build the tables with a general sort.  obj_flag == NULL:
+ * incidence lists only. */
 size_t foho_topology_workspace_bytes(int32_t V);
-int foho_topology_tables(const int32_t* faces, int32_t V, int32_t Vh, int32_t F, int32_t* inc_off, int32_t* inc_fc,
-                         int32_t* nbr_off, int32_t* nbr_idx, int32_t* flag, void* workspace, size_t workspace_bytes,
-                         void* stream);
+int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8_t* obj_flag, int32_t* inc_off, int32_t* inc_fc,
+                         int32_t* nbr_idx, int32_t* flag, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

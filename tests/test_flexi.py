@@ -189,26 +189,41 @@ def test_device_topology_tables_equal_the_host_builders():
     from helpers import make_scene
     sc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in make_scene("ico2", 64, 64, seed=0).items()}
     gb = E.GuidanceBatch([sc], grid_res=16)
+    def host_lists(of, Vh, Vtot):
+        off, idx = E.neighbour_csr(E.unique_edges(of) + Vh, Vtot)
+        return off, idx
+
+    def check_nbr(gb, of):
+        Vh, Vtot = gb.meta[0]["Vh"], gb.Vtot
+        off, idx = host_lists(of, Vh, Vtot)
+        d_off, d_idx = gb.nbr_off.cpu().numpy(), gb.nbr_idx.cpu().numpy()
+        for v in list(range(Vh, Vh + 50)) + list(range(Vtot - 50, Vtot)):
+            assert np.array_equal(d_idx[d_off[v]:d_off[v + 1]], idx[off[v]:off[v + 1]]), v
+
     for kind in ("ico4", "20k"):
         ov, of = synthetic.make_object(kind)
         gb.update_object(ov * 0.05, of)
-        Vh, Fh = gb.meta[0]["Vh"], gb.meta[0]["Fh"]
         faces = gb.faces.cpu().numpy().astype(np.int64)
         inc_off, inc_fc = E.incidence_csr(faces, gb.Vtot)
-        edges = E.unique_edges(of) + Vh
-        nbr_off, nbr_idx = E.neighbour_csr(edges, gb.Vtot)
-        assert gb.meta[0]["n_edges"] == len(edges) == 3 * len(of) // 2
+        assert gb.meta[0]["n_edges"] == len(E.unique_edges(of)) == 3 * len(of) // 2
         assert np.array_equal(gb.inc_off.cpu().numpy(), inc_off) and np.array_equal(gb.inc_fc.cpu().numpy(), inc_fc)
-        assert np.array_equal(gb.nbr_off.cpu().numpy(), nbr_off)
-        assert np.array_equal(gb.nbr_idx.cpu().numpy()[:len(nbr_idx)], nbr_idx)
-    # open mesh (one face removed): not a closed manifold -> the flag sends it to the sort path, same tables as the host's
+        assert gb.nbr_off.data_ptr() == gb.inc_off.data_ptr()        # neighbour lists share the incidence offsets
+        check_nbr(gb, of)
+        # the constructor takes the same device path
+        g2 = E.GuidanceBatch([dict(sc, obj_verts=(ov * 0.05).astype(np.float32), obj_faces=of)], grid_res=16)
+        assert np.array_equal(g2.inc_fc.cpu().numpy(), inc_fc) and g2.meta[0]["n_edges"] == 3 * len(of) // 2
+        check_nbr(g2, of)
+        gh = E.GuidanceBatch([dict(sc, obj_verts=(ov * 0.05).astype(np.float32), obj_faces=of)], grid_res=16, topology="host")
+        assert np.array_equal(gh.inc_fc.cpu().numpy(), inc_fc) and gh.meta[0]["n_edges"] == g2.meta[0]["n_edges"]
+    # open mesh (two faces removed): not a closed manifold -> the flag sends it to the sort path, same tables as the host's
     ov, of = synthetic.make_object("ico4")
     of = of[:-2]
     gb.update_object(ov * 0.05, of)
     Vh = gb.meta[0]["Vh"]
-    edges = E.unique_edges(of) + Vh
-    nbr_off, nbr_idx = E.neighbour_csr(edges, gb.Vtot)
-    assert gb.meta[0]["n_edges"] == len(edges) != 3 * len(of) // 2
-    assert np.array_equal(gb.nbr_off.cpu().numpy(), nbr_off) and np.array_equal(gb.nbr_idx.cpu().numpy()[:len(nbr_idx)], nbr_idx)
+    assert gb.meta[0]["n_edges"] == len(E.unique_edges(of)) != 3 * len(of) // 2
+    check_nbr(gb, of)
     inc_off, inc_fc = E.incidence_csr(gb.faces.cpu().numpy().astype(np.int64), gb.Vtot)
     assert np.array_equal(gb.inc_fc.cpu().numpy(), inc_fc)
+    g3 = E.GuidanceBatch([dict(sc, obj_verts=(ov * 0.05).astype(np.float32), obj_faces=of)], grid_res=16)
+    assert g3.meta[0]["n_edges"] == len(E.unique_edges(of))
+    check_nbr(g3, of)
