@@ -460,15 +460,20 @@ class GuidanceBatch:
         l = self.losses[b].detach().cpu().tolist()
         return dict(zip(L.LOSS_NAMES, l))
 
-    def raise_on_flags(self):
+    def raise_on_flags(self, strict_k=True):
         """bit1: fractional-fragment list overflow, bit2: a pixel holds at least 100 fractional-coverage fragments, the only
-        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones;
-        fail loudly instead of deviating."""
+        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones.
+        Fails loudly instead of deviating; strict_k=False downgrades bit2 to a warning (a collapsing object -- thousands
+        of sub-pixel faces on one pixel -- is outside any regime where the K=100 cut-off is meaningful)."""
         f = self.flags.detach().cpu().numpy()
         if (f & 2).any():
             raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
         if (f & 4).any():
-            raise L.FohoError("a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced")
+            msg = "a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced"
+            if strict_k:
+                raise L.FohoError(msg)
+            import warnings
+            warnings.warn(msg + f" (images {np.flatnonzero(f & 4).tolist()})")
         return f
 
     # ------------------------------------------------------------------ HIP graph + per-kernel timing

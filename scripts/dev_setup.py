@@ -18,3 +18,11 @@ g = gb.capture(cfg, steps_per_graph=50)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(15): g.replay()
 torch.cuda.synchronize(); print("750 iterations: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+for spg in (1, 10, 50, 200):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); g = gb.capture(cfg, steps_per_graph=spg); torch.cuda.synchronize()
+    t1 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); t2 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); t3 = time.perf_counter()
+    print("capture of %d iterations: %.1f ms; first replay %.1f ms, second %.1f ms" % (spg, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+from followmyhold_amd import inputs
+torch.cuda.synchronize(); t0 = time.perf_counter()
+inputs.run_mesh_guidance([sc]); torch.cuda.synchronize()
+print("run_mesh_guidance (750 iterations, 11 phase loops): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
