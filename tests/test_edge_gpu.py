@@ -185,3 +185,46 @@ def test_full_size_properties(obj_kind):
     gbatch.step(cfg)
     torch.cuda.synchronize()
     assert np.array_equal(gbatch.losses[1].cpu().numpy(), ga.losses[0].cpu().numpy())
+
+
+@gpu
+def test_full_size_step_matches_the_oracle():
+    """configs[1] itself -- 512x512, 778-vertex hand, 10 242-vertex / 20 480-face object, 65^3 grid -- one joint step against
+    the CPU oracle: face ids, depth and edge distances bit-exact, losses 1e-4, parameter / vertex gradients 1e-3 (the
+    oracle needs a few seconds here; the small-scene tests carry the tighter gradient bound)."""
+    from followmyhold_amd import engine as E
+    from oracle import clib
+    import os
+    clib.set_threads(min(32, len(os.sched_getaffinity(0))))
+    sc = _full_scene("20k")
+    tsc = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in sc.items()}
+    p = S.make_params(scale_obj=torch.tensor([0.98]), rot_hand=torch.tensor([0.999, 0.01, -0.02, 0.015]),
+                      trans_obj=torch.tensor([0.002, -0.001, 0.001]))
+    st = S.JointStepper(tsc, p, denoise_i=19, grid_res=64)
+    total, terms, aux, grads = st.step(update=False)
+    gb = E.GuidanceBatch([sc])
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    P = 512 * 512
+    p2f = gb.region("p2f", torch.int32, (2, P)).cpu().numpy()
+    zb = gb.region("zbuf", torch.float32, (2, P)).cpu().numpy()
+    sd = gb.region("sdist", torch.float32, (2, P)).cpu().numpy()
+    for r, ren in enumerate([aux["hand"]["render"], aux["render"]]):
+        ref = ren["sel"]["pix_to_face"].reshape(-1)
+        hit = ref >= 0
+        assert np.array_equal(p2f[r], ref)
+        assert np.array_equal(zb[r][hit], ren["sel"]["zbuf"].reshape(-1)[hit])
+        assert np.array_equal(sd[r][hit], ren["sel"]["dists"].reshape(-1)[hit])
+    l = gb.loss_dict(0)
+    assert int(l["n_intersect"]) == aux["n_int"]
+    assert abs(l["total"] - float(total)) <= 1e-4 * abs(float(total))
+    for a, b in [("normal1", "normal_hoi"), ("disp1", "disp_hoi"), ("sil1", "sil_hoi"), ("contact", "contact"), ("edge", "edge")]:
+        assert abs(l[a] - float(terms[b])) <= 1e-4 * max(abs(float(terms[b])), 1e-6), (a, l[a], float(terms[b]))
+    g = gb.grad_params[0].cpu().numpy()
+    gref = np.concatenate([grads[k].numpy().reshape(-1) for k in E.PARAM_NAMES])
+    assert np.linalg.norm(g - gref) <= 1e-3 * np.linalg.norm(gref)
+    gv, gvr = gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()
+    assert np.linalg.norm(gv - gvr) <= 1e-3 * np.linalg.norm(gvr)
