@@ -64,6 +64,18 @@ def test_host_only_queries_work_without_a_gpu(lib):
     assert lib.foho_step_run(None, None, 0, None) == -1
     lib.foho_last_error.restype = ctypes.c_char_p
     assert b"null" in lib.foho_last_error()
+    # size queries and argument checks of the other entry points
+    for fn, args, lo in [("foho_flexi_workspace_bytes", (64,), 1_000_000), ("foho_topology_workspace_bytes", (11020,), 50_000),
+                         ("foho_raster_workspace_bytes", (11020, 22032, 512, 512), 1_000_000), ("foho_icp_workspace_bytes", (5000, 10000), 1)]:
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_size_t
+        assert f(*args) >= lo, fn
+    assert lib.foho_flexi_workspace_bytes(0) == 0 and lib.foho_topology_workspace_bytes(0) == 0
+    lib.foho_flexi_fwd.restype = ctypes.c_int
+    assert lib.foho_flexi_fwd(None, None, 64, None, 0, None, 0, None, None, None, ctypes.c_size_t(0), None) == -1
+    assert b"foho_flexi_fwd" in lib.foho_last_error()
+    lib.foho_topology_tables.restype = ctypes.c_int
+    assert lib.foho_topology_tables(None, 10, 10, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1
 
 
 def test_struct_layouts_match_the_header():
