@@ -115,7 +115,6 @@ def get_all_axis_aligned_reflections():
 def sample_surface_even(m: Mesh, count: int, rng: np.random.Generator):
     """trimesh.sample.sample_surface_even: 3*count area-weighted samples, then greedy removal of points closer than
     sqrt(area / (3 count)); may return fewer than `count` points."""
-    from scipy.spatial import cKDTree
     area = m.area_faces
     radius = np.sqrt(area.sum() / (3 * count))
     n = count * 3
@@ -127,15 +126,32 @@ def sample_surface_even(m: Mesh, count: int, rng: np.random.Generator):
     r[flip] -= 1.0
     r = np.abs(r)
     pts = tri[:, 0] + ((tri[:, 1:] - tri[:, :1]) * r).sum(axis=1)
-    tree = cKDTree(pts)
-    consumed = np.zeros(n, bool)
-    keep = np.zeros(n, bool)
-    for i, group in enumerate(tree.query_ball_point(pts, radius)):
-        if consumed[i]:
-            continue
-        keep[i] = True
-        consumed[group] = True
-    return pts[keep][:count]
+    return pts[greedy_remove_close(pts, radius)][:count]
+
+
+def greedy_remove_close(pts, radius):
+    """trimesh.points.remove_close: walk the points in order, keep a point unless an earlier KEPT point lies within
+    `radius`.  That is the lexicographically first maximal independent set of the "closer than radius" graph; it is
+    computed here in vectorised rounds over the pair list (a point is decided once all its lower-index neighbours
+    are) instead of a Python loop over the points -- same mask."""
+    from scipy.spatial import cKDTree
+    n = len(pts)
+    pairs = cKDTree(pts).query_pairs(radius, output_type="ndarray")      # (i < j)
+    lo, hi = pairs[:, 0], pairs[:, 1]
+    state = np.zeros(n, np.int8)                                         # 0 undecided, 1 kept, 2 removed
+    while True:
+        und = state == 0
+        if not und.any():
+            break
+        removed = np.zeros(n, bool)
+        removed[hi[state[lo] == 1]] = True
+        state[und & removed] = 2
+        waiting = np.zeros(n, bool)
+        waiting[hi[state[lo] == 0]] = True
+        state[(state == 0) & ~waiting] = 1
+        live = (state[hi] == 0) & (state[lo] != 2)
+        lo, hi = lo[live], hi[live]
+    return state == 1
 
 
 def icp(source_mesh: Mesh, target_mesh: Mesh, n_iter, count_source=5_000, count_target=5_000, test_reflections=False,
@@ -159,14 +175,14 @@ def icp(source_mesh: Mesh, target_mesh: Mesh, n_iter, count_source=5_000, count_
     target_points = target_mesh.vertices if target_mesh.is_point_cloud else sample_surface_even(target_mesh, count_target, rng)
     n_outliers = int(outliers * count_source)   # ICP:89 uses the REQUESTED count, not len(source_points)
     n_outliers = min(n_outliers, len(source_points) - 2)
+    # `for cube in cubes` (ICP:91) as one batched enqueue; the first strictly lowest cost wins, as in the loop
+    starts = np.stack([transform_points(source_points, cube) for cube in cubes])
+    Ts, costs = ops.icp_points_multi(starts, target_points, n_iter, n_outliers=n_outliers, fixed_scale=fixed_scale,
+                                     min_scale=min_scale, max_scale=max_scale)
     best_cost, best_T = np.inf, np.eye(4)
-    for cube in cubes:
-        start = transform_points(source_points, cube)
-        T, cost = ops.icp_points(start, target_points, n_iter, n_outliers=n_outliers, fixed_scale=fixed_scale,
-                                 min_scale=min_scale, max_scale=max_scale)
-        T = T @ cube
+    for cube, T, cost in zip(cubes, Ts, costs):
         if cost < best_cost:
-            best_cost, best_T = cost, T
+            best_cost, best_T = float(cost), T @ cube
     return best_T, best_cost
 
 

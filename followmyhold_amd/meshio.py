@@ -17,6 +17,47 @@ _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short":
               "double": "f8", "float64": "f8"}
 
 
+def _read_uniform_list_element(f, el, end):
+    """Binary element whose list properties all have the same length in every row (the usual all-triangle face element):
+    read it as one structured array.  Returns the (count, n) vertex-index array, False when the element has no vertex
+    index list, or None (file position restored) when the rows are not uniform."""
+    pos = f.tell()
+    if el["count"] == 0:
+        return False
+    # list lengths of the first row
+    fields, lens = [], []
+    for q, p in enumerate(el["props"]):
+        if p[0] == "list":
+            cdt, idt = np.dtype(end + _PLY_TYPES[p[1]]), np.dtype(end + _PLY_TYPES[p[2]])
+            raw = f.read(cdt.itemsize)
+            if len(raw) < cdt.itemsize:
+                f.seek(pos)
+                return None
+            n = int(np.frombuffer(raw, cdt)[0])
+            f.seek(idt.itemsize * n, 1)
+            fields += [(f"c{q}", cdt), (f"l{q}", idt, (n,))]
+            lens.append((q, n, p[3]))
+        else:
+            dt = np.dtype(end + _PLY_TYPES[p[0]])
+            f.seek(dt.itemsize, 1)
+            fields.append((f"s{q}", dt))
+    f.seek(pos)
+    dt = np.dtype(fields)
+    raw = f.read(dt.itemsize * el["count"])
+    if len(raw) < dt.itemsize * el["count"]:
+        f.seek(pos)
+        return None
+    data = np.frombuffer(raw, dtype=dt, count=el["count"])
+    for q, n, _ in lens:
+        if not np.all(data[f"c{q}"] == n):
+            f.seek(pos)
+            return None
+    for q, n, name in lens:
+        if name in ("vertex_indices", "vertex_index"):
+            return data[f"l{q}"].reshape(el["count"], n)
+    return False
+
+
 def load_ply(path):
     """Returns (verts (V,3) float32, faces (F,3) int64).  Faces with more than 3 vertices are fan-triangulated;
     a file without a face element (point cloud) returns an empty (0,3) face array."""
@@ -67,6 +108,13 @@ def load_ply(path):
                 if el["name"] == "vertex":
                     verts = np.stack([data["x"], data["y"], data["z"]], 1).astype(np.float32)
             else:
+                fast = _read_uniform_list_element(f, el, end)
+                if fast is not None:
+                    if el["name"] == "face" and fast is not False:
+                        n = fast.shape[1]
+                        faces = np.stack([np.stack([fast[:, 0], fast[:, k], fast[:, k + 1]], 1) for k in range(1, n - 1)],
+                                         1).reshape(-1, 3).astype(np.int64) if n >= 3 else faces
+                    continue
                 tri = []
                 for _ in range(el["count"]):
                     row_idx = None

@@ -163,26 +163,36 @@ def lbs(betas, rot_mats, model: LbsModel, use_mfma=-1):
 
 
 # ------------------------------------------------------------------------------------------------ ICP
+def icp_points_multi(start_points, target_points, n_iter, n_outliers=0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
+                     device="cuda", return_history=False):
+    """The icp() loop of src/foho/alignment/mesh_align.py:91-142 for ALL start point sets (S, N, 3) against one target
+    (float64), one enqueue and one synchronisation.  Returns (transforms (S,4,4), costs (S,)[, histories (S,n_iter)])."""
+    lib = L.lib()
+    src = torch.as_tensor(np.ascontiguousarray(np.asarray(start_points, np.float64))).to(device)
+    tgt = torch.as_tensor(np.ascontiguousarray(np.asarray(target_points, np.float64))).to(device)
+    if src.dim() != 3 or src.shape[2] != 3 or tgt.dim() != 2 or tgt.shape[1] != 3:
+        raise L.FohoError("icp_points_multi: expected (S,N,3) start points and (M,3) target points")
+    S, N, M = src.shape[0], src.shape[1], tgt.shape[0]
+    lib.foho_icp_batch_workspace_bytes.restype = ctypes.c_size_t
+    nws = lib.foho_icp_batch_workspace_bytes(S, N, M)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=device)
+    T = torch.zeros(S, 16, dtype=torch.float64, device=device)
+    cost = torch.zeros(S, dtype=torch.float64, device=device)
+    hist = torch.zeros(S, max(n_iter, 1), dtype=torch.float64, device=device)
+    L.check(lib.foho_icp_run_batch(P(src.data_ptr()), S, N, P(tgt.data_ptr()), M, int(n_iter), int(n_outliers),
+                                   int(bool(fixed_scale)), ctypes.c_double(min_scale), ctypes.c_double(max_scale),
+                                   P(T.data_ptr()), P(cost.data_ptr()), P(hist.data_ptr()), P(ws.data_ptr()),
+                                   ctypes.c_size_t(nws), _stream(src)), "foho_icp_run_batch")
+    out = (T.cpu().numpy().reshape(S, 4, 4), cost.cpu().numpy())      # the copies synchronise
+    return out + (hist.cpu().numpy()[:, :n_iter],) if return_history else out
+
+
 def icp_points(source_points, target_points, n_iter, n_outliers=0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
                device="cuda", return_history=False):
-    """The icp() loop of src/foho/alignment/mesh_align.py:91-142 on sampled point sets (float64).
-    Returns (best_transform (4,4) np.float64, best_cost float[, cost history])."""
-    lib = L.lib()
-    src = torch.as_tensor(np.asarray(source_points, np.float64)).contiguous().to(device)
-    tgt = torch.as_tensor(np.asarray(target_points, np.float64)).contiguous().to(device)
-    N, M = src.shape[0], tgt.shape[0]
-    lib.foho_icp_workspace_bytes.restype = ctypes.c_size_t
-    nws = lib.foho_icp_workspace_bytes(N, M)
-    ws = torch.zeros(nws, dtype=torch.uint8, device=device)
-    T = torch.zeros(16, dtype=torch.float64, device=device)
-    cost = torch.zeros(1, dtype=torch.float64, device=device)
-    hist = torch.zeros(max(n_iter, 1), dtype=torch.float64, device=device)
-    L.check(lib.foho_icp_run(P(src.data_ptr()), N, P(tgt.data_ptr()), M, int(n_iter), int(n_outliers), int(bool(fixed_scale)),
-                             ctypes.c_double(min_scale), ctypes.c_double(max_scale), P(T.data_ptr()), P(cost.data_ptr()),
-                             P(hist.data_ptr()), P(ws.data_ptr()), ctypes.c_size_t(nws), _stream(src)), "foho_icp_run")
-    torch.cuda.synchronize(src.device)
-    out = (T.cpu().numpy().reshape(4, 4), float(cost.item()))
-    return out + (hist.cpu().numpy()[:n_iter],) if return_history else out
+    """One start of icp_points_multi.  Returns (best_transform (4,4) np.float64, best_cost float[, cost history])."""
+    out = icp_points_multi(np.asarray(source_points, np.float64)[None], target_points, n_iter, n_outliers, fixed_scale,
+                           min_scale, max_scale, device, return_history)
+    return (out[0][0], float(out[1][0])) + ((out[2][0],) if return_history else ())
 
 
 # ------------------------------------------------------------------------------------------------ iso-surfacing

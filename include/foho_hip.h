@@ -31,6 +31,7 @@
  *   foho_point_mesh_dist     kaolin.metrics.trianglemesh.point_to_mesh_distance (SDF:101)
  *   foho_lbs_fwd/_bwd        smplx MANOLayer forward (third_party/estimator/hamer/hamer/models/hamer.py:125-130)
  *   foho_icp_run             icp() loop: cKDTree.query + trimmed procrustes + scale clip (ICP:104-142)
+ *   foho_icp_run_batch       the same for all start transforms of icp() at once (ICP:91-175)
  */
 #ifndef FOHO_HIP_H
 #define FOHO_HIP_H
@@ -224,6 +225,16 @@ size_t foho_icp_workspace_bytes(int32_t N, int32_t M);
 int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int32_t n_iter, int32_t n_outliers,
                  int32_t fixed_scale, double min_scale, double max_scale, double* T_out, double* cost_out,
                  double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The multi-start loop of icp() (`for cube in cubes`, ICP:91-175: identity + 7 reflections + 9 axis rotations) as
+ * ONE enqueue: src (n_starts, N, 3) holds the already transformed start point sets, the target is shared; every
+ * iteration is 2 launches whose grids carry the start index, so the 17 coarse starts cost the launches of one.
+ * T_out (n_starts, 16), cost_out (n_starts), cost_history (n_starts, n_iter) optional; per start identical to
+ * foho_icp_run (which is this call with n_starts = 1). */
+size_t foho_icp_batch_workspace_bytes(int32_t n_starts, int32_t N, int32_t M);
+int foho_icp_run_batch(const double* src, int32_t n_starts, int32_t N, const double* tgt, int32_t M, int32_t n_iter,
+                       int32_t n_outliers, int32_t fixed_scale, double min_scale, double max_scale, double* T_out,
+                       double* cost_out, double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- iso-surfacing between the diffusion latent and the guidance path ----------------
  * kaolin FlexiCubes.__call__(x_nx3, s_n, cube_fx8, res) with default weights, as called at pipelines.py:1393 / 1509

@@ -91,6 +91,21 @@ def test_meshio_roundtrip(tmp_path):
         meshio.save_ply(p, v, f, binary=binary)
         v2, f2 = meshio.load_ply(p)
         assert np.allclose(v2, v, atol=1e-6) and np.array_equal(f2, f)
+    # polygonal binary faces: uniform quads (one structured read) and mixed triangles / quads (row-by-row fallback),
+    # with a scalar property after the list, big endian
+    import struct
+    for rows in ([[0, 1, 2, 3], [3, 2, 1, 0]], [[0, 1, 2], [0, 1, 2, 3], [4, 3, 2, 1, 0]]):
+        p = str(tmp_path / "poly.ply")
+        with open(p, "wb") as fh:
+            fh.write((f"ply\nformat binary_big_endian 1.0\nelement vertex 5\nproperty float x\nproperty float y\n"
+                      f"property float z\nelement face {len(rows)}\nproperty list uchar int vertex_indices\n"
+                      f"property uchar flags\nend_header\n").encode())
+            fh.write(np.arange(15, dtype=">f4").tobytes())
+            for r in rows:
+                fh.write(struct.pack(f">B{len(r)}iB", len(r), *r, 7))
+        v2, f2 = meshio.load_ply(p)
+        want = [[r[0], r[k], r[k + 1]] for r in rows for k in range(1, len(r) - 1)]
+        assert np.array_equal(v2, np.arange(15, dtype=np.float32).reshape(5, 3)) and np.array_equal(f2, want)
     p = str(tmp_path / "pc.ply")
     meshio.save_ply(p, v)
     v2, f2 = meshio.load_ply(p)

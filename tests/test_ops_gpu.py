@@ -110,3 +110,27 @@ def test_icp_loop_matches_the_numpy_reference(N, M, outliers):
     assert abs(c - c_ref) <= 1e-9 * abs(c_ref) and np.allclose(T, T_ref, rtol=1e-8, atol=1e-10)
     # the alignment actually improves
     assert hist[-1] < 0.5 * hist[0]
+
+
+@gpu
+def test_icp_multi_start_equals_the_per_start_loop():
+    """`for cube in cubes` (ICP:91-175: identity, 7 reflections, 9 rotations) as one batched enqueue: every start gets
+    the transform / cost / history of its own single-start run, bit for bit, and matches the numpy restatement."""
+    from followmyhold_amd import ops
+    from foho.alignment import mesh_align as MA
+    rng = np.random.default_rng(3)
+    ov, _ = synthetic.make_object("20k")
+    tgt_all = ov.astype(np.float64) * 3.0
+    tgt = tgt_all[rng.choice(len(tgt_all), 3000, replace=False)]
+    src = tgt_all[rng.choice(len(tgt_all), 700, replace=False)] * 1.1 + 0.01
+    cubes = [np.eye(4)] + MA.get_all_axis_aligned_reflections() + MA.get_all_axis_aligned_rotations()
+    assert len(cubes) == 17
+    starts = np.stack([icp_ref.transform_points(src, c) for c in cubes])
+    Ts, costs, hists = ops.icp_points_multi(starts, tgt, n_iter=8, n_outliers=140, min_scale=0.7, max_scale=3.0, return_history=True)
+    assert Ts.shape == (17, 4, 4) and costs.shape == (17,) and hists.shape == (17, 8)
+    for s in (0, 3, 9, 16):
+        T1, c1, h1 = ops.icp_points(starts[s], tgt, n_iter=8, n_outliers=140, min_scale=0.7, max_scale=3.0, return_history=True)
+        assert np.array_equal(T1, Ts[s]) and c1 == costs[s] and np.array_equal(h1, hists[s])
+    T_ref, c_ref = icp_ref.icp_points(starts[5], tgt, n_iter=8, outliers=0.2, min_scale=0.7, max_scale=3.0)
+    assert abs(costs[5] - c_ref) <= 1e-9 * abs(c_ref) and np.allclose(Ts[5], T_ref, rtol=1e-8, atol=1e-10)
+    assert np.argmin(costs) == 0      # the unrotated start wins on an asymmetric object
