@@ -7,8 +7,10 @@ What is kept from the reference: the nine required flags + --task_list_file (RUN
 `_load_task_list` (RUN:178-185).  Added: when launched under torch.distributed (one process per GPU) every rank
 takes its round-robin share of the image list and rank 0 prints the all-reduced batch metrics.
 
-`run_hunyuan_w_guid` needs the Hunyuan3D-2 DiT + ShapeVAE (neural nets outside the hot path, SURVEY.md 8(a) A20);
-they are looked up at call time and a clear error is raised when hy3dgen is not installed.
+`run_hunyuan_w_guid` runs followmyhold_amd.pipeline.GuidedShapePipeline -- the patched Hunyuan pipeline's __call__ with
+the guidance arithmetic on HIP -- over the Hunyuan3D-2 DiT + ShapeVAE (PyTorch networks outside the hot path, SURVEY.md
+8(a) A20), which are looked up at call time; without hy3dgen a clear error is raised unless FOHO_STANDIN_NETWORKS=1
+(random-initialised stand-ins) or FOHO_MESH_LEVEL_GUIDANCE=1 (fixed object mesh) is set.
 """
 import argparse
 import json
@@ -77,26 +79,18 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
         rasterizer=p3d.MeshRasterizer(cameras=cameras, raster_settings=p3d.RasterizationSettings(
             image_size=(H, W), blur_radius=blur, faces_per_pixel=100, bin_size=None)),
         shader=p3d.SoftSilhouetteShader(blend_params=blend))
-    try:
-        from hy3dgen.shapegen.pipelines import Hunyuan3DDiTFlowMatchingPipeline_main
-    except ImportError as e:
-        if os.environ.get("FOHO_MESH_LEVEL_GUIDANCE") == "1":
-            return _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path,
-                                        cropped_hand_mask_path, moge_mesh_path, T_h2m_path, hunyuan_hoi_mesh_path,
-                                        save_path_obj, save_path_hand, config, device)
-        raise RuntimeError("Hunyuan3D-2 (hy3dgen) is not installed: the DiT/VAE that produce the object latent are "
-                           "outside the MI355X hot path (SURVEY.md 8(a) A20). Set FOHO_MESH_LEVEL_GUIDANCE=1 to run "
-                           "phases A/B/C on the fixed Hunyuan mesh, or use followmyhold_amd.engine.GuidanceBatch "
-                           "directly.") from e
-    from PIL import Image
-    image = Image.open(cropped_obj_img_path).convert("RGBA")
-    pipeline = Hunyuan3DDiTFlowMatchingPipeline_main.from_pretrained("tencent/Hunyuan3D-2")
-    obj_mesh, hand_mesh = pipeline(
-        image=[image], mc_algo="mc", generator=torch.manual_seed(2), config=config, renderer=renderer,
-        sil_renderer=sil_renderer, cropped_obj_img_path=cropped_obj_img_path, hamer_for_guid_path=hamer_for_guid_path,
-        aligned_mano_mesh_path=aligned_mano_mesh_path, obj_mask_path=cropped_obj_mask_path,
-        hand_mask_path=cropped_hand_mask_path, moge_mesh_path=moge_mesh_path, h2m_rt_path=T_h2m_path,
-        hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path)
+    pipeline = _build_pipeline(device)
+    if pipeline is None:        # FOHO_MESH_LEVEL_GUIDANCE=1 and no networks: phases A/B/C on the fixed Hunyuan mesh
+        return _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path,
+                                    cropped_hand_mask_path, moge_mesh_path, T_h2m_path, hunyuan_hoi_mesh_path,
+                                    save_path_obj, save_path_hand, config, device)
+    out = pipeline(
+        image=_load_object_image(cropped_obj_img_path), mc_algo="mc", generator=torch.manual_seed(2), config=config,
+        renderer=renderer, sil_renderer=sil_renderer, cropped_obj_img_path=cropped_obj_img_path,
+        hamer_for_guid_path=hamer_for_guid_path, aligned_mano_mesh_path=aligned_mano_mesh_path,
+        obj_mask_path=cropped_obj_mask_path, hand_mask_path=cropped_hand_mask_path, moge_mesh_path=moge_mesh_path,
+        h2m_rt_path=T_h2m_path, hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path)
+    obj_mesh, hand_mesh = out       # a None return (NaN in phase B, PL:1442-1444) raises here like in the reference
     try:
         meshio.save_ply(save_path_obj, obj_mesh.verts_packed().cpu().numpy(), obj_mesh.faces_packed().cpu().numpy())
         meshio.save_ply(save_path_hand, hand_mesh.verts_packed().cpu().numpy(), hand_mesh.faces_packed().cpu().numpy())
@@ -107,6 +101,52 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
         print(f"Empty mesh for {cropped_obj_img_path}")
         return None, None
     return obj_mesh, hand_mesh
+
+
+def _load_object_image(path):
+    """RUN:122-138: RGBA image of the object crop; pure white pixels become transparent.  The "inpaint" branch needs
+    hy3dgen's BackgroundRemover (rembg), a network outside this repository."""
+    from PIL import Image
+    if "inpaint" in path:
+        try:
+            from hy3dgen.rembg import BackgroundRemover
+        except ImportError as e:
+            raise RuntimeError("inpainted crops need hy3dgen.rembg.BackgroundRemover (RUN:119-126)") from e
+        return [BackgroundRemover()(Image.open(path).convert("RGB"))]
+    a = np.array(Image.open(path).convert("RGBA"))
+    white = (a[..., :3] == 255).all(-1)
+    a[white] = (255, 255, 255, 0)
+    return [Image.fromarray(a, "RGBA")]
+
+
+_PIPELINE = None
+
+
+def _build_pipeline(device):
+    """The guided pipeline (followmyhold_amd.pipeline.GuidedShapePipeline) over the Hunyuan3D-2 networks when hy3dgen is
+    installed (RUN:140), over random-initialised stand-ins when FOHO_STANDIN_NETWORKS=1 (plumbing runs without the
+    weights), None when FOHO_MESH_LEVEL_GUIDANCE=1 asks for the fixed-mesh driver.  Built once per process."""
+    global _PIPELINE
+    if _PIPELINE is not None:
+        return _PIPELINE
+    from followmyhold_amd.pipeline import GuidedShapePipeline
+    if os.environ.get("FOHO_STANDIN_NETWORKS") == "1":
+        import torch
+        from followmyhold_amd import standins
+        _PIPELINE = standins.make_standin_pipeline(device=device, dtype=torch.float32)
+        return _PIPELINE
+    try:
+        from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
+    except ImportError as e:
+        if os.environ.get("FOHO_MESH_LEVEL_GUIDANCE") == "1":
+            return None
+        raise RuntimeError("Hunyuan3D-2 (hy3dgen) is not installed: the DiT/VAE that produce the object latent are "
+                           "PyTorch networks outside the MI355X hot path (SURVEY.md 8(a) A20). Set FOHO_STANDIN_NETWORKS=1 "
+                           "to run the full guided pipeline on random-initialised stand-ins, FOHO_MESH_LEVEL_GUIDANCE=1 "
+                           "to run phases A/B/C on the fixed Hunyuan mesh, or use followmyhold_amd.pipeline / "
+                           "followmyhold_amd.engine directly.") from e
+    _PIPELINE = GuidedShapePipeline.from_hy3dgen(Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("tencent/Hunyuan3D-2"))
+    return _PIPELINE
 
 
 def _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, cropped_obj_mask_path, cropped_hand_mask_path,

@@ -185,17 +185,21 @@ def load_fov(path):
 
 
 # ------------------------------------------------------------------------------------------------ one image
-def load_scene_from_files(p, J_regressor, render_fn, n_hand_verts=778):
+def load_scene_from_files(p, J_regressor, render_fn, n_hand_verts=778, fov=None, with_object=True):
     """Scene dict for `engine.GuidanceBatch` from the reference's per-image files.  `p` = `foho.guidance.run.derive_paths`
     output; `render_fn(verts, faces, H, W, fov) -> (normal, disp, pix_to_face)` renders the MoGe mesh into the target
-    maps (engine.hip_render_fn on the GPU)."""
+    maps (engine.hip_render_fn on the GPU).  `fov` overrides fov.json (the pipeline gets it from the renderer's camera,
+    RUN:90); with_object=False leaves the object empty (the pipeline decodes it from the latent every iteration)."""
     hand_mask, obj_mask = load_mask(p["cropped_hand_mask_path"]), load_mask(p["cropped_obj_mask_path"])
     H, W = hand_mask.shape
-    fov = load_fov(p["moge_fov_path"])
+    fov = load_fov(p["moge_fov_path"]) if fov is None else float(fov)
     T = np.load(p["T_h2m_path"]).astype(np.float64).reshape(4, 4)
     mano_v, mano_f = meshio.load_ply(p["aligned_mano_mesh_path"])
     hand_moge = mano_v.astype(np.float64) @ T[:3, :3].T + T[:3, 3]          # transform_hunyuan2moge (PL:242-250, 1241)
-    obj_v, obj_f = meshio.load_ply(p["hunyuan_hoi_mesh_path"])
+    if with_object:
+        obj_v, obj_f = meshio.load_ply(p["hunyuan_hoi_mesh_path"])
+    else:
+        obj_v, obj_f = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64)
     mv, mf = load_glb(p["moge_mesh_path"])
     normal, disp, _ = render_fn(mv, mf, H, W, fov)
     hoi = (hand_mask | obj_mask).astype(np.float32)                         # PL:1243, 1252-1253

@@ -1,0 +1,313 @@
+"""Guided flow-matching shape pipeline: the `__call__` of the reference's patched
+`Hunyuan3DDiTFlowMatchingPipeline_main` (third_party_patches/hy3dgen/shapegen/pipelines.py:1041-1679; PL below) with the
+optimisation-in-the-loop arithmetic on the MI355X kernels.
+
+What stays PyTorch-ROCm ("host code stays Python"): the DiT (`model`), the ShapeVAE (`vae`: latent ->
+transformer -> cross-attention geometry decoder), the image conditioner and the flow-matching scheduler.  They are
+constructor arguments with the interfaces the reference uses (PL:563-742); `from_hy3dgen` adopts the components of an
+installed Hunyuan3D-2 pipeline object.  What runs on hand-written HIP: FlexiCubes (`foho_flexi_fwd/_bwd`), the topology
+tables of the mesh it emits (`foho_topology_tables`), and the whole guidance iteration -- transforms, three renders,
+keypoints, nearest neighbours, edge loss, inside count, every loss head, their backward and the Adam/AdamW update of the
+14 similarity parameters (`foho_step_run`).  Per inner iteration the only torch autograd left is
+latent -> VAE -> SDF, which receives dL/dSDF from the FlexiCubes backward kernel and carries it to `noise_pred_obj`
+(PL:1507-1509, PL:1600-1601).
+
+Differences from the reference, all outside the arithmetic:
+  * `renderer` / `sil_renderer` only supply the camera (fov); the fused step renders itself.
+  * debug dumps (`FOHO_DEBUG_DIR`, PL:1076-1091, 1664-1675) write losses.txt / params.json and the final meshes; the
+    matplotlib grids are not produced.
+  * the 14 similarity parameters live in the GuidanceBatch (device memory) instead of seven leaf tensors; each phase gets
+    a fresh optimiser state exactly like the reference's per-step `torch.optim.Adam/AdamW(...)` (PL:1318, 1384, 1478).
+    `noise_pred_obj` keeps its own torch AdamW with the same hyper-parameters (Adam is element-wise, so splitting one
+    optimiser into two changes nothing).
+"""
+import datetime
+import json
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import engine as E
+from . import inputs, ops
+from .facade import Meshes, TexturesVertex, generate_dense_grid_points, quaternion_to_matrix
+from .scheduler import retrieve_timesteps
+
+
+def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
+    """PL:292-338 (return_mesh=False): rescale the latent, run the VAE transformer, query the geometry decoder in chunks of
+    8000 grid points, negate the logits so that the field is negative inside.  -> (1, G, G, G) float32."""
+    pred = 1 / vae.scale_factor * pred
+    pred = vae(pred)
+    logits = []
+    for start in range(0, xyz_samples.shape[0], num_chunks):
+        queries = xyz_samples[start:start + num_chunks].to(device).to(pred.dtype)
+        logits.append(vae.geo_decoder(queries.unsqueeze(0), pred))
+    grid_logits = torch.cat(logits, dim=1)
+    return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
+
+
+def similarity_about_center(verts, scale, quat, trans):
+    """transform_mesh_around_center_w_scale (PL:108-118): scale and rotate about the bounding-box centre, then shift."""
+    center = (verts.min(dim=0)[0] + verts.max(dim=0)[0]) / 2.0
+    R = quaternion_to_matrix(quat).float().reshape(3, 3)
+    return (scale * (verts - center)) @ R.T + center + trans
+
+
+def _cat_recursive(*parts, dtype):
+    if isinstance(parts[0], torch.Tensor):
+        return torch.cat(parts, dim=0).to(dtype)
+    return {k: _cat_recursive(*[p[k] for p in parts], dtype=dtype) for k in parts[0].keys()}
+
+
+class GuidedShapePipeline:
+    """Drop-in for `Hunyuan3DDiTFlowMatchingPipeline_main`: same constructor (PL:563-585), same `__call__` signature and
+    return value (PL:1044-1072, 1679)."""
+
+    def __init__(self, vae, model, scheduler, conditioner, image_processor, device="cuda", dtype=torch.float16, **kwargs):
+        self.vae, self.model, self.scheduler = vae, model, scheduler
+        self.conditioner, self.image_processor = conditioner, image_processor
+        self.to(device, dtype)
+
+    @classmethod
+    def from_hy3dgen(cls, pipe):
+        """Adopt the networks of an (unpatched) hy3dgen `Hunyuan3DDiTFlowMatchingPipeline` object."""
+        from .scheduler import FlowMatchEulerDiscreteScheduler
+        sch = FlowMatchEulerDiscreteScheduler(num_train_timesteps=pipe.scheduler.config.num_train_timesteps,
+                                              shift=getattr(pipe.scheduler.config, "shift", 1.0))
+        return cls(pipe.vae, pipe.model, sch, pipe.conditioner, pipe.image_processor, device=pipe.device, dtype=pipe.dtype)
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+            for m in (self.vae, self.model, self.conditioner):
+                m.to(device)
+        if dtype is not None:
+            self.dtype = dtype
+            for m in (self.vae, self.model, self.conditioner):
+                m.to(dtype=dtype)
+
+    # ------------------------------------------------------------------ PL:599-742
+    def encode_cond(self, image, mask, do_classifier_free_guidance, dual_guidance, to_cpu=False):
+        bsz = image.shape[0]
+        cond = self.conditioner(image=image, mask=mask)
+        if do_classifier_free_guidance:
+            un_cond = self.conditioner.unconditional_embedding(bsz)
+            if dual_guidance:
+                drop_main = dict(un_cond)
+                drop_main["additional"] = cond["additional"]
+                cond = _cat_recursive(cond, drop_main, un_cond, dtype=self.dtype)
+            else:
+                cond = _cat_recursive(cond, un_cond, dtype=self.dtype)
+        if to_cpu:
+            self.conditioner.to("cpu")
+        return cond
+
+    def prepare_latents(self, batch_size, dtype, device, generator, latents=None):
+        shape = (batch_size, *self.vae.latent_shape)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            latents = torch.randn(shape, generator=generator if isinstance(generator, torch.Generator) else None,
+                                  device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents * getattr(self.scheduler, "init_noise_sigma", 1.0)
+
+    def prepare_image(self, image, hand_mask=None):
+        if isinstance(image, str) and not os.path.exists(image):
+            raise FileNotFoundError(f"Couldn't find image at path {image}")
+        images, masks = [], []
+        for img in image if isinstance(image, list) else [image]:
+            out = self.image_processor(img, return_mask=True)
+            im, mk = (out.get("image"), out.get("mask")) if isinstance(out, dict) else out
+            images.append(im)
+            masks.append(mk)
+        images = torch.cat(images, dim=0).to(self.device, dtype=self.dtype)
+        masks = torch.cat(masks, dim=0).to(self.device, dtype=self.dtype) if masks[0] is not None else None
+        return images, masks
+
+    # ------------------------------------------------------------------ PL:1044-1679
+    @torch.no_grad()
+    def __call__(self, image=None, num_inference_steps: int = 30, timesteps=None, sigmas=None, eta: float = 0.0,
+                 guidance_scale: float = 7.5, generator=None, box_v=1.10, octree_resolution=64, mc_level=0.0, mc_algo="mc",
+                 num_chunks=8000, output_type: Optional[str] = "trimesh", enable_pbar=True, config=None, renderer=None,
+                 sil_renderer=None, cropped_obj_img_path=None, hamer_for_guid_path=None, aligned_mano_mesh_path=None,
+                 obj_mask_path=None, hand_mask_path=None, moge_mesh_path=None, h2m_rt_path=None, hunyuan_hoi_mesh_path=None,
+                 **kwargs):
+        kwargs.pop("callback", None)            # popped and ignored, as in PL:1073-1074
+        kwargs.pop("callback_steps", None)
+        final_res = int(kwargs.pop("final_octree_resolution", 384))          # PL:1627 (tests use a smaller grid)
+        J_regressor = kwargs.pop("J_regressor", None)                        # default: the file of PL:1218
+        self.stats = stats = {"inner_iterations": 0, "skipped_empty": 0}
+        device, dtype = self.device, self.dtype
+        cfg0 = config() if config is not None else E.OptimizationConfig()
+
+        debug_root = os.environ.get("FOHO_DEBUG_DIR")
+        index = cropped_obj_img_path.split("/")[-1].split("_")[0]
+        log = None
+        if debug_root:
+            save_dir = os.path.join(debug_root, f"{datetime.datetime.now().strftime('%Y%m%d_%H%M%S')}_exp_obj{index}_inpainted")
+            os.makedirs(save_dir, exist_ok=True)
+            log = open(os.path.join(save_dir, "losses.txt"), "w")
+
+        def say(msg):
+            if log:
+                log.write(msg + "\n")
+            print(msg)
+
+        do_cfg = guidance_scale >= 0 and not (getattr(self.model, "guidance_embed", False) is True)
+        obj_img, obj_mask = self.prepare_image(image)
+        cond_obj = self.encode_cond(image=obj_img, mask=obj_mask, do_classifier_free_guidance=do_cfg, dual_guidance=False)
+
+        # dense grid the latent is decoded on (PL:1126-1143); FlexiCubes needs no cube index table here
+        octree_res = 64 if "guidance_octree_resolution" not in kwargs else int(kwargs.pop("guidance_octree_resolution"))
+        guid_res = octree_res
+        bmin, bmax = np.full(3, -1.10), np.full(3, 1.10)
+        xyz_np, grid_size, _ = generate_dense_grid_points(bmin, bmax, octree_depth=5, octree_resolution=octree_res, indexing="ij")
+        xyz_samples = torch.as_tensor(xyz_np, dtype=torch.float32, device=device)
+
+        obj_guidance_scale = cfg0.obj_guidance_scale
+        batch_size = cfg0.batch_size
+        num_inference_steps = cfg0.num_inference_steps
+        handopt_start_step = cfg0.handopt_start_step
+        guidance_start_step = cfg0.guidance_start_step
+        guidance_end_step = num_inference_steps
+        if debug_root:
+            keys = ["obj_guidance_scale", "optimization_steps_hand", "optimization_steps_joint", "optimization_steps_scale",
+                    "num_inference_steps", "guidance_start_step", "handopt_start_step", "phase1_hand_lrs", "phase2_hand_lrs",
+                    "obj_lrs", "obj_2half_lrs", "noise_obj_lr1", "noise_obj_lr2", "use_intersection_loss"]
+            with open(os.path.join(save_dir, "params.json"), "w") as f:
+                json.dump({**{k: getattr(cfg0, k) for k in keys}, "guidance_end_step": guidance_end_step}, f, indent=4)
+
+        sigmas = np.linspace(0, 1, num_inference_steps) if sigmas is None else sigmas     # starts from 0 (PL:1186-1193)
+        timesteps_obj, n_steps_obj = retrieve_timesteps(self.scheduler, num_inference_steps, device, sigmas=sigmas)
+        guidance = None
+        if getattr(self.model, "guidance_embed", False) is True:
+            guidance = torch.tensor([guidance_scale] * batch_size, device=device, dtype=dtype)
+        self.model.eval()
+        self.vae.eval()
+        obj_latents = self.prepare_latents(batch_size, dtype, device, generator).clone()
+
+        # per-image inputs (PL:1217-1256): masks, keypoints, aligned MANO mesh, Hunyuan -> MoGe transform, MoGe target maps
+        fov = float(renderer.rasterizer.cameras.fov) if renderer is not None else None
+        paths = dict(cropped_hand_mask_path=hand_mask_path, cropped_obj_mask_path=obj_mask_path, moge_mesh_path=moge_mesh_path,
+                     moge_fov_path=os.path.join(os.path.dirname(moge_mesh_path), "fov.json"), T_h2m_path=h2m_rt_path,
+                     aligned_mano_mesh_path=aligned_mano_mesh_path, hamer_for_guid_path=hamer_for_guid_path)
+        jr = inputs.load_j_regressor() if J_regressor is None else np.asarray(J_regressor, np.float32)
+        scene = inputs.load_scene_from_files(paths, jr, E.hip_render_fn(device), fov=fov, with_object=False)
+        gb = E.GuidanceBatch([scene], device=device, grid_res=guid_res, n_renders=2)
+        T_h2m = torch.as_tensor(scene["T_h2m"], dtype=torch.float32, device=device)
+        hand_moge = torch.as_tensor(scene["hand_verts"], dtype=torch.float32, device=device)
+        hand_faces = torch.as_tensor(scene["hand_faces"], dtype=torch.int64, device=device)
+
+        def decode_mesh(noise_pred, t, latents, res, xyz, gsz):
+            x1 = self.scheduler.step_final(noise_pred, t, latents)
+            sdf = latent2sdf(x1, xyz, gsz, self.vae, device, num_chunks)
+            return ops.flexicubes(xyz, sdf[0].flatten(), res)
+
+        def latent_phase(phase, iters, i, t, noise_pred, lr, nan_returns_none):
+            """Phases B / C (PL:1362-1453 / 1456-1601): `iters` iterations of decode -> fused step -> AdamW."""
+            cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
+            gb.set_n_renders(n_renders)
+            gb.reset_optimizer()
+            noise_pred = noise_pred.clone().detach().requires_grad_(True)
+            opt = torch.optim.AdamW([{"params": [noise_pred], "lr": lr}], eps=1e-4)
+            for k in range(int(iters)):
+                opt.zero_grad()
+                verts, faces, _ = decode_mesh(noise_pred, t, obj_latents, guid_res, xyz_samples, grid_size)
+                if verts.shape[0] == 0:
+                    print("Invalid mesh detected, aborting step!")
+                    stats["skipped_empty"] += 1
+                    continue
+                loss = gb.objective(verts, faces, cfg)
+                stats["inner_iterations"] += 1
+                if torch.isnan(loss):
+                    print("Total loss is NaN")
+                    if nan_returns_none:
+                        return None
+                    break
+                if k % 10 == 0:
+                    l = gb.loss_dict(0)
+                    say(f"Opt step {k}, object loss: {l['edge']}, loss_intersection: {l.get('intersection', 0.0)}, "
+                        f"total: {l['total']}")
+                loss.backward()
+                opt.step()
+            gb.raise_on_flags(strict_k=False)
+            return noise_pred.detach().clone()
+
+        obj_out = hand_out = None
+        for i, t in enumerate(timesteps_obj):
+            latent_in = torch.cat([obj_latents] * 2) if do_cfg else obj_latents
+            timestep = t.expand(latent_in.shape[0]).to(obj_latents.dtype) / self.scheduler.config.num_train_timesteps
+            noise_pred_obj = self.model(latent_in, timestep, cond_obj, guidance=guidance)
+            if do_cfg:      # trust the learned prior early, the guidance later (PL:1284-1293)
+                scale_i = obj_guidance_scale * (1 - i / n_steps_obj) if i >= guidance_start_step + 1 else obj_guidance_scale
+                c, u = noise_pred_obj.chunk(2)
+                noise_pred_obj = u + scale_i * (c - u)
+
+            if i >= handopt_start_step:
+                with torch.enable_grad():
+                    if i == handopt_start_step:                      # phase A: hand only, no latent involved (PL:1296-1358)
+                        say(f"Pre-guidance step {i}, optimizing hands only")
+                        cfg, n_renders = E.phase_cfg("A", cfg0, denoise_i=i, do_update=True)
+                        gb.set_n_renders(n_renders)
+                        gb.reset_optimizer()
+                        n = int(cfg0.optimization_steps_hand)
+                        spg = max([d for d in range(1, 51) if n % d == 0]) if n > 0 else 1
+                        graph = gb.capture(cfg, steps_per_graph=spg)
+                        gb.reset_optimizer()
+                        for _ in range(n // spg):
+                            graph.replay()
+                        stats["inner_iterations"] += n
+                        torch.cuda.synchronize(device)
+                        l = gb.loss_dict(0)
+                        say(f"Opt step {n - 1}, loss_2d_kps: {l.get('kps', 0.0)}, total: {l['total']}")
+                    elif i == handopt_start_step + 1:                # phase B: object transform + latent (PL:1361-1453)
+                        say(f"Object optimization step {i}, optimizing object transformation")
+                        noise_pred_obj = latent_phase("B", cfg0.optimization_steps_scale, i, t, noise_pred_obj,
+                                                      cfg0.noise_obj_lr1, nan_returns_none=True)
+                        if noise_pred_obj is None:
+                            return None
+                    elif handopt_start_step + 2 <= i <= guidance_end_step:   # phase C: joint (PL:1455-1601)
+                        say(f"Joint optimization step {i}, optimizing hands and object together")
+                        noise_pred_obj = latent_phase("C", cfg0.optimization_steps_joint, i, t, noise_pred_obj,
+                                                      cfg0.noise_obj_lr2, nan_returns_none=False)
+                noise_pred_obj = noise_pred_obj.detach().clone()
+
+            obj_latents = self.scheduler.step(noise_pred_obj, t, obj_latents).prev_sample
+
+            # current clean-sample estimate as a mesh in the MoGe world (PL:1612-1661); the last one is the result
+            p = gb.params[0]
+            if i >= handopt_start_step:
+                hand_now = similarity_about_center(hand_moge, p[0], p[4:8], p[1:4])
+            if i == num_inference_steps - 1 and final_res != octree_res:     # final decode on the fine grid (PL:1626-1642)
+                octree_res = final_res
+                xyz_np, grid_size, _ = generate_dense_grid_points(bmin, bmax, octree_depth=5, octree_resolution=octree_res,
+                                                                  indexing="ij")
+                xyz_samples = torch.as_tensor(xyz_np, dtype=torch.float32, device=device)
+            verts, faces, _ = decode_mesh(noise_pred_obj, t, obj_latents, octree_res, xyz_samples, grid_size)
+            if verts.shape[0] == 0:
+                print("Invalid mesh detected, aborting step!")
+                continue
+            obj_world = similarity_about_center(verts @ T_h2m[:3, :3].T + T_h2m[:3, 3], p[8], p[12:16], p[9:12])
+            tex = torch.zeros_like(obj_world)
+            tex[:, 2] = 1.0
+            obj_out = Meshes(verts=[obj_world], faces=[faces], textures=TexturesVertex(verts_features=[tex]))
+            if i >= handopt_start_step:
+                tex_h = torch.zeros_like(hand_now)
+                tex_h[:, 1] = 1.0
+                hand_out = Meshes(verts=[hand_now], faces=[hand_faces], textures=TexturesVertex(verts_features=[tex_h]))
+            if debug_root and i in (14, num_inference_steps - 1):
+                from . import meshio
+                tag = "final" if i == num_inference_steps - 1 else f"guidance_step_{i}"
+                meshio.save_ply(os.path.join(save_dir, f"{tag}_hand_mesh.ply"), hand_out.verts_packed().cpu().numpy(),
+                                hand_faces.cpu().numpy())
+                meshio.save_ply(os.path.join(save_dir, f"{tag}_obj_mesh.ply"), obj_world.cpu().numpy(), faces.cpu().numpy())
+        if log:
+            log.close()
+        self.guidance_batch = gb
+        return obj_out, hand_out

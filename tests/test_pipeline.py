@@ -1,0 +1,241 @@
+"""The guided flow-matching pipeline (followmyhold_amd/pipeline.py) = the patched
+`Hunyuan3DDiTFlowMatchingPipeline_main.__call__` (third_party_patches/hy3dgen/shapegen/pipelines.py:1041-1679) with the
+guidance arithmetic on HIP.  The DiT / ShapeVAE are random-initialised stand-ins (followmyhold_amd/standins.py): what is
+tested is the loop, the interfaces and the latent -> SDF -> FlexiCubes -> loss -> gradient chain, not a trained model."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from followmyhold_amd import inputs, pipeline as PLN, standins, synthetic
+from followmyhold_amd.scheduler import FlowMatchEulerDiscreteScheduler
+
+gpu = pytest.mark.gpu
+
+
+def test_call_signature_is_the_reference_one():
+    """PL:1044-1072: parameter names, order and defaults."""
+    want = [("image", None), ("num_inference_steps", 30), ("timesteps", None), ("sigmas", None), ("eta", 0.0),
+            ("guidance_scale", 7.5), ("generator", None), ("box_v", 1.10), ("octree_resolution", 64), ("mc_level", 0.0),
+            ("mc_algo", "mc"), ("num_chunks", 8000), ("output_type", "trimesh"), ("enable_pbar", True), ("config", None),
+            ("renderer", None), ("sil_renderer", None), ("cropped_obj_img_path", None), ("hamer_for_guid_path", None),
+            ("aligned_mano_mesh_path", None), ("obj_mask_path", None), ("hand_mask_path", None), ("moge_mesh_path", None),
+            ("h2m_rt_path", None), ("hunyuan_hoi_mesh_path", None)]
+    sig = inspect.signature(PLN.GuidedShapePipeline.__call__)
+    got = [(n, p.default) for n, p in sig.parameters.items() if n not in ("self", "kwargs")]
+    assert got == want
+    assert list(sig.parameters)[-1] == "kwargs" and sig.parameters["kwargs"].kind is inspect.Parameter.VAR_KEYWORD
+    init = list(inspect.signature(PLN.GuidedShapePipeline.__init__).parameters)
+    assert init[1:8] == ["vae", "model", "scheduler", "conditioner", "image_processor", "device", "dtype"]   # PL:563-573
+
+
+def test_latent2sdf_chunking_sign_and_layout():
+    """PL:292-313: latent rescaled by 1/scale_factor, queries in chunks, logits negated, (1,G,G,G) x-major float32."""
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(scale_factor=0.5)
+    xyz, gsz, _ = PLN.generate_dense_grid_points(np.full(3, -1.1), np.full(3, 1.1), 5, octree_resolution=6)
+    xyz = torch.as_tensor(xyz)
+    lat = torch.randn(1, *vae.latent_shape)
+    a = PLN.latent2sdf(lat, xyz, gsz, vae, "cpu", num_chunks=50)
+    b = PLN.latent2sdf(lat, xyz, gsz, vae, "cpu", num_chunks=8000)
+    assert a.shape == (1, 7, 7, 7) and a.dtype == torch.float32 and torch.allclose(a, b, atol=1e-6)
+    direct = -vae.geo_decoder(xyz[None], vae(lat / 0.5)).reshape(7, 7, 7)
+    assert torch.allclose(a[0], direct, atol=1e-6)
+    assert a[0, 3, 3, 3] < 0 < a[0, 0, 0, 0]                 # negative inside (box centre), positive at the corner
+    lat.requires_grad_(True)
+    PLN.latent2sdf(lat, xyz, gsz, vae, "cpu").sum().backward()
+    assert lat.grad.abs().sum() > 0
+
+
+def test_encode_cond_prepare_latents_and_image(tmp_path):
+    pipe = standins.make_standin_pipeline(device="cpu")
+    from PIL import Image
+    rgba = np.zeros((40, 40, 4), np.uint8)
+    rgba[10:30, 10:30] = 255
+    img = Image.fromarray(rgba, "RGBA")
+    im, mk = pipe.prepare_image([img])
+    assert im.shape == (1, 3, 32, 32) and mk.shape == (1, 1, 32, 32)
+    c = pipe.encode_cond(image=im, mask=mk, do_classifier_free_guidance=True, dual_guidance=False)
+    assert c["main"].shape[0] == 2 and torch.equal(c["main"][1], torch.zeros_like(c["main"][1]))   # [cond, uncond]
+    c1 = pipe.encode_cond(image=im, mask=mk, do_classifier_free_guidance=False, dual_guidance=False)
+    assert c1["main"].shape[0] == 1 and torch.allclose(c1["main"][0], c["main"][0])
+    l1 = pipe.prepare_latents(1, torch.float32, "cpu", torch.Generator().manual_seed(2))
+    l2 = pipe.prepare_latents(1, torch.float32, "cpu", torch.Generator().manual_seed(2))
+    assert l1.shape == (1, *pipe.vae.latent_shape) and torch.equal(l1, l2)
+    with pytest.raises(ValueError):
+        pipe.prepare_latents(2, torch.float32, "cpu", [torch.Generator()])
+    with pytest.raises(FileNotFoundError):
+        pipe.prepare_image(str(tmp_path / "missing.png"))
+
+
+def test_similarity_about_center_matches_reference_formula():
+    """PL:108-118 with a quaternion rotation (PL:1322-1325)."""
+    v = torch.randn(50, 3)
+    q = torch.tensor([0.9, 0.1, -0.2, 0.3])
+    out = PLN.similarity_about_center(v, torch.tensor([1.3]), q, torch.tensor([0.1, 0.2, -0.3]))
+    c = (v.min(0)[0] + v.max(0)[0]) / 2
+    w, x, y, z = (q / q.norm()).tolist()
+    R = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert torch.allclose(out, (1.3 * (v - c)) @ R.T + c + torch.tensor([0.1, 0.2, -0.3]), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+def _scene_for_pipeline(H=128, W=128, radius=0.8):
+    """A synthetic image whose object fills the Hunyuan box like a real decode does: the Hunyuan -> MoGe similarity is
+    rescaled so that a Hunyuan-space radius of `radius` becomes the scene's 5 cm object."""
+    from followmyhold_amd import engine as E
+    sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="ico4", H=H, W=W, seed=5)
+    T = sc["T_h2m"].astype(np.float64)
+    ov_moge = sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    s_old = np.cbrt(np.linalg.det(T[:3, :3]))
+    T2 = T.copy()
+    T2[:3, :3] *= (0.05 / radius) / s_old
+    sc["T_h2m"] = T2.astype(np.float32)
+    sc["obj_verts"] = ((ov_moge - T2[:3, 3]) @ np.linalg.inv(T2[:3, :3]).T).astype(np.float32)
+    return sc
+
+
+def _write(tmp_path, sc, index="7"):
+    names = ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir", "hamer_out_dir", "h2m_rt_dir",
+             "aligned_mano_dir"]
+    d = {n: os.path.join(str(tmp_path), n) for n in names}
+    T = sc["T_h2m"].astype(np.float64)
+    ov = sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    mv = np.concatenate([sc["gt_hand_verts"], ov.astype(np.float32)], 0)
+    mf = np.concatenate([sc["hand_faces"], sc["obj_faces"] + len(sc["gt_hand_verts"])], 0)
+    inputs.save_scene_files(sc, mv, mf, d, index)
+    from PIL import Image
+    rgba = np.zeros((sc["H"], sc["W"], 4), np.uint8)
+    rgba[sc["obj_mask"]] = 255
+    img_path = os.path.join(d["cropped_obj_img_dir"], f"{index}_cropped_hoi_1.png")
+    Image.fromarray(rgba, "RGBA").save(img_path)
+    return dict(cropped_obj_img_path=img_path,
+                hamer_for_guid_path=os.path.join(d["hamer_out_dir"], f"{index}_kps_for_guidance.npy"),
+                aligned_mano_mesh_path=os.path.join(d["aligned_mano_dir"], f"{index}_hamer_aligned_mano.ply"),
+                obj_mask_path=os.path.join(d["mask_dir"], f"{index}_cropped_obj_mask.png"),
+                hand_mask_path=os.path.join(d["mask_dir"], f"{index}_cropped_hand_mask.png"),
+                moge_mesh_path=os.path.join(d["moge_out_dir"], f"{index}_cropped_hoi", "mesh.glb"),
+                h2m_rt_path=os.path.join(d["h2m_rt_dir"], f"{index}_hoi_mesh.npy"),
+                hunyuan_hoi_mesh_path=os.path.join(d["hunyuan_hoi_mesh_dir"], f"{index}_hoi_mesh.ply"))
+
+
+def _short_config(noise_lr=None):
+    from followmyhold_amd import engine as E
+    c = E.OptimizationConfig()
+    c.num_inference_steps, c.guidance_start_step, c.handopt_start_step, c.guidance_end_step = 5, 2, 1, 5
+    c.optimization_steps_hand, c.optimization_steps_scale, c.optimization_steps_joint = 10, 3, 2
+    if noise_lr is not None:
+        c.noise_obj_lr1 = c.noise_obj_lr2 = noise_lr
+    return c
+
+
+def _renderer(fov):
+    from followmyhold_amd import facade as p3d
+    cams = p3d.FoVPerspectiveCameras(device="cuda", fov=fov)
+    return p3d.MeshRenderer(rasterizer=p3d.MeshRasterizer(cameras=cams, raster_settings=p3d.RasterizationSettings(image_size=128)),
+                            shader=p3d.PhongNormalShader(cameras=cams))
+
+
+@gpu
+def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
+    """All five denoising steps of a short schedule: phase A at step 1, B at step 2, C at steps 3-4, final decode on a
+    finer grid; returns (object Meshes, hand Meshes) in the MoGe world."""
+    from PIL import Image
+    from followmyhold_amd import facade as p3d
+    sc = _scene_for_pipeline()
+    paths = _write(tmp_path, sc)
+    monkeypatch.setenv("FOHO_DEBUG_DIR", str(tmp_path / "debug"))
+    pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1)
+    img = Image.open(paths["cropped_obj_img_path"])
+
+    def run(cfg):
+        return pipe(image=[img], mc_algo="mc", generator=torch.manual_seed(2), config=cfg, renderer=_renderer(sc["fov"]),
+                    sil_renderer=None, J_regressor=sc["J_regressor"], guidance_octree_resolution=24,
+                    final_octree_resolution=40, callback=lambda *a: None, callback_steps=1, **paths)
+
+    obj, hand = run(_short_config())
+    assert isinstance(obj, p3d.Meshes) and isinstance(hand, p3d.Meshes)
+    assert pipe.stats == {"inner_iterations": 10 + 3 + 2 * 2, "skipped_empty": 0}
+    ov, of = obj.verts_packed(), obj.faces_packed()
+    hv, hf = hand.verts_packed(), hand.faces_packed()
+    assert ov.shape[0] > 1000 and of.shape[0] == 2 * ov.shape[0] - 4            # closed genus-0 surface from the fine grid
+    assert torch.isfinite(ov).all() and torch.isfinite(hv).all()
+    assert hv.shape == (778, 3) and np.array_equal(hf.cpu().numpy(), sc["hand_faces"])
+    # the object sits where the Hunyuan -> MoGe transform and the optimised similarity put it: near the scene's object
+    T = sc["T_h2m"].astype(np.float64)
+    centre = (sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).mean(0)
+    assert np.abs(ov.mean(0).cpu().numpy() - centre).max() < 0.05
+    # the hand is the MoGe-space MANO mesh under the optimised similarity (PL:1614-1618)
+    gb = pipe.guidance_batch
+    p = gb.params[0]
+    want = PLN.similarity_about_center(torch.as_tensor(sc["hand_verts"], device="cuda"), p[0], p[4:8], p[1:4])
+    assert torch.allclose(hv, want, atol=1e-5)
+    assert not torch.allclose(p[:8].cpu(), torch.tensor([1.0, 0, 0, 0, 1, 0, 0, 0]))      # phase A moved the hand
+    assert not torch.allclose(p[8:].cpu(), torch.tensor([1.0, 0, 0, 0, 1, 0, 0, 0]))      # phases B / C moved the object
+    # debug artefacts (PL:1076-1091, 1664-1675)
+    dbg = [os.path.join(r, f) for r, _, fs in os.walk(str(tmp_path / "debug")) for f in fs]
+    assert any(f.endswith("params.json") for f in dbg) and any(f.endswith("final_obj_mesh.ply") for f in dbg)
+    assert "Joint optimization step 4" in open([f for f in dbg if f.endswith("losses.txt")][0]).read()
+    # the gradient reaches the latent: with the latent's learning rates at zero the decoded object differs
+    monkeypatch.delenv("FOHO_DEBUG_DIR")
+    obj0, _ = run(_short_config(noise_lr=0.0))
+    v0 = obj0.verts_packed()
+    assert v0.shape != ov.shape or not torch.allclose(v0, ov, atol=1e-6)
+
+
+@gpu
+def test_latent_to_loss_chain_matches_the_oracle_chain():
+    """One phase-C iteration exactly as the pipeline runs it (PL:1505-1601): noise prediction -> step_final -> VAE ->
+    SDF grid -> FlexiCubes -> joint loss, and dL/d(noise prediction).  HIP chain vs the CPU chain through the oracle
+    (same VAE weights on the CPU -> oracle/flexi_ref -> oracle/step_ref)."""
+    from followmyhold_amd import engine as E, ops
+    from helpers import make_scene
+    from oracle import flexi_ref as FR, ref_ops as R, step_ref as S
+    res = 12
+    sc = make_scene("ico2", 64, 64, seed=0)
+    # Hunyuan -> MoGe similarity rescaled so that the stand-in decoder's r = 0.8 sphere is the scene's object
+    T = sc["T_h2m"].double()
+    s_old = float(torch.linalg.det(T[:3, :3])) ** (1 / 3)
+    T2 = T.clone()
+    T2[:3, :3] *= (float(sc["obj_verts"].norm(dim=1).mean()) * s_old / 0.8) / s_old
+    sc["T_h2m"] = T2.float()
+    torch.manual_seed(3)
+    vae = standins.StandInShapeVAE(gain=0.4)
+    sch = FlowMatchEulerDiscreteScheduler()
+    sch.set_timesteps(sigmas=np.linspace(0, 1, 20), device="cpu")
+    t = sch.timesteps[12]
+    latents = torch.randn(1, *vae.latent_shape)
+    noise0 = torch.randn(1, *vae.latent_shape)
+    xyz, gsz, _ = PLN.generate_dense_grid_points(np.full(3, -1.1), np.full(3, 1.1), 5, octree_resolution=res)
+    xyz = torch.as_tensor(xyz)
+    # oracle chain (CPU)
+    n_o = noise0.clone().requires_grad_(True)
+    sdf_o = PLN.latent2sdf(sch.step_final(n_o, t, latents), xyz, gsz, vae, "cpu")
+    V, F, _ = FR.flexicubes(xyz, sdf_o[0].flatten(), res)
+    assert len(V) > 100
+    p = S.make_params()
+    total, terms, aux = S.phase_c_loss(dict(sc, obj_faces=F), p, V, R.unique_edges(F), denoise_i=19, grid_res=16)
+    total.backward()
+    # HIP chain
+    sch_g = FlowMatchEulerDiscreteScheduler()
+    sch_g.set_timesteps(sigmas=np.linspace(0, 1, 20), device="cuda")
+    vae_g = vae.to("cuda")
+    n_g = noise0.cuda().requires_grad_(True)
+    sdf_g = PLN.latent2sdf(sch_g.step_final(n_g, sch_g.timesteps[12], latents.cuda()), xyz.cuda(), gsz, vae_g, "cuda")
+    assert torch.equal(sdf_g.cpu() < 0, sdf_o.detach() < 0)            # same inside/outside pattern on both devices
+    v, f, _ = ops.flexicubes(xyz.cuda(), sdf_g[0].flatten(), res)
+    assert torch.equal(f.cpu(), F)
+    npsc = {k: (v_.numpy() if isinstance(v_, torch.Tensor) else v_) for k, v_ in sc.items()}
+    gb = E.GuidanceBatch([npsc], grid_res=16)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    loss = gb.objective(v, f, cfg)
+    loss.backward()
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    assert abs(float(loss) - float(total)) <= 1e-4 * abs(float(total))
+    g, go = n_g.grad.cpu().numpy(), n_o.grad.numpy()
+    assert np.linalg.norm(go) > 0 and np.linalg.norm(g - go) <= 5e-3 * np.linalg.norm(go), (np.linalg.norm(g - go), np.linalg.norm(go))
