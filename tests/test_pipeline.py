@@ -239,3 +239,28 @@ def test_latent_to_loss_chain_matches_the_oracle_chain():
     assert abs(float(loss) - float(total)) <= 1e-4 * abs(float(total))
     g, go = n_g.grad.cpu().numpy(), n_o.grad.numpy()
     assert np.linalg.norm(go) > 0 and np.linalg.norm(g - go) <= 5e-3 * np.linalg.norm(go), (np.linalg.norm(g - go), np.linalg.norm(go))
+
+
+@gpu
+def test_guidance_stage_driver_with_standin_networks(tmp_path, monkeypatch):
+    """`foho.guidance.run.run` (RUN:188-261) end to end through GuidedShapePipeline: image -> RGBA with white made
+    transparent, pipeline call with the reference's keyword arguments, {idx}_obj.ply / {idx}_hand.ply written."""
+    from foho.guidance import run as G
+    from followmyhold_amd import meshio
+    sc = _scene_for_pipeline()
+    paths = _write(tmp_path, sc, index="31")
+    jr = str(tmp_path / "J.npy")
+    np.save(jr, sc["J_regressor"])
+    monkeypatch.setenv("FOHO_J_REGRESSOR", jr)
+    monkeypatch.setenv("FOHO_STANDIN_NETWORKS", "1")
+    monkeypatch.setattr(G, "_PIPELINE", None)
+    monkeypatch.setattr(G, "OptimizationConfig", lambda: _short_config())
+    img = G._load_object_image(paths["cropped_obj_img_path"])[0]
+    assert img.mode == "RGBA"
+    d = {k: os.path.join(str(tmp_path), k) for k in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                                     "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]}
+    G.run(project_root=str(tmp_path), task_list_file=None, **d)
+    ov, of = meshio.load_ply(os.path.join(d["guidance_out_dir"], "31_obj.ply"))
+    hv, hf = meshio.load_ply(os.path.join(d["guidance_out_dir"], "31_hand.ply"))
+    assert len(ov) > 1000 and len(of) == 2 * len(ov) - 4 and np.isfinite(ov).all()
+    assert hv.shape == (778, 3) and np.array_equal(hf, sc["hand_faces"])
