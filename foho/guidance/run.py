@@ -91,13 +91,18 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
         obj_mask_path=cropped_obj_mask_path, hand_mask_path=cropped_hand_mask_path, moge_mesh_path=moge_mesh_path,
         h2m_rt_path=T_h2m_path, hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path)
     obj_mesh, hand_mesh = out       # a None return (NaN in phase B, PL:1442-1444) raises here like in the reference
-    try:
-        meshio.save_ply(save_path_obj, obj_mesh.verts_packed().cpu().numpy(), obj_mesh.faces_packed().cpu().numpy())
+    try:    # RUN:159-166: floaters, degenerate faces, decimation to 40k faces, export
+        from followmyhold_amd import postprocess as pp
+        obj_mesh = pp.TriMesh(obj_mesh.verts_packed().cpu().numpy(), obj_mesh.faces_packed().cpu().numpy())
+        obj_mesh = pp.FloaterRemover()(obj_mesh)
+        obj_mesh = pp.DegenerateFaceRemover()(obj_mesh)
+        obj_mesh = pp.FaceReducer()(obj_mesh)
+        obj_mesh.export(save_path_obj)
         meshio.save_ply(save_path_hand, hand_mesh.verts_packed().cpu().numpy(), hand_mesh.faces_packed().cpu().numpy())
     except Exception:
         print(f"Error in saving mesh for {cropped_obj_img_path}")
         return None, None
-    if obj_mesh.verts_packed().shape[0] == 0:
+    if len(obj_mesh.vertices) == 0:
         print(f"Empty mesh for {cropped_obj_img_path}")
         return None, None
     return obj_mesh, hand_mesh

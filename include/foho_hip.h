@@ -32,6 +32,7 @@
  *   foho_lbs_fwd/_bwd        smplx MANOLayer forward (third_party/estimator/hamer/hamer/models/hamer.py:125-130)
  *   foho_icp_run             icp() loop: cKDTree.query + trimmed procrustes + scale clip (ICP:104-142)
  *   foho_icp_run_batch       the same for all start transforms of icp() at once (ICP:91-175)
+ *   foho_mesh_decimate       hy3dgen FaceReducer = pymeshlab quadric edge collapse (RUN:163), host code
  */
 #ifndef FOHO_HIP_H
 #define FOHO_HIP_H
@@ -261,6 +262,15 @@ int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* gra
 size_t foho_topology_workspace_bytes(int32_t V);
 int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8_t* obj_flag, int32_t* inc_off, int32_t* inc_fc,
                          int32_t* nbr_idx, int32_t* flag, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- mesh post-processing after the pipeline ------------------------------------------
+ * `obj_mesh = FaceReducer()(obj_mesh)` (src/foho/guidance/run.py:163): hy3dgen's pymeshlab quadric edge-collapse
+ * decimation to at most 40 000 faces (preserve boundary / normals / topology).  HOST pointers, synchronous, no GPU
+ * involved (the reference's is MeshLab's serial CPU code; it runs once per image).  verts (V,3) float32, faces (F,3)
+ * int64 -> out_verts (room for V x 3), out_faces (room for F x 3), out_counts[2] = {vertices, faces} written.
+ * Vertices and faces keep their relative order; the same input gives the same output. */
+int foho_mesh_decimate(const float* verts, int32_t V, const int64_t* faces, int32_t F, int32_t target_faces,
+                       float* out_verts, int64_t* out_faces, int32_t* out_counts);
 
 #ifdef __cplusplus
 }

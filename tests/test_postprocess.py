@@ -1,0 +1,119 @@
+"""Mesh post-processing (src/foho/guidance/run.py:159-164: FloaterRemover, DegenerateFaceRemover, FaceReducer).  The
+reference's filters live in pymeshlab behind hy3dgen (neither available: parity unpinned), so the tests are known-answer
+properties of the published algorithms.  Host code only: runs without a GPU."""
+import numpy as np
+import pytest
+
+from followmyhold_amd import postprocess as PP, synthetic
+
+
+def _edge_counts(f):
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    _, c = np.unique(e, axis=0, return_counts=True)
+    return c
+
+
+def _volume(v, f):
+    t = v[f].astype(np.float64)
+    return float(np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0)
+
+
+def _box(n):
+    """Closed axis-aligned unit box, every side an n x n grid of quads split into triangles, outward orientation."""
+    idx, verts, faces = {}, [], []
+
+    def vid(p):
+        k = tuple(np.round(p, 9))
+        if k not in idx:
+            idx[k] = len(verts)
+            verts.append(p)
+        return idx[k]
+
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            u, w = [(1, 2), (2, 0), (0, 1)][axis]
+            for i in range(n):
+                for j in range(n):
+                    q = []
+                    for di, dj in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                        p = np.zeros(3)
+                        p[axis], p[u], p[w] = side, (i + di) / n, (j + dj) / n
+                        q.append(vid(p))
+                    if side == 0.0:
+                        q = q[::-1]
+                    faces += [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]
+    return np.array(verts, np.float32), np.array(faces, np.int64)
+
+
+def test_decimation_of_a_sphere_stays_a_closed_oriented_sphere():
+    v, f = synthetic.icosphere(5, 1.0)                      # 20480 faces
+    ov, of = PP.decimate(v, f, 2000)
+    assert len(of) <= 2000 and len(of) >= 1990
+    assert (_edge_counts(of) == 2).all()                    # closed 2-manifold
+    assert len(ov) - 3 * len(of) // 2 + len(of) == 2        # Euler characteristic of a sphere
+    assert np.abs(np.linalg.norm(ov, axis=1) - 1.0).max() < 0.02
+    assert abs(_volume(ov, of) - _volume(v, f)) < 0.02 * _volume(v, f) and _volume(ov, of) > 0
+    ov2, of2 = PP.decimate(v, f, 2000)
+    assert np.array_equal(ov, ov2) and np.array_equal(of, of2)          # deterministic
+    # asking for more faces than there are is the identity; the smallest closed result is a tetrahedron
+    same_v, same_f = PP.decimate(v, f, 10 ** 6)
+    assert np.array_equal(same_v, v) and np.array_equal(same_f, f)
+    tv, tf = PP.decimate(v, f, 0)
+    assert len(tf) >= 4 and (_edge_counts(tf) == 2).all()
+
+
+def test_decimation_keeps_planar_regions_and_sharp_edges_exact():
+    """Quadric error is zero for collapses inside a plane or along a crease: a finely tessellated box decimates to a
+    coarse box with the same volume and corners."""
+    v, f = _box(12)                                         # 1728 faces
+    assert (_edge_counts(f) == 2).all() and abs(_volume(v, f) - 1.0) < 1e-6
+    ov, of = PP.decimate(v, f, 60)
+    assert len(of) <= 60 and (_edge_counts(of) == 2).all()
+    assert abs(_volume(ov, of) - 1.0) < 1e-5
+    corners = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    assert all(np.abs(ov - c).sum(1).min() < 1e-5 for c in corners)
+    assert ov.min() > -1e-5 and ov.max() < 1 + 1e-5
+
+
+def test_decimation_preserves_an_open_boundary():
+    n = 24
+    ys, xs = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    z = 0.05 * np.sin(xs / n * 6.0) * np.cos(ys / n * 5.0)
+    v = np.stack([xs / n, ys / n, z], -1).reshape(-1, 3).astype(np.float32)
+    q = (ys[:-1, :-1] * (n + 1) + xs[:-1, :-1]).reshape(-1)
+    f = np.concatenate([np.stack([q, q + 1, q + n + 2], 1), np.stack([q, q + n + 2, q + n + 1], 1)]).astype(np.int64)
+    ov, of = PP.decimate(v, f, 200)
+    c = _edge_counts(of)
+    assert len(of) <= 200 and set(np.unique(c)) <= {1, 2} and (c == 1).sum() >= 4
+    assert np.allclose(ov[:, :2].min(0), 0, atol=1e-3) and np.allclose(ov[:, :2].max(0), 1, atol=1e-3)   # outline kept
+    t = ov[of].astype(np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum()
+    assert 0.98 < area < 1.1
+    assert (np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])[:, 2] > 0).all()          # no flipped triangle
+
+
+def test_floater_and_degenerate_removal_and_the_reference_chain(tmp_path):
+    v, f = synthetic.icosphere(4, 1.0)                      # 5120 faces
+    sv, sf = synthetic.icosphere(0, 0.05)                   # 20-face floater = 0.39 % of the big component
+    mv, mf = synthetic.icosphere(1, 0.2)                    # 80 faces = 1.6 %: stays
+    verts = np.concatenate([v, sv + 3.0, mv - 3.0]).astype(np.float32)
+    faces = np.concatenate([f, sf + len(v), mf + len(v) + len(sv)])
+    verts = np.concatenate([verts, [[9, 9, 9]]]).astype(np.float32)                   # unused vertex
+    faces = np.concatenate([faces, [[0, 0, 1]], [[2, 3, 3]]])                       # index-degenerate faces
+    label, counts = PP.face_components(len(verts), faces[:-2])
+    assert sorted(counts.tolist()) == [20, 80, 5120]
+    m = PP.DegenerateFaceRemover()((verts, faces))
+    assert len(m.faces) == 5120 + 20 + 80 and len(m.vertices) == len(verts) - 1
+    m = PP.FloaterRemover()(m)
+    assert len(m.faces) == 5120 + 80 and len(m.vertices) == len(v) + len(mv)
+    m2 = PP.FaceReducer()(m)                                # below 40000 faces: untouched
+    assert m2 is m
+    m3 = PP.FaceReducer()(m, max_facenum=1000)
+    assert len(m3.faces) <= 1000 and (_edge_counts(m3.faces) == 2).all()
+    p = str(tmp_path / "o.ply")
+    m3.export(p)
+    from followmyhold_amd import meshio
+    rv, rf = meshio.load_ply(p)
+    assert np.array_equal(rf, m3.faces) and np.allclose(rv, m3.vertices)
+    with pytest.raises(Exception):
+        PP.decimate(verts, np.array([[0, 1, 10 ** 6]]), 10)
