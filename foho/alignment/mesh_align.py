@@ -158,8 +158,10 @@ def icp(source_mesh: Mesh, target_mesh: Mesh, n_iter, count_source=5_000, count_
         test_rotations=False, fixed_scale=False, outliers=0, on_surface=False, min_scale=0.5, max_scale=2.0, plot=False,
         seed: Optional[int] = 0):
     """ICP:56-175.  Returns (best_of_all_transform (4,4), best_of_all_cost)."""
-    if plot or on_surface:
-        raise NotImplementedError("plot / on_surface need pyvista / trimesh.proximity, which this build does not ship")
+    if plot:
+        raise NotImplementedError("plot needs pyvista (an interactive viewer), which this build does not ship")
+    if on_surface and target_mesh.is_point_cloud:
+        raise ValueError("on_surface needs a target mesh with faces (trimesh.proximity.closest_point, ICP:106-107)")
     from followmyhold_amd import ops
     rng = np.random.default_rng(seed)
     cubes = [np.eye(4)]
@@ -177,8 +179,12 @@ def icp(source_mesh: Mesh, target_mesh: Mesh, n_iter, count_source=5_000, count_
     n_outliers = min(n_outliers, len(source_points) - 2)
     # `for cube in cubes` (ICP:91) as one batched enqueue; the first strictly lowest cost wins, as in the loop
     starts = np.stack([transform_points(source_points, cube) for cube in cubes])
-    Ts, costs = ops.icp_points_multi(starts, target_points, n_iter, n_outliers=n_outliers, fixed_scale=fixed_scale,
-                                     min_scale=min_scale, max_scale=max_scale)
+    if on_surface:      # closest point ON the target triangles instead of the nearest sampled target point (ICP:106-107)
+        Ts, costs = ops.icp_points_multi(starts, target_mesh.vertices, n_iter, n_outliers=n_outliers, fixed_scale=fixed_scale,
+                                         min_scale=min_scale, max_scale=max_scale, target_faces=target_mesh.faces)
+    else:
+        Ts, costs = ops.icp_points_multi(starts, target_points, n_iter, n_outliers=n_outliers, fixed_scale=fixed_scale,
+                                         min_scale=min_scale, max_scale=max_scale)
     best_cost, best_T = np.inf, np.eye(4)
     for cube, T, cost in zip(cubes, Ts, costs):
         if cost < best_cost:

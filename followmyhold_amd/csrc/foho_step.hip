@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
 
 #include "../../include/foho_hip.h"
 #include "foho_common.h"

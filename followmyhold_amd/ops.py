@@ -164,34 +164,49 @@ def lbs(betas, rot_mats, model: LbsModel, use_mfma=-1):
 
 # ------------------------------------------------------------------------------------------------ ICP
 def icp_points_multi(start_points, target_points, n_iter, n_outliers=0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
-                     device="cuda", return_history=False):
+                     device="cuda", return_history=False, target_faces=None):
     """The icp() loop of src/foho/alignment/mesh_align.py:91-142 for ALL start point sets (S, N, 3) against one target
-    (float64), one enqueue and one synchronisation.  Returns (transforms (S,4,4), costs (S,)[, histories (S,n_iter)])."""
+    (float64), one enqueue and one synchronisation.  Returns (transforms (S,4,4), costs (S,)[, histories (S,n_iter)]).
+    target_faces (F,3) switches to on_surface=True (ICP:106-107): target_points are then the target mesh's vertices and
+    every source point is matched to the closest point on the triangles."""
     lib = L.lib()
     src = torch.as_tensor(np.ascontiguousarray(np.asarray(start_points, np.float64))).to(device)
     tgt = torch.as_tensor(np.ascontiguousarray(np.asarray(target_points, np.float64))).to(device)
     if src.dim() != 3 or src.shape[2] != 3 or tgt.dim() != 2 or tgt.shape[1] != 3:
         raise L.FohoError("icp_points_multi: expected (S,N,3) start points and (M,3) target points")
     S, N, M = src.shape[0], src.shape[1], tgt.shape[0]
-    lib.foho_icp_batch_workspace_bytes.restype = ctypes.c_size_t
-    nws = lib.foho_icp_batch_workspace_bytes(S, N, M)
+    tf = None
+    if target_faces is not None:
+        tf = torch.as_tensor(np.ascontiguousarray(np.asarray(target_faces, np.int32))).to(device)
+        if tf.dim() != 2 or tf.shape[1] != 3 or tf.shape[0] < 1:
+            raise L.FohoError("icp_points_multi: target_faces must be (F,3)")
+        if int(tf.min()) < 0 or int(tf.max()) >= M:
+            raise L.FohoError("icp_points_multi: target face index out of range")
+        lib.foho_icp_surface_workspace_bytes.restype = ctypes.c_size_t
+        nws = lib.foho_icp_surface_workspace_bytes(S, N, tf.shape[0])
+    else:
+        lib.foho_icp_batch_workspace_bytes.restype = ctypes.c_size_t
+        nws = lib.foho_icp_batch_workspace_bytes(S, N, M)
     ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=device)
     T = torch.zeros(S, 16, dtype=torch.float64, device=device)
     cost = torch.zeros(S, dtype=torch.float64, device=device)
     hist = torch.zeros(S, max(n_iter, 1), dtype=torch.float64, device=device)
-    L.check(lib.foho_icp_run_batch(P(src.data_ptr()), S, N, P(tgt.data_ptr()), M, int(n_iter), int(n_outliers),
-                                   int(bool(fixed_scale)), ctypes.c_double(min_scale), ctypes.c_double(max_scale),
-                                   P(T.data_ptr()), P(cost.data_ptr()), P(hist.data_ptr()), P(ws.data_ptr()),
-                                   ctypes.c_size_t(nws), _stream(src)), "foho_icp_run_batch")
+    tail = (int(n_iter), int(n_outliers), int(bool(fixed_scale)), ctypes.c_double(min_scale), ctypes.c_double(max_scale),
+            P(T.data_ptr()), P(cost.data_ptr()), P(hist.data_ptr()), P(ws.data_ptr()), ctypes.c_size_t(nws), _stream(src))
+    if tf is not None:
+        L.check(lib.foho_icp_run_surface(P(src.data_ptr()), S, N, P(tgt.data_ptr()), M, P(tf.data_ptr()), int(tf.shape[0]), *tail),
+                "foho_icp_run_surface")
+    else:
+        L.check(lib.foho_icp_run_batch(P(src.data_ptr()), S, N, P(tgt.data_ptr()), M, *tail), "foho_icp_run_batch")
     out = (T.cpu().numpy().reshape(S, 4, 4), cost.cpu().numpy())      # the copies synchronise
     return out + (hist.cpu().numpy()[:, :n_iter],) if return_history else out
 
 
 def icp_points(source_points, target_points, n_iter, n_outliers=0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
-               device="cuda", return_history=False):
+               device="cuda", return_history=False, target_faces=None):
     """One start of icp_points_multi.  Returns (best_transform (4,4) np.float64, best_cost float[, cost history])."""
     out = icp_points_multi(np.asarray(source_points, np.float64)[None], target_points, n_iter, n_outliers, fixed_scale,
-                           min_scale, max_scale, device, return_history)
+                           min_scale, max_scale, device, return_history, target_faces)
     return (out[0][0], float(out[1][0])) + ((out[2][0],) if return_history else ())
 
 

@@ -32,6 +32,7 @@
  *   foho_lbs_fwd/_bwd        smplx MANOLayer forward (third_party/estimator/hamer/hamer/models/hamer.py:125-130)
  *   foho_icp_run             icp() loop: cKDTree.query + trimmed procrustes + scale clip (ICP:104-142)
  *   foho_icp_run_batch       the same for all start transforms of icp() at once (ICP:91-175)
+ *   foho_icp_run_surface     the same with on_surface=True: closest point on the target triangles (ICP:106-107)
  *   foho_mesh_decimate       hy3dgen FaceReducer = pymeshlab quadric edge collapse (RUN:163), host code
  */
 #ifndef FOHO_HIP_H
@@ -236,6 +237,15 @@ size_t foho_icp_batch_workspace_bytes(int32_t n_starts, int32_t N, int32_t M);
 int foho_icp_run_batch(const double* src, int32_t n_starts, int32_t N, const double* tgt, int32_t M, int32_t n_iter,
                        int32_t n_outliers, int32_t fixed_scale, double min_scale, double max_scale, double* T_out,
                        double* cost_out, double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
+
+/* icp(..., on_surface=True) (ICP:106-107): q = trimesh.proximity.closest_point(target_mesh, p), the closest point ON the
+ * target triangles (float64 brute force over all Ft triangles, Voronoi-region test per triangle) instead of the nearest
+ * sampled target point; everything else as foho_icp_run_batch.  tgt_verts (Vt,3) float64, tgt_faces (Ft,3) int32. */
+size_t foho_icp_surface_workspace_bytes(int32_t n_starts, int32_t N, int32_t Ft);
+int foho_icp_run_surface(const double* src, int32_t n_starts, int32_t N, const double* tgt_verts, int32_t Vt,
+                         const int32_t* tgt_faces, int32_t Ft, int32_t n_iter, int32_t n_outliers, int32_t fixed_scale,
+                         double min_scale, double max_scale, double* T_out, double* cost_out, double* cost_history,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- iso-surfacing between the diffusion latent and the guidance path ----------------
  * kaolin FlexiCubes.__call__(x_nx3, s_n, cube_fx8, res) with default weights, as called at pipelines.py:1393 / 1509

@@ -78,11 +78,60 @@ def nearest(p, q):
     return np.sqrt(d2[np.arange(len(p)), idx]), idx
 
 
+def closest_point_on_triangles(tri, p):
+    """trimesh.triangles.closest_point for every (point, triangle) pair: tri (F,3,3), p (N,3) -> (N,F,3).  Voronoi regions
+    of the triangle (Ericson, Real-Time Collision Detection 5.1.5), evaluated branch-free; degenerate triangles -> NaN."""
+    a, b, c = tri[None, :, 0], tri[None, :, 1], tri[None, :, 2]
+    P = p[:, None, :]
+    ab, ac, ap = b - a, c - a, P - a
+    dot = lambda x, y: (x * y).sum(-1)
+    d1, d2 = dot(ab, ap), dot(ac, ap)
+    bp = P - b
+    d3, d4 = dot(ab, bp), dot(ac, bp)
+    cp = P - c
+    d5, d6 = dot(ab, cp), dot(ac, cp)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        denom = 1.0 / (va + vb + vc)
+        v, w = vb * denom, vc * denom                                   # interior
+        m_bc = (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0)
+        wbc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        v, w = np.where(m_bc, 1 - wbc, v), np.where(m_bc, wbc, w)
+        m_ac = (vb <= 0) & (d2 >= 0) & (d6 <= 0)
+        v, w = np.where(m_ac, 0.0, v), np.where(m_ac, d2 / (d2 - d6), w)
+        m_c = (d6 >= 0) & (d5 <= d6)
+        v, w = np.where(m_c, 0.0, v), np.where(m_c, 1.0, w)
+        m_ab = (vc <= 0) & (d1 >= 0) & (d3 <= 0)
+        v, w = np.where(m_ab, d1 / (d1 - d3), v), np.where(m_ab, 0.0, w)
+        m_b = (d3 >= 0) & (d4 <= d3)
+        v, w = np.where(m_b, 1.0, v), np.where(m_b, 0.0, w)
+        m_a = (d1 <= 0) & (d2 <= 0)
+        v, w = np.where(m_a, 0.0, v), np.where(m_a, 0.0, w)
+    return a + ab * v[..., None] + ac * w[..., None]
+
+
+def closest_point(verts, faces, p, chunk=256):
+    """trimesh.proximity.closest_point(mesh, p)[:2]: closest surface point and distance (exhaustive instead of the
+    r-tree candidate search; ties -> lowest face index)."""
+    tri = np.asarray(verts, np.float64)[np.asarray(faces)]
+    q, dist = np.zeros_like(p), np.zeros(len(p))
+    for s0 in range(0, len(p), chunk):
+        pc = p[s0:s0 + chunk]
+        cand = closest_point_on_triangles(tri, pc)
+        d2 = ((cand - pc[:, None, :]) ** 2).sum(-1)
+        d2 = np.where(np.isnan(d2), np.inf, d2)
+        idx = d2.argmin(1)
+        q[s0:s0 + chunk] = cand[np.arange(len(pc)), idx]
+        dist[s0:s0 + chunk] = np.sqrt(d2[np.arange(len(pc)), idx])
+    return q, dist
+
+
 def icp_points(source_points, target_points, n_iter, outliers=0.0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
-               record=None):
+               record=None, target_faces=None):
     """ICP:91-142 for one 'cube' (identity start), on already-sampled point sets.
     Returns (best_transform, best_cost) with the reference's bookkeeping: the cost of an iteration is measured
-    BEFORE that iteration's update while `best_transform` stores the transform AFTER it (ICP:129, ICP:140-142)."""
+    BEFORE that iteration's update while `best_transform` stores the transform AFTER it (ICP:129, ICP:140-142).
+    target_faces given = on_surface (ICP:106-107): `target_points` are the target mesh's vertices."""
     src = np.asarray(source_points, np.float64)
     tgt = np.asarray(target_points, np.float64)
     n_out = int(outliers * len(src))
@@ -90,8 +139,11 @@ def icp_points(source_points, target_points, n_iter, outliers=0.0, fixed_scale=F
     best_cost, best_transform = np.inf, transform.copy()
     for _ in range(n_iter):
         p = transform_points(src, transform)
-        dist, qi = nearest(p, tgt)
-        q = tgt[qi]
+        if target_faces is not None:
+            q, dist = closest_point(tgt, target_faces, p)
+        else:
+            dist, qi = nearest(p, tgt)
+            q = tgt[qi]
         if n_out > 0:
             order = np.argsort(dist)  # same default (quicksort) as the reference's np.argsort
             inl = order[:-n_out]

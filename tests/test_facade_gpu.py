@@ -131,3 +131,27 @@ def test_alignment_stage_end_to_end(tmp_path):
     moved = v @ T[:3, :3].T + T[:3, 3]
     err = np.linalg.norm(moved - (v @ M[:3, :3].T + M[:3, 3]), axis=1).mean()
     assert err < 0.05 * 0.4, err      # point-to-point ICP on sampled points: within 5 % of the 0.4 m object diameter
+
+
+@gpu
+def test_align_meshes_on_surface(tmp_path):
+    """align_meshes_impl(..., on_surface=True) (ICP:106-107, CLI flag -os): mesh-to-mesh alignment against the target
+    triangles; at least as tight as the sampled-point variant of the same call."""
+    from foho.alignment import mesh_align as MA
+    from followmyhold_amd import meshio, synthetic
+    v, f = synthetic.make_object("20k")
+    v = v.astype(np.float64) * 4
+    M = np.eye(4)
+    M[:3, :3] = 1.2 * synthetic.axis_angle_matrix([0.05, 0.02, -0.04])
+    M[:3, 3] = [0.2, 0.1, -0.15]
+    a, b = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    meshio.save_ply(a, v, f)
+    meshio.save_ply(b, v @ M[:3, :3].T + M[:3, 3], f)
+    want = v @ M[:3, :3].T + M[:3, 3]
+    errs = {}
+    for os_ in (False, True):
+        T = MA.align_meshes_impl(a, b, None, None, False, 0.2, False, False, os_, 30, 1000, 5000, 40, 2000, 10000, 0.7, 3.0, False)
+        errs[os_] = np.linalg.norm(v @ T[:3, :3].T + T[:3, 3] - want, axis=1).mean()
+    assert errs[True] < 0.05 * 0.4 and errs[True] < 1.05 * errs[False], errs    # a near-sphere slides tangentially: 5 % of 0.4 m
+    with pytest.raises(ValueError):
+        MA.icp(MA.Mesh(v, f), MA.Mesh(v), 2, on_surface=True)

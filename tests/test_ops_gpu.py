@@ -134,3 +134,35 @@ def test_icp_multi_start_equals_the_per_start_loop():
     T_ref, c_ref = icp_ref.icp_points(starts[5], tgt, n_iter=8, outliers=0.2, min_scale=0.7, max_scale=3.0)
     assert abs(costs[5] - c_ref) <= 1e-9 * abs(c_ref) and np.allclose(Ts[5], T_ref, rtol=1e-8, atol=1e-10)
     assert np.argmin(costs) == 0      # the unrotated start wins on an asymmetric object
+
+
+@gpu
+def test_icp_on_surface_matches_the_numpy_reference():
+    """icp(..., on_surface=True) (ICP:106-107): source points are matched to the closest point ON the target triangles.
+    Same cost history and transform as the float64 restatement (exhaustive Voronoi-region closest point)."""
+    from followmyhold_amd import ops
+    rng = np.random.default_rng(11)
+    tv, tf = synthetic.icosphere(3, 0.3)                    # 1280 faces
+    tv = (tv * (1 + 0.2 * np.sin(9 * tv[:, :1]) * np.cos(7 * tv[:, 1:2]))).astype(np.float64)
+    bary = rng.dirichlet(np.ones(3), 400)
+    src0 = (tv[tf[rng.integers(0, len(tf), 400)]] * bary[:, :, None]).sum(1)
+    Mtx = np.eye(4)
+    Mtx[:3, :3] = 0.93 * synthetic.axis_angle_matrix([0.06, -0.04, 0.08])
+    Mtx[:3, 3] = [0.01, -0.012, 0.008]
+    src = icp_ref.transform_points(src0, np.linalg.inv(Mtx))
+    rec = []
+    T_ref, c_ref = icp_ref.icp_points(src, tv, n_iter=10, outliers=0.1, min_scale=0.7, max_scale=3.0, record=rec, target_faces=tf)
+    T, c, hist = ops.icp_points(src, tv, n_iter=10, n_outliers=40, min_scale=0.7, max_scale=3.0, return_history=True,
+                                target_faces=tf)
+    assert np.allclose(hist, [r[0] for r in rec], rtol=1e-8, atol=1e-13)
+    assert abs(c - c_ref) <= 1e-8 * abs(c_ref) + 1e-14 and np.allclose(T, T_ref, rtol=1e-7, atol=1e-9)
+    assert hist[-1] < 0.2 * hist[0]
+    # against the sampled-point variant the surface residual is the smaller one
+    _, c_pts = ops.icp_points(src, tv, n_iter=10, n_outliers=40, min_scale=0.7, max_scale=3.0)
+    assert c < c_pts
+    # batched starts share the triangles
+    Ts, cs = ops.icp_points_multi(np.stack([src, src + 0.01]), tv, n_iter=4, n_outliers=40, target_faces=tf)
+    T1, c1 = ops.icp_points(src + 0.01, tv, n_iter=4, n_outliers=40, target_faces=tf)
+    assert np.array_equal(Ts[1], T1) and cs[1] == c1
+    with pytest.raises(Exception):
+        ops.icp_points(src, tv, n_iter=2, target_faces=np.array([[0, 1, 10 ** 6]]))

@@ -187,3 +187,19 @@ def test_k12_float64_finite_differences_of_the_differentiable_rasteriser_path():
         vm[i, k] -= h
         fd = (float(loss_fn(vp)) - float(loss_fn(vm))) / (2 * h)
         assert abs(fd - float(g[i, k])) <= 2e-4 * max(1.0, abs(fd)), (i, k, fd, float(g[i, k]))
+
+
+def test_closest_point_on_triangle_regions():
+    """trimesh.proximity.closest_point restatement (icp on_surface, ICP:106-107): one query per Voronoi region of a
+    triangle -- interior, three vertices, three edges -- and the nearer of two triangles wins."""
+    from oracle import icp_ref as I
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 5], [1, 0, 5], [0, 1, 5]], float)
+    f = np.array([[0, 1, 2], [3, 4, 5]])
+    p = np.array([[0.2, 0.2, 1.0], [-1, -1, 0], [2, 0, 0], [0, 3, 1], [0.5, -1, 0], [1, 1, 0], [-1, 0.5, 0], [0.2, 0.2, 4.0]], float)
+    q, d = I.closest_point(v, f, p)
+    want = np.array([[0.2, 0.2, 0], [0, 0, 0], [1, 0, 0], [0, 1, 0], [0.5, 0, 0], [0.5, 0.5, 0], [0, 0.5, 0], [0.2, 0.2, 5]])
+    assert np.allclose(q, want) and np.allclose(d, np.linalg.norm(p - want, axis=1))
+    # a collinear triangle behaves like its longest segment (the edge regions catch every query)
+    q2, d2 = I.closest_point(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2], [0, 0, 1], [1, 0, 1], [0, 1, 1]], float),
+                             np.array([[0, 1, 2], [3, 4, 5]]), np.array([[0.1, 0.1, 0.0], [0.1, 0.1, 0.9]]))
+    assert np.allclose(q2, [[1 / 15] * 3, [0.1, 0.1, 1.0]]) and np.allclose(d2[1], 0.1)
