@@ -8,7 +8,8 @@ from followmyhold_amd import _lib as L_
 L_.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")  # ablation hooks live in the STAMPS build
 from followmyhold_amd import engine as E, synthetic
 sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512, seed=0)
-gb = E.GuidanceBatch([sc]); cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+NB = int(os.environ.get("NB", "1"))
+gb = E.GuidanceBatch([sc] * NB); cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
 cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
 for _ in range(int(os.environ.get("NSTEP", "25"))): gb.step(cfgu)
 torch.cuda.synchronize()

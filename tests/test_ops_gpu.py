@@ -166,3 +166,23 @@ def test_icp_on_surface_matches_the_numpy_reference():
     assert np.array_equal(Ts[1], T1) and cs[1] == c1
     with pytest.raises(Exception):
         ops.icp_points(src, tv, n_iter=2, target_faces=np.array([[0, 1, 10 ** 6]]))
+
+
+@gpu
+def test_lbs_large_batch_matrix_core_tiles():
+    """B >= 128 takes the 64 x 64 register-blocked pose-blend kernel (k_lbs_poseblend_mfma64): bit-identical to the
+    16 x 16 kernel small batches use (same k-chunking), ragged last tile included, and 1e-5 from the VALU path."""
+    from followmyhold_amd import ops
+    model = ops.LbsModel(synthetic.mano_like_model())
+    g = torch.Generator().manual_seed(0)
+    B = 200
+    betas = torch.randn(B, 10, generator=g).cuda()
+    aa = torch.randn(B, 16, 3, generator=g) * 0.4
+    rot = torch.stack([torch.from_numpy(np.stack([synthetic.axis_angle_matrix(a.numpy()) for a in row])) for row in aa]).float().cuda()
+    v_big, j_big = ops.lbs(betas, rot, model, use_mfma=1)
+    v_small, j_small = ops.lbs(betas[:100].contiguous(), rot[:100].contiguous(), model, use_mfma=1)      # B < 128: 16 x 16 kernel
+    assert torch.equal(v_big[:100], v_small) and torch.equal(j_big[:100], j_small)
+    v_tail, _ = ops.lbs(betas[150:].contiguous(), rot[150:].contiguous(), model, use_mfma=1)
+    assert torch.equal(v_big[150:], v_tail)
+    v_valu, _ = ops.lbs(betas, rot, model, use_mfma=0)
+    assert (v_big - v_valu).abs().max() < 1e-5
