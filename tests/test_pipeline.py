@@ -168,7 +168,7 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
     # the object sits where the Hunyuan -> MoGe transform and the optimised similarity put it: near the scene's object
     T = sc["T_h2m"].astype(np.float64)
     centre = (sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).mean(0)
-    assert np.abs(ov.mean(0).cpu().numpy() - centre).max() < 0.05
+    assert np.abs(ov.mean(0).cpu().numpy() - centre).max() < 0.12     # 7 AdamW steps of lr 1e-2 may move it by 7 cm
     # the hand is the MoGe-space MANO mesh under the optimised similarity (PL:1614-1618)
     gb = pipe.guidance_batch
     p = gb.params[0]
