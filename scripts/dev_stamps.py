@@ -31,23 +31,3 @@ for rep in range(4):
     for nm, o in (("hand", 50), ("obj", 60)):
         print("raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f (T=%d candidates)" % (
             nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), a[o + 8]))
-    if rep == 3:
-        st, en = a[100:560], a[560:1020]
-        hit = (en > st) & (st > 0)
-        t0 = st[st > 0].min()
-        dur = (en - st)[hit] / 100.0
-        print("pixbwd render 1, tiles 300..759: %d with hits; body us: min %.1f mean %.1f max %.1f; start since first: max %.1f; end since first: max %.1f" % (
-            hit.sum(), dur.min(), dur.mean(), dur.max(), (st[st > 0].max() - t0) / 100.0, (en[hit].max() - t0) / 100.0))
-        print("  longest bodies:", np.round(np.sort(dur)[-10:], 1).tolist())
-        p2f = gb.region("p2f", torch.int32, (2, 512, 512))[1].cpu().numpy()
-        order = np.argsort(-(en - st) * hit)[:8]
-        for o in order:
-            t = o + 300; ty, tx = divmod(t, 32)
-            blk = p2f[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
-            print("  tile %d (%d,%d): body %.1f us, hits %d, distinct faces %d, hand faces %d" % (t, tx, ty, (en[o] - st[o]) / 100.0, (blk >= 0).sum(),
-                  len(np.unique(blk[blk >= 0])), ((blk >= 0) & (blk < 1552)).sum()))
-        order = np.argsort((en - st) + (~hit) * 10**9)[:4]
-        for o in order:
-            t = o + 300; ty, tx = divmod(t, 32)
-            blk = p2f[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
-            print("  fast tile %d: body %.1f us, hits %d, distinct faces %d" % (t, (en[o] - st[o]) / 100.0, (blk >= 0).sum(), len(np.unique(blk[blk >= 0]))))
