@@ -5,7 +5,7 @@ Run in the build container only (needs /root/reference; the GPU box never runs t
 Writes tests/golden/ref_helpers.npz (+ ref_meta.json).  The un-vendored dependencies of the
 reference (pytorch3d, kaolin, diffusers, trimesh, cv2, ...) are replaced by empty stub modules,
 so only functions whose arithmetic lives in /root/reference itself are exercised (SURVEY.md 8c,
-fixtures F1-F9).  Nothing from the reference is copied: the outputs are data.
+fixtures F1-F9; F10-F12 added for the pipeline helpers).  Nothing from the reference is copied: the outputs are data.
 """
 import importlib
 import json
@@ -234,6 +234,46 @@ def main():
     # compute_loss_stable_fp32 (PL:1001-1018)
     lt = {"a": torch.tensor(1.5), "b": torch.tensor(float("nan")), "c": torch.tensor(0.25, dtype=torch.float16), "d": None}
     out["f10_stable_sum"] = PL.compute_loss_stable_fp32(lt)
+
+    # F11 latent2sdf (PL:292-313) with an arithmetic stand-in for the VAE (the test rebuilds it from f11_w): rescaling by
+    # 1/scale_factor, the vae() call, fp16 queries in chunks of 8000, concatenation, (1,G,G,G) view, float32, negation
+    class FakeVAE:
+        scale_factor = 0.7
+
+        def __init__(self, w):
+            self.w = w
+
+        def __call__(self, x):
+            return x * 2 + 1
+
+        def geo_decoder(self, queries, latents):
+            return (queries.float() @ self.w + latents.float().mean())[..., :1].to(latents.dtype)
+
+    w11 = torch.randn(3, 2, generator=g)
+    lat11 = torch.randn(1, 16, 4, generator=g).half()
+    xyz11, gs11, _ = PL.generate_dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 5, "ij", 24)   # 15625 points: 2 chunks
+    out.update(f11_w=w11, f11_latent=lat11,
+               f11_sdf=PL.latent2sdf(lat11, torch.FloatTensor(xyz11), gs11, FakeVAE(w11), "cpu"))
+
+    # F12 encode_cond (PL:599-639): classifier-free-guidance batches are [cond, uncond] (and [cond, uncond-with-additional,
+    # uncond] for dual guidance), cast to the pipeline dtype
+    class FakeCond:
+        def __call__(self, image=None, mask=None):
+            return {"main": image.mean(dim=(2, 3)).unsqueeze(1).float(), "additional": {"x": mask.float().sum(dim=(1, 2, 3)).reshape(-1, 1)}}
+
+        def unconditional_embedding(self, bsz):
+            return {"main": torch.zeros(bsz, 1, 3), "additional": {"x": -torch.ones(bsz, 1)}}
+
+    refpipe = object.__new__(PL.Hunyuan3DDiTPipeline)
+    refpipe.conditioner, refpipe.dtype = FakeCond(), torch.float16
+    img12 = torch.rand(1, 3, 8, 8, generator=g)
+    msk12 = (torch.rand(1, 1, 8, 8, generator=g) > 0.5).float()
+    c_plain = refpipe.encode_cond(img12, msk12, False, False)
+    c_cfg = refpipe.encode_cond(img12, msk12, True, False)
+    c_dual = refpipe.encode_cond(img12, msk12, True, True)
+    out.update(f12_image=img12, f12_mask=msk12, f12_plain_main=c_plain["main"], f12_cfg_main=c_cfg["main"],
+               f12_cfg_add=c_cfg["additional"]["x"], f12_dual_main=c_dual["main"], f12_dual_add=c_dual["additional"]["x"])
+    meta["f12_dtypes"] = dict(plain=str(c_plain["main"].dtype), cfg=str(c_cfg["main"].dtype), dual=str(c_dual["additional"]["x"].dtype))
 
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})

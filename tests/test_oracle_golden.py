@@ -138,3 +138,51 @@ def test_f9_task_list_and_path_contract(tmp_path, monkeypatch):
     assert p["T_h2m_path"] == "T/12_hoi_mesh.npy" and p["aligned_mano_mesh_path"] == "L/12_hamer_aligned_mano.ply"
     assert p["hunyuan_hoi_mesh_path"] == "H/12_hoi_mesh.ply" and p["hamer_for_guid_path"] == "A/12_kps_for_guidance.npy"
     assert p["save_path_obj"] == "O/12_obj.ply" and p["save_path_hand"] == "O/12_hand.ply"
+
+
+def test_f11_latent2sdf_matches_the_reference():
+    """pipeline.latent2sdf against the reference's latent2sdf (PL:292-313) run on an arithmetic stand-in VAE: latent
+    rescaling, fp16 queries, 8000-point chunks, (1,G,G,G) layout, negation."""
+    from followmyhold_amd import pipeline as PLN
+
+    class FakeVAE:
+        scale_factor = 0.7
+
+        def __init__(self, w):
+            self.w = w
+
+        def __call__(self, x):
+            return x * 2 + 1
+
+        def geo_decoder(self, queries, latents):
+            assert queries.dtype == torch.float16 and queries.shape[1] <= 8000
+            return (queries.float() @ self.w + latents.float().mean())[..., :1].to(latents.dtype)
+
+    w = torch.from_numpy(G["f11_w"])
+    lat = torch.from_numpy(G["f11_latent"])
+    xyz, gs, _ = PLN.generate_dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 5, "ij", 24)
+    got = PLN.latent2sdf(lat, torch.as_tensor(xyz), gs, FakeVAE(w), "cpu")
+    assert got.dtype == torch.float32 and tuple(got.shape) == G["f11_sdf"].shape == (1, 25, 25, 25)
+    assert np.array_equal(got.numpy(), G["f11_sdf"])
+
+
+def test_f12_encode_cond_matches_the_reference():
+    """GuidedShapePipeline.encode_cond against Hunyuan3DDiTPipeline.encode_cond (PL:599-639): batch order and dtype of the
+    classifier-free-guidance conditioning, nested dictionaries included."""
+    from followmyhold_amd import pipeline as PLN
+
+    class FakeCond:
+        def __call__(self, image=None, mask=None):
+            return {"main": image.mean(dim=(2, 3)).unsqueeze(1).float(), "additional": {"x": mask.float().sum(dim=(1, 2, 3)).reshape(-1, 1)}}
+
+        def unconditional_embedding(self, bsz):
+            return {"main": torch.zeros(bsz, 1, 3), "additional": {"x": -torch.ones(bsz, 1)}}
+
+    pipe = object.__new__(PLN.GuidedShapePipeline)
+    pipe.conditioner, pipe.dtype = FakeCond(), torch.float16
+    img, msk = torch.from_numpy(G["f12_image"]), torch.from_numpy(G["f12_mask"])
+    plain, cfg, dual = pipe.encode_cond(img, msk, False, False), pipe.encode_cond(img, msk, True, False), pipe.encode_cond(img, msk, True, True)
+    assert np.array_equal(plain["main"].numpy(), G["f12_plain_main"])
+    assert np.array_equal(cfg["main"].numpy(), G["f12_cfg_main"]) and np.array_equal(cfg["additional"]["x"].numpy(), G["f12_cfg_add"])
+    assert np.array_equal(dual["main"].numpy(), G["f12_dual_main"]) and np.array_equal(dual["additional"]["x"].numpy(), G["f12_dual_add"])
+    assert {k: str(v) for k, v in dict(plain=plain["main"].dtype, cfg=cfg["main"].dtype, dual=dual["additional"]["x"].dtype).items()} == META["f12_dtypes"]
