@@ -13,8 +13,8 @@ ICP_SETTINGS = dict(fixed_scale=False, outliers=0.2, test_rotations=False, test_
 
 
 def pick_moge_target(moge_dir: str):
-    """h2m.py:24-34: mesh.ply, else pointcloud.ply, else mesh.glb (the latter needs a glTF reader -> skipped)."""
-    for name in ("mesh.ply", "pointcloud.ply"):
+    """h2m.py:24-34: mesh.ply, else pointcloud.ply, else mesh.glb (read by followmyhold_amd.inputs.load_glb)."""
+    for name in ("mesh.ply", "pointcloud.ply", "mesh.glb"):
         p = os.path.join(moge_dir, name)
         if os.path.isfile(p):
             return p

@@ -275,6 +275,34 @@ def main():
                f12_cfg_add=c_cfg["additional"]["x"], f12_dual_main=c_dual["main"], f12_dual_add=c_dual["additional"]["x"])
     meta["f12_dtypes"] = dict(plain=str(c_plain["main"].dtype), cfg=str(c_cfg["main"].dtype), dual=str(c_dual["additional"]["x"].dtype))
 
+    # F13 alignment drivers (src/foho/alignment/h2m.py:12-55, mano.py:12-44): which files are paired and with which
+    # align_meshes_impl arguments, on a small directory tree (the call itself is captured, trimesh is not needed)
+    import tempfile
+    calls = []
+    fake = types.ModuleType("foho.alignment.mesh_align")
+    fake.align_meshes_impl = lambda **kw: calls.append(kw)
+    sys.modules["foho.alignment.mesh_align"] = fake
+    mods = {}
+    for name in ("h2m", "mano"):
+        spec = importlib.util.spec_from_file_location(f"ref_{name}", os.path.join(REF, "src/foho/alignment", f"{name}.py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    with tempfile.TemporaryDirectory() as root:
+        tree = ["hy/3_hoi_mesh.ply", "hy/12_hoi_mesh.ply", "hy/7_hoi_mesh.ply", "hy/9_hoi_mesh.ply", "hy/notes.txt",
+                "moge/3_cropped_hoi/mesh.ply", "moge/3_cropped_hoi/pointcloud.ply", "moge/12_cropped_hoi/pointcloud.ply",
+                "moge/12_cropped_hoi/mesh.glb", "moge/7_cropped_hoi/mesh.glb", "moge/9_cropped_hoi/other.txt",
+                "hamer/3_hamer.obj", "hamer/12_hamer.obj", "hamer/3_hamer.ply"]
+        for rel in tree:
+            os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+            open(os.path.join(root, rel), "w").close()
+        rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) else v
+        mods["h2m"].run(os.path.join(root, "hy"), os.path.join(root, "moge"), os.path.join(root, "rt"))
+        h2m_calls = sorted(({k: rel_(v) for k, v in c.items()} for c in calls), key=lambda c: c["source_mesh_path"])
+        calls.clear()
+        mods["mano"].run(os.path.join(root, "hamer"), os.path.join(root, "hy"), os.path.join(root, "aligned"))
+        mano_calls = sorted(({k: rel_(v) for k, v in c.items()} for c in calls), key=lambda c: c["source_mesh_path"])
+    meta["f13"] = dict(tree=tree, h2m=h2m_calls, mano=mano_calls)
+
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     with open(os.path.join(HERE, "ref_meta.json"), "w") as f:

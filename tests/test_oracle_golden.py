@@ -186,3 +186,24 @@ def test_f12_encode_cond_matches_the_reference():
     assert np.array_equal(cfg["main"].numpy(), G["f12_cfg_main"]) and np.array_equal(cfg["additional"]["x"].numpy(), G["f12_cfg_add"])
     assert np.array_equal(dual["main"].numpy(), G["f12_dual_main"]) and np.array_equal(dual["additional"]["x"].numpy(), G["f12_dual_add"])
     assert {k: str(v) for k, v in dict(plain=plain["main"].dtype, cfg=cfg["main"].dtype, dual=dual["additional"]["x"].dtype).items()} == META["f12_dtypes"]
+
+
+def test_f13_alignment_drivers_pair_files_like_the_reference(tmp_path, monkeypatch):
+    """foho.alignment.h2m.run / mano.run (h2m.py:12-55, mano.py:12-44): same source / target / output pairing -- incl. the
+    mesh.ply > pointcloud.ply > mesh.glb preference and the skip of images without MoGe geometry -- and the same
+    align_meshes_impl arguments as the reference produced on this directory tree."""
+    from foho.alignment import h2m, mano
+    f13 = META["f13"]
+    root = str(tmp_path)
+    for rel in f13["tree"]:
+        os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+        open(os.path.join(root, rel), "w").close()
+    calls = []
+    rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) else v
+    for mod in (h2m, mano):
+        monkeypatch.setattr(mod, "align_meshes_impl", lambda **kw: calls.append({k: rel_(v) for k, v in kw.items()}))
+    h2m.run(os.path.join(root, "hy"), os.path.join(root, "moge"), os.path.join(root, "rt"))
+    assert sorted(calls, key=lambda c: c["source_mesh_path"]) == f13["h2m"]
+    calls.clear()
+    mano.run(os.path.join(root, "hamer"), os.path.join(root, "hy"), os.path.join(root, "aligned"))
+    assert sorted(calls, key=lambda c: c["source_mesh_path"]) == f13["mano"]
