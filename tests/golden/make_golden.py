@@ -303,6 +303,30 @@ def main():
         mano_calls = sorted(({k: rel_(v) for k, v in c.items()} for c in calls), key=lambda c: c["source_mesh_path"])
     meta["f13"] = dict(tree=tree, h2m=h2m_calls, mano=mano_calls)
 
+    # F14 the mesh_align command line (ICP:219-262, a click command): option names, short forms, types and defaults as seen
+    # by align_meshes_impl (captured; trimesh / pyvista stubbed)
+    for n in ("pyvista", "trimesh.registration", "trimesh.proximity"):
+        _stub(n)
+    del sys.modules["foho.alignment.mesh_align"]
+    spec = importlib.util.spec_from_file_location("ref_mesh_align", os.path.join(REF, "src/foho/alignment/mesh_align.py"))
+    MA = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MA)
+    from click.testing import CliRunner
+    got = []
+    MA.align_meshes_impl = lambda *a: got.append(list(a))
+    with tempfile.TemporaryDirectory() as root:
+        a_, b_ = os.path.join(root, "a.ply"), os.path.join(root, "b.ply")
+        open(a_, "w").close(), open(b_, "w").close()
+        argvs = [["A", "B"],
+                 ["A", "B", "-tp", "T", "-tmp", "M.ply", "-fs", "-o", "0.35", "-trot", "-tref", "-os", "-ir", "7", "-csr", "11", "-ctr",
+                  "13", "-if", "17", "-csf", "19", "-ctf", "23", "-mis", "0.9", "-mas", "1.5"],
+                 ["A", "B", "--transform_path", "T2", "--outliers", "0.1", "--iterations_fine", "3", "--max_scale", "2.0"]]
+        for av in argvs:
+            r = CliRunner().invoke(MA.align_meshes, [a_ if x == "A" else b_ if x == "B" else x for x in av])
+            assert r.exit_code == 0, r.output
+        got = [["A" if x == a_ else "B" if x == b_ else x for x in g_] for g_ in got]
+    meta["f14"] = dict(argv=argvs, args=got)
+
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     with open(os.path.join(HERE, "ref_meta.json"), "w") as f:

@@ -207,3 +207,14 @@ def test_f13_alignment_drivers_pair_files_like_the_reference(tmp_path, monkeypat
     calls.clear()
     mano.run(os.path.join(root, "hamer"), os.path.join(root, "hy"), os.path.join(root, "aligned"))
     assert sorted(calls, key=lambda c: c["source_mesh_path"]) == f13["mano"]
+
+
+def test_f14_mesh_align_command_line_matches_the_reference(monkeypatch):
+    """foho.alignment.mesh_align.main (ICP:219-262): the same option names, short forms, types and defaults reach
+    align_meshes_impl as through the reference's click command."""
+    from foho.alignment import mesh_align as MA
+    got = []
+    monkeypatch.setattr(MA, "align_meshes_impl", lambda *a: got.append(list(a)))
+    for argv in META["f14"]["argv"]:
+        MA.main(list(argv))
+    assert got == META["f14"]["args"]
