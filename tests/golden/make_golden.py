@@ -327,6 +327,61 @@ def main():
         got = [["A" if x == a_ else "B" if x == b_ else x for x in g_] for g_ in got]
     meta["f14"] = dict(argv=argvs, args=got)
 
+    # F15 the guidance stage driver (RUN:178-261): task list, per-image file names, skip rules (outputs exist, empty mask),
+    # fov.json, the keyword arguments handed to run_hunyuan_w_guid (captured; cv2.imread stood in by PIL)
+    from PIL import Image
+
+    def imread(path, flag=None):
+        return np.array(Image.open(path)) if os.path.exists(path) else None
+
+    for n in ("hy3dgen", "hy3dgen.rembg", "hy3dgen.shapegen", "hy3dgen.shapegen.pipelines", "hy3dgen.shapegen.postprocessors"):
+        _stub(n)
+    sys.modules["cv2"].imread = imread
+    sys.modules["cv2"].IMREAD_UNCHANGED = -1
+    spec = importlib.util.spec_from_file_location("ref_run", os.path.join(REF, "src/foho/guidance/run.py"))
+    RUN = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(RUN)
+    seen = []
+    with tempfile.TemporaryDirectory() as root:
+        d = {k: os.path.join(root, k) for k in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                                "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]}
+        for v in d.values():
+            os.makedirs(v)
+        imgs = ["12_cropped_hoi_1.png", "3_cropped_hoi_0.png", "7_cropped_hoi_1.png", "9_cropped_hoi_1.png", "21_cropped_hoi_0.png"]
+        for name in imgs:
+            idx = name.split("_")[0]
+            Image.fromarray(np.zeros((4, 4, 3), np.uint8)).save(os.path.join(d["cropped_obj_img_dir"], name))
+            os.makedirs(os.path.join(d["moge_out_dir"], f"{idx}_cropped_hoi"))
+            if idx != "21":     # image 21 has no fov.json: the reference's try/except moves on
+                with open(os.path.join(d["moge_out_dir"], f"{idx}_cropped_hoi", "fov.json"), "w") as f:
+                    json.dump({"fov_x": 40.0 + int(idx)}, f)
+            hand = np.full((4, 4), 255, np.uint8) if idx != "7" else np.zeros((4, 4), np.uint8)   # image 7: empty hand mask
+            Image.fromarray(hand).save(os.path.join(d["mask_dir"], f"{idx}_cropped_hand_mask.png"))
+            Image.fromarray(np.full((4, 4), 255, np.uint8)).save(os.path.join(d["mask_dir"], f"{idx}_cropped_obj_mask.png"))
+        for tag in ("obj", "hand"):                                                          # image 3: outputs exist
+            open(os.path.join(d["guidance_out_dir"], f"3_{tag}.ply"), "w").close()
+        rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) else v
+
+        def fake_guid(**kw):
+            seen.append({k: rel_(v) for k, v in kw.items() if k != "config"})
+            return (None, None) if "9_" in kw["cropped_obj_img_path"] else (1, 1)
+
+        RUN.run_hunyuan_w_guid = fake_guid
+        os.environ.pop("SLURM_ARRAY_TASK_ID", None)
+        RUN.run(project_root=root, task_list_file=None, **d)
+        order_all = [c["cropped_obj_img_path"] for c in seen]
+        tl = os.path.join(root, "tasks.json")
+        with open(tl, "w") as f:
+            json.dump([["12_cropped_hoi_1.png"], ["9_cropped_hoi_1.png", "3_cropped_hoi_0.png"]], f)
+        os.environ["SLURM_ARRAY_TASK_ID"] = "1"
+        n0 = len(seen)
+        RUN.run(project_root=root, task_list_file=tl, **d)
+        os.environ.pop("SLURM_ARRAY_TASK_ID")
+        listing = RUN._load_task_list(None, d["cropped_obj_img_dir"])
+    meta["f15"] = dict(images=imgs, calls=sorted(seen[:n0], key=lambda c: c["cropped_obj_img_path"]), n_calls=n0,
+                       task_list_calls=[c["cropped_obj_img_path"] for c in seen[n0:]],
+                       listing_is_sorted=bool(listing == sorted(listing)), listing_set=sorted(listing))
+
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     with open(os.path.join(HERE, "ref_meta.json"), "w") as f:

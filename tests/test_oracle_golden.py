@@ -218,3 +218,51 @@ def test_f14_mesh_align_command_line_matches_the_reference(monkeypatch):
     for argv in META["f14"]["argv"]:
         MA.main(list(argv))
     assert got == META["f14"]["args"]
+
+
+def test_f15_guidance_driver_matches_the_reference(tmp_path, monkeypatch):
+    """foho.guidance.run.run (RUN:188-261) on the directory tree the reference's own run() was executed on: the same images
+    reach run_hunyuan_w_guid with the same keyword arguments (file names, fov), the same ones are skipped (outputs
+    exist, empty mask, missing fov.json -> per-image exception), a (None, None) result moves on, and the task list is
+    chunked by SLURM_ARRAY_TASK_ID."""
+    from PIL import Image
+    from foho.guidance import run as G
+    f15 = META["f15"]
+    root = str(tmp_path)
+    d = {k: os.path.join(root, k) for k in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                            "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]}
+    for v in d.values():
+        os.makedirs(v)
+    for name in f15["images"]:
+        idx = name.split("_")[0]
+        Image.fromarray(np.zeros((4, 4, 3), np.uint8)).save(os.path.join(d["cropped_obj_img_dir"], name))
+        os.makedirs(os.path.join(d["moge_out_dir"], f"{idx}_cropped_hoi"))
+        if idx != "21":
+            with open(os.path.join(d["moge_out_dir"], f"{idx}_cropped_hoi", "fov.json"), "w") as f:
+                json.dump({"fov_x": 40.0 + int(idx)}, f)
+        hand = np.full((4, 4), 255, np.uint8) if idx != "7" else np.zeros((4, 4), np.uint8)
+        Image.fromarray(hand).save(os.path.join(d["mask_dir"], f"{idx}_cropped_hand_mask.png"))
+        Image.fromarray(np.full((4, 4), 255, np.uint8)).save(os.path.join(d["mask_dir"], f"{idx}_cropped_obj_mask.png"))
+    for tag in ("obj", "hand"):
+        open(os.path.join(d["guidance_out_dir"], f"3_{tag}.ply"), "w").close()
+    seen = []
+    rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) else v
+
+    def fake_guid(**kw):
+        seen.append({k: rel_(v) for k, v in kw.items() if k != "config"})
+        return (None, None) if "9_" in kw["cropped_obj_img_path"] else (1, 1)
+
+    monkeypatch.setattr(G, "run_hunyuan_w_guid", fake_guid)
+    for k in ("SLURM_ARRAY_TASK_ID", "WORLD_SIZE", "RANK"):
+        monkeypatch.delenv(k, raising=False)
+    G.run(project_root=root, task_list_file=None, **d)
+    assert len(seen) == f15["n_calls"] and sorted(seen, key=lambda c: c["cropped_obj_img_path"]) == f15["calls"]
+    tl = os.path.join(root, "tasks.json")
+    with open(tl, "w") as f:
+        json.dump([["12_cropped_hoi_1.png"], ["9_cropped_hoi_1.png", "3_cropped_hoi_0.png"]], f)
+    monkeypatch.setenv("SLURM_ARRAY_TASK_ID", "1")
+    n0 = len(seen)
+    G.run(project_root=root, task_list_file=tl, **d)
+    assert [c["cropped_obj_img_path"] for c in seen[n0:]] == f15["task_list_calls"]
+    monkeypatch.delenv("SLURM_ARRAY_TASK_ID")
+    assert G._load_task_list(None, d["cropped_obj_img_dir"]) == f15["listing_set"]
