@@ -366,6 +366,7 @@ def main():
             seen.append({k: rel_(v) for k, v in kw.items() if k != "config"})
             return (None, None) if "9_" in kw["cropped_obj_img_path"] else (1, 1)
 
+        orig_guid = RUN.run_hunyuan_w_guid
         RUN.run_hunyuan_w_guid = fake_guid
         os.environ.pop("SLURM_ARRAY_TASK_ID", None)
         RUN.run(project_root=root, task_list_file=None, **d)
@@ -381,6 +382,108 @@ def main():
     meta["f15"] = dict(images=imgs, calls=sorted(seen[:n0], key=lambda c: c["cropped_obj_img_path"]), n_calls=n0,
                        task_list_calls=[c["cropped_obj_img_path"] for c in seen[n0:]],
                        listing_is_sorted=bool(listing == sorted(listing)), listing_set=sorted(listing))
+
+    # F16 run_hunyuan_w_guid (RUN:65-175) with recording stand-ins for the pytorch3d / hy3dgen classes: camera, blend and
+    # raster settings of the two renderers, the RGBA image handed to the pipeline (white made transparent), the pipeline's
+    # keyword arguments, the post-processing order and the export targets
+    log = []
+
+    class Rec:
+        def __init__(self, *a, **kw):
+            self.args, self.kw = a, kw
+            log.append((type(self).__name__, kw))
+
+    def rec(name):
+        return type(name, (Rec,), {})
+
+    names = ["FoVPerspectiveCameras", "BlendParams", "RasterizationSettings", "MeshRenderer", "MeshRasterizer",
+             "SoftSilhouetteShader", "PhongNormalShader"]
+    K = {n: rec(n) for n in names}
+    K["BlendParams"] = type("BlendParams", (Rec,), {"sigma": property(lambda self: self.kw["sigma"])})
+    for n in names:
+        setattr(RUN, n, K[n])
+
+    class FakeMeshes:
+        def __init__(self, v, f):
+            self.v, self.f = v, f
+
+        def verts_packed(self):
+            return self.v
+
+        def faces_packed(self):
+            return self.f
+
+    pipe_calls = []
+
+    class FakePipe:
+        @classmethod
+        def from_pretrained(cls, path):
+            log.append(("from_pretrained", {"path": path}))
+            return cls()
+
+        def __call__(self, **kw):
+            pipe_calls.append(kw)
+            return FakeMeshes(torch.rand(5, 3), torch.tensor([[0, 1, 2]])), FakeMeshes(torch.rand(4, 3), torch.tensor([[0, 1, 3]]))
+
+    class FakeTrimesh:
+        def __init__(self, vertices=None, faces=None):
+            self.vertices, self.faces = vertices, faces
+
+        def export(self, path):
+            log.append(("export", {"path": path, "n_vertices": len(self.vertices)}))
+
+    def post(name):
+        class P:
+            def __call__(self, mesh):
+                log.append((name, {}))
+                return mesh
+        return P
+
+    class FakeIO:
+        def save_mesh(self, mesh, path):
+            log.append(("IO.save_mesh", {"path": path}))
+
+    RUN.Hunyuan3DDiTFlowMatchingPipeline_main = FakePipe
+    RUN.trimesh = types.SimpleNamespace(Trimesh=FakeTrimesh)
+    RUN.FloaterRemover, RUN.DegenerateFaceRemover, RUN.FaceReducer = post("FloaterRemover"), post("DegenerateFaceRemover"), post("FaceReducer")
+    RUN.IO = FakeIO
+    RUN.BackgroundRemover = lambda: (lambda im: im)
+    sys.modules["cv2"].IMREAD_GRAYSCALE = 0
+    with tempfile.TemporaryDirectory() as root:
+        rgb = (np.arange(6 * 5 * 3).reshape(6, 5, 3) * 3 % 256).astype(np.uint8)
+        rgb[1, 2] = 255
+        rgb[4, 0] = 255
+        rgb[3, 3] = (255, 255, 254)
+        img_path = os.path.join(root, "12_cropped_hoi_1.png")
+        Image.fromarray(rgb).save(img_path)
+        hm = os.path.join(root, "hand.png")
+        Image.fromarray(np.full((6, 5), 255, np.uint8)).save(hm)
+        res = orig_guid(
+            cropped_obj_img_path=img_path, fovx=41.5, hamer_for_guid_path="K", aligned_mano_mesh_path="MANO",
+            cropped_obj_mask_path="OM", cropped_hand_mask_path=hm, moge_mesh_path="MOGE", T_h2m_path="T",
+            hunyuan_hoi_mesh_path="HY", save_path_obj=os.path.join(root, "o.ply"), save_path_hand=os.path.join(root, "h.ply"),
+            config="CFG", device="cpu")
+        kw = pipe_calls[0]
+        image16 = np.array(kw["image"][0])
+        rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) and v.startswith(root) else v
+
+        def plain(v):
+            if isinstance(v, torch.Tensor):
+                return v.tolist()
+            if isinstance(v, (np.floating, np.integer)):
+                return v.item()
+            if isinstance(v, Rec):
+                return type(v).__name__
+            if isinstance(v, tuple):
+                return [plain(x) for x in v]
+            return rel_(v)
+
+        meta["f16"] = dict(
+            log=[[n, {k: plain(v) for k, v in kw_.items()}] for n, kw_ in log],
+            pipeline_kwargs={k: plain(v) for k, v in kw.items() if k not in ("image", "generator", "renderer", "sil_renderer")},
+            pipeline_kwarg_names=sorted(kw.keys()), image_mode=kw["image"][0].mode, n_images=len(kw["image"]),
+            generator_seed=int(kw["generator"].initial_seed()), returns_pair=bool(isinstance(res, tuple) and len(res) == 2))
+        out.update(f16_rgb=rgb, f16_image=image16)
 
     np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})

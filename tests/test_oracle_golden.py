@@ -266,3 +266,64 @@ def test_f15_guidance_driver_matches_the_reference(tmp_path, monkeypatch):
     assert [c["cropped_obj_img_path"] for c in seen[n0:]] == f15["task_list_calls"]
     monkeypatch.delenv("SLURM_ARRAY_TASK_ID")
     assert G._load_task_list(None, d["cropped_obj_img_dir"]) == f15["listing_set"]
+
+
+def test_f16_run_hunyuan_w_guid_matches_the_reference(tmp_path, monkeypatch):
+    """foho.guidance.run.run_hunyuan_w_guid against a recording of the reference's (RUN:65-175): camera, blend and raster
+    settings of the two renderers, the RGBA image (pure white -> transparent), the pipeline's keyword arguments and seed,
+    post-processing + export of both meshes."""
+    from PIL import Image
+    from foho.guidance import run as Gd
+    from followmyhold_amd import facade as p3d, meshio, postprocess
+    f16 = META["f16"]
+    rec = {}
+    for name, kw in f16["log"]:
+        rec.setdefault(name, []).append(kw)
+    root = str(tmp_path)
+    img_path, hm = os.path.join(root, "12_cropped_hoi_1.png"), os.path.join(root, "hand.png")
+    Image.fromarray(G["f16_rgb"]).save(img_path)
+    Image.fromarray(np.full((6, 5), 255, np.uint8)).save(hm)
+    calls, order = [], []
+
+    class FakePipe:
+        def __call__(self, **kw):
+            calls.append(kw)
+            return (p3d.Meshes(verts=[torch.rand(5, 3)], faces=[torch.tensor([[0, 1, 2]])]),
+                    p3d.Meshes(verts=[torch.rand(4, 3)], faces=[torch.tensor([[0, 1, 3]])]))
+
+    monkeypatch.setattr(Gd, "_build_pipeline", lambda device: FakePipe())
+    for cls in ("FloaterRemover", "DegenerateFaceRemover", "FaceReducer"):
+        orig = getattr(postprocess, cls).__call__
+        monkeypatch.setattr(getattr(postprocess, cls), "__call__",
+                            (lambda o, c: lambda self, mesh, *a, **k: (order.append(c), o(self, mesh, *a, **k))[1])(orig, cls))
+    res = Gd.run_hunyuan_w_guid(
+        cropped_obj_img_path=img_path, fovx=41.5, hamer_for_guid_path="K", aligned_mano_mesh_path="MANO",
+        cropped_obj_mask_path="OM", cropped_hand_mask_path=hm, moge_mesh_path="MOGE", T_h2m_path="T",
+        hunyuan_hoi_mesh_path="HY", save_path_obj=os.path.join(root, "o.ply"), save_path_hand=os.path.join(root, "h.ply"),
+        config="CFG", device="cpu")
+    assert isinstance(res, tuple) and len(res) == 2 and f16["returns_pair"]
+    kw = calls[0]
+    assert sorted(kw.keys()) == f16["pipeline_kwarg_names"]
+    rel_ = lambda v: os.path.relpath(v, root) if isinstance(v, str) and v.startswith(root) else v
+    assert {k: rel_(v) for k, v in kw.items() if k not in ("image", "generator", "renderer", "sil_renderer")} == f16["pipeline_kwargs"]
+    assert len(kw["image"]) == f16["n_images"] and kw["image"][0].mode == f16["image_mode"]
+    assert np.array_equal(np.array(kw["image"][0]), G["f16_image"])
+    assert int(kw["generator"].initial_seed()) == f16["generator_seed"]
+    # renderers
+    cam_ref, blend_ref = rec["FoVPerspectiveCameras"][0], rec["BlendParams"][0]
+    rs_ref, rs_sil_ref = rec["RasterizationSettings"]
+    for rend, rs_want, shader in ((kw["renderer"], rs_ref, p3d.PhongNormalShader), (kw["sil_renderer"], rs_sil_ref, p3d.SoftSilhouetteShader)):
+        cam, rs = rend.rasterizer.cameras, rend.rasterizer.raster_settings
+        assert isinstance(rend.shader, shader)
+        assert cam.R.tolist() == cam_ref["R"] and cam.T.tolist() == cam_ref["T"]
+        assert (cam.fov, cam.znear, cam.zfar) == (cam_ref["fov"], cam_ref["znear"], cam_ref["zfar"])
+        assert list(rs.image_size) == rs_want["image_size"] and rs.faces_per_pixel == rs_want["faces_per_pixel"]
+        assert rs.bin_size == rs_want["bin_size"] and rs.max_faces_per_bin == rs_want["max_faces_per_bin"]
+        assert np.float32(rs.blur_radius) == np.float32(rs_want["blur_radius"])
+        bp = rend.shader.blend_params
+        assert np.float32(bp.sigma) == np.float32(blend_ref["sigma"]) and np.float32(bp.gamma) == np.float32(blend_ref["gamma"])
+    # post-processing order and outputs
+    assert order == [n for n, _ in f16["log"] if n in ("FloaterRemover", "DegenerateFaceRemover", "FaceReducer")]
+    ov, of = meshio.load_ply(os.path.join(root, rec["export"][0]["path"]))
+    hv, hf = meshio.load_ply(os.path.join(root, rec["IO.save_mesh"][0]["path"]))
+    assert len(hv) == 4 and len(hf) == 1 and len(of) == 1
