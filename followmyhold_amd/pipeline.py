@@ -42,7 +42,7 @@ def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     pred = vae(pred)
     logits = []
     for start in range(0, xyz_samples.shape[0], num_chunks):
-        queries = xyz_samples[start:start + num_chunks].to(device).to(pred.dtype)
+        queries = xyz_samples[start:start + num_chunks].to(device).half()      # fp16 whatever the VAE's dtype (PL:303)
         logits.append(vae.geo_decoder(queries.unsqueeze(0), pred))
     grid_logits = torch.cat(logits, dim=1)
     return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
@@ -142,7 +142,10 @@ class GuidedShapePipeline:
         kwargs.pop("callback_steps", None)
         final_res = int(kwargs.pop("final_octree_resolution", 384))          # PL:1627 (tests use a smaller grid)
         J_regressor = kwargs.pop("J_regressor", None)                        # default: the file of PL:1218
+        on_phase_end = kwargs.pop("on_phase_end", None)      # hook(phase, denoising step, GuidanceBatch): inspection / tests
         self.stats = stats = {"inner_iterations": 0, "skipped_empty": 0}
+        self.loss_log = loss_log = []        # (phase, denoising step, iteration, loss terms) every 10th iteration, like the prints
+        self.param_log = param_log = []      # (phase, denoising step, the 16 similarity parameters, noise prediction) at phase end
         device, dtype = self.device, self.dtype
         cfg0 = config() if config is not None else E.OptimizationConfig()
 
@@ -232,11 +235,15 @@ class GuidedShapePipeline:
                     break
                 if k % 10 == 0:
                     l = gb.loss_dict(0)
+                    loss_log.append((phase, i, k, l))
                     say(f"Opt step {k}, object loss: {l['edge']}, loss_intersection: {l.get('intersection', 0.0)}, "
                         f"total: {l['total']}")
                 loss.backward()
                 opt.step()
             gb.raise_on_flags(strict_k=False)
+            param_log.append((phase, i, gb.params[0].detach().clone(), noise_pred.detach().clone()))
+            if on_phase_end is not None:
+                on_phase_end(phase, i, gb)
             return noise_pred.detach().clone()
 
         obj_out = hand_out = None
@@ -266,6 +273,9 @@ class GuidedShapePipeline:
                         torch.cuda.synchronize(device)
                         l = gb.loss_dict(0)
                         say(f"Opt step {n - 1}, loss_2d_kps: {l.get('kps', 0.0)}, total: {l['total']}")
+                        param_log.append(("A", i, gb.params[0].detach().clone(), None))
+                        if on_phase_end is not None:
+                            on_phase_end("A", i, gb)
                     elif i == handopt_start_step + 1:                # phase B: object transform + latent (PL:1361-1453)
                         say(f"Object optimization step {i}, optimizing object transformation")
                         noise_pred_obj = latent_phase("B", cfg0.optimization_steps_scale, i, t, noise_pred_obj,
