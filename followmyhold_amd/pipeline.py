@@ -266,6 +266,11 @@ class GuidedShapePipeline:
                         n = int(cfg0.optimization_steps_hand)
                         spg = max([d for d in range(1, 51) if n % d == 0]) if n > 0 else 1
                         graph = gb.capture(cfg, steps_per_graph=spg)
+                        # capture() ran one iteration from the current parameters and put the optimiser state back: what it
+                        # left in gb.losses are the k = 0 losses the reference prints (PL:1351-1355)
+                        l0 = gb.loss_dict(0)
+                        loss_log.append(("A", i, 0, l0))
+                        say(f"Opt step 0, loss_2d_kps: {l0['kps']}, loss_normal_hand: {l0['normal0']}, loss_disp_hand: {l0['disp0']}")
                         gb.reset_optimizer()
                         for _ in range(n // spg):
                             graph.replay()

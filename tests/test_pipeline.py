@@ -313,10 +313,12 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path):
     # first-iteration losses the reference printed (PL:1446-1450, 1594-1598)
     num = lambda line: dict((k.strip(), float(v)) for k, v in re.findall(r"([A-Za-z_ 0-9]+): ([-+0-9.eE]+)", line.split(",", 1)[1]))
     opt = [l for l in meta["log"] if l.startswith("Opt step 0")]
-    ref_b, ref_c = num(opt[1]), num(opt[2])
-    (pb, ib, kb, lb), (pc, ic, kc, lc) = pipe.loss_log
-    assert (pb, ib, kb, pc, ic, kc) == ("B", 2, 0, "C", 3, 0)
+    ref_a, ref_b, ref_c = num(opt[0]), num(opt[1]), num(opt[2])
+    (pa_, ia, ka, la), (pb, ib, kb, lb), (pc, ic, kc, lc) = pipe.loss_log
+    assert (pa_, ia, ka, pb, ib, kb, pc, ic, kc) == ("A", 1, 0, "B", 2, 0, "C", 3, 0)
     close = lambda a, b, tol: abs(a - b) <= tol * abs(b)
+    assert close(la["kps"], ref_a["loss_2d_kps"], 1e-4) and close(la["normal0"], ref_a["loss_normal_hand"], 1e-4)
+    assert close(la["disp0"], ref_a["loss_disp_hand"], 1e-4)
     assert close(lb["edge"], ref_b["object loss"], 1e-4) and close(lb["normal0"], ref_b["loss_normal_obj"], 1e-4)
     assert close(lb["disp0"], ref_b["loss_disp"], 1e-4)
     assert close(lc["edge"], ref_c["object loss"], 2e-3) and close(lc["normal1"], ref_c["loss_normal_hoi"], 2e-3)
