@@ -12,6 +12,22 @@ ICP_SETTINGS = dict(fixed_scale=False, outliers=0.2, test_rotations=False, test_
                     count_source_fine=5000, count_target_fine=10000, min_scale=0.7, max_scale=3.0, plot=False)
 
 
+def each_source(directory: str, pattern: str, what: str):
+    """[(path, image index, file stem)] of the source meshes of a stage; the index is the text before the first "_"."""
+    found = sorted(glob.glob(os.path.join(directory, pattern)))
+    if not found:
+        print(f"No {what} found in {directory}")
+    return [(p, os.path.basename(p).split("_")[0], os.path.splitext(os.path.basename(p))[0]) for p in found]
+
+
+def cli(run_fn, *flags) -> None:
+    """The stages take only required --<name> directory flags (h2m.py:57-68, mano.py:46-57)."""
+    parser = argparse.ArgumentParser()
+    for flag in flags:
+        parser.add_argument(f"--{flag}", required=True)
+    run_fn(**vars(parser.parse_args()))
+
+
 def pick_moge_target(moge_dir: str):
     """h2m.py:24-34: mesh.ply, else pointcloud.ply, else mesh.glb (read by followmyhold_amd.inputs.load_glb)."""
     for name in ("mesh.ply", "pointcloud.ply", "mesh.glb"):
@@ -22,32 +38,22 @@ def pick_moge_target(moge_dir: str):
 
 
 def run(hunyuan_mesh_dir: str, moge_out_dir: str, h2m_rt_dir: str) -> None:
-    meshes = sorted(glob.glob(os.path.join(hunyuan_mesh_dir, "*.ply")))
-    if not meshes:
-        print(f"No Hunyuan HOI meshes found in {hunyuan_mesh_dir}")
-        return
-    os.makedirs(h2m_rt_dir, exist_ok=True)
-    for mesh_path in meshes:
-        base_name = os.path.basename(mesh_path)
-        i = base_name.split("_")[0]
-        j = os.path.splitext(base_name)[0]
-        moge_dir = os.path.join(moge_out_dir, f"{i}_cropped_hoi")
-        target_mesh = pick_moge_target(moge_dir)
-        if target_mesh is None:
-            print(f"No MoGe mesh found for {i} in {moge_dir}. Skipping.")
+    sources = each_source(hunyuan_mesh_dir, "*.ply", "Hunyuan HOI meshes")
+    if sources:
+        os.makedirs(h2m_rt_dir, exist_ok=True)
+    for path, index, stem in sources:
+        moge_dir = os.path.join(moge_out_dir, f"{index}_cropped_hoi")
+        target = pick_moge_target(moge_dir)
+        if target is None:
+            print(f"No MoGe mesh found for {index} in {moge_dir}. Skipping.")
             continue
-        # np.save appends ".npy": the guidance stage reads {i}_hoi_mesh.npy (run.py:216)
-        align_meshes_impl(source_mesh_path=mesh_path, target_mesh_path=target_mesh, transform_path=os.path.join(h2m_rt_dir, j),
+        # np.save appends ".npy": the guidance stage reads {index}_hoi_mesh.npy (run.py:216)
+        align_meshes_impl(source_mesh_path=path, target_mesh_path=target, transform_path=os.path.join(h2m_rt_dir, stem),
                           transformed_mesh_path=None, **ICP_SETTINGS)
 
 
 def main() -> None:
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--hunyuan_mesh_dir", required=True)
-    parser.add_argument("--moge_out_dir", required=True)
-    parser.add_argument("--h2m_rt_dir", required=True)
-    a = parser.parse_args()
-    run(hunyuan_mesh_dir=a.hunyuan_mesh_dir, moge_out_dir=a.moge_out_dir, h2m_rt_dir=a.h2m_rt_dir)
+    cli(run, "hunyuan_mesh_dir", "moge_out_dir", "h2m_rt_dir")
 
 
 if __name__ == "__main__":
