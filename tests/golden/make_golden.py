@@ -18,6 +18,7 @@ import torch
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = sys.argv[1] if len(sys.argv) > 1 else HERE          # optional output directory (tests regenerate into a temp dir)
 
 
 class _Anything:
@@ -485,9 +486,9 @@ def main():
             generator_seed=int(kw["generator"].initial_seed()), returns_pair=bool(isinstance(res, tuple) and len(res) == 2))
         out.update(f16_rgb=rgb, f16_image=image16)
 
-    np.savez_compressed(os.path.join(HERE, "ref_helpers.npz"),
+    np.savez_compressed(os.path.join(OUT, "ref_helpers.npz"),
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
-    with open(os.path.join(HERE, "ref_meta.json"), "w") as f:
+    with open(os.path.join(OUT, "ref_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, default=str)
     print("wrote", len(out), "arrays")
 

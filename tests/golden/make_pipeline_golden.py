@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = sys.argv[1] if len(sys.argv) > 1 else HERE          # optional output directory (tests regenerate into a temp dir)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -163,8 +164,8 @@ def main():
         big = [p for p in params if p.numel() > 4]
         if big:
             arrays[f"opt{n}_noise"] = big[0].detach().float().numpy()
-    np.savez_compressed(os.path.join(HERE, "ref_pipeline.npz"), **arrays)
-    with open(os.path.join(HERE, "ref_pipeline.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "ref_pipeline.npz"), **arrays)
+    with open(os.path.join(OUT, "ref_pipeline.json"), "w") as f:
         json.dump(dict(scene=SCENE, radius=RADIUS, schedule=SCHEDULE, vae_kw=VAE_KW, log=lines, optimizers=[m[0] for m in made],
                        torch=torch.__version__), f, indent=1)
     print("hand", arrays["hand_verts"].shape, "object", arrays["obj_counts"], arrays["obj_stats"])

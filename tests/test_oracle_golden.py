@@ -327,3 +327,27 @@ def test_f16_run_hunyuan_w_guid_matches_the_reference(tmp_path, monkeypatch):
     ov, of = meshio.load_ply(os.path.join(root, rec["export"][0]["path"]))
     hv, hf = meshio.load_ply(os.path.join(root, rec["IO.save_mesh"][0]["path"]))
     assert len(hv) == 4 and len(hf) == 1 and len(of) == 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only mounted in the build container")
+def test_golden_files_regenerate_from_the_reference(tmp_path):
+    """Provenance of tests/golden/: both generator scripts, run again on /root/reference, reproduce the committed files --
+    the helper vectors bit for bit, the pipeline trajectory (a float32 optimisation on all host cores) to 1e-5."""
+    import subprocess
+    import sys
+    gdir = os.path.join(HERE, "golden")
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    for script in ("make_golden.py", "make_pipeline_golden.py"):
+        r = subprocess.run([sys.executable, os.path.join(gdir, script), str(tmp_path)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    new = np.load(str(tmp_path / "ref_helpers.npz"))
+    assert sorted(new.files) == sorted(G.files)
+    for k in G.files:
+        assert np.array_equal(new[k], G[k], equal_nan=True), k
+    assert json.load(open(tmp_path / "ref_meta.json")) == META
+    old_p, new_p = np.load(os.path.join(gdir, "ref_pipeline.npz")), np.load(str(tmp_path / "ref_pipeline.npz"))
+    assert sorted(old_p.files) == sorted(new_p.files)
+    for k in old_p.files:
+        assert np.allclose(new_p[k], old_p[k], rtol=1e-5, atol=1e-6), k
+    jo, jn = json.load(open(os.path.join(gdir, "ref_pipeline.json"))), json.load(open(tmp_path / "ref_pipeline.json"))
+    assert jo["schedule"] == jn["schedule"] and jo["optimizers"] == jn["optimizers"] and len(jo["log"]) == len(jn["log"])
