@@ -203,3 +203,16 @@ def test_closest_point_on_triangle_regions():
     q2, d2 = I.closest_point(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2], [0, 0, 1], [1, 0, 1], [0, 1, 1]], float),
                              np.array([[0, 1, 2], [3, 4, 5]]), np.array([[0.1, 0.1, 0.0], [0.1, 0.1, 0.9]]))
     assert np.allclose(q2, [[1 / 15] * 3, [0.1, 0.1, 1.0]]) and np.allclose(d2[1], 0.1)
+
+
+def test_nearest_neighbour_restatement_equals_scipy_ckdtree():
+    """The reference's ICP queries scipy.spatial.cKDTree (ICP:16, 91, 109); scipy is installed here, so the oracle's
+    brute-force `nearest` is pinned against the real thing: same indices, same distances."""
+    from scipy.spatial import cKDTree
+    from oracle import icp_ref as I
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=(3000, 3))
+    p = rng.normal(size=(1200, 3)) * 1.3
+    d_ref, i_ref = cKDTree(q).query(p)
+    d, i = I.nearest(p, q)
+    assert np.array_equal(i, i_ref) and np.allclose(d, d_ref, rtol=1e-12, atol=1e-15)
