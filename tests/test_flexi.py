@@ -227,3 +227,28 @@ def test_device_topology_tables_equal_the_host_builders():
     g3 = E.GuidanceBatch([dict(sc, obj_verts=(ov * 0.05).astype(np.float32), obj_faces=of)], grid_res=16)
     assert g3.meta[0]["n_edges"] == len(E.unique_edges(of))
     check_nbr(g3, of)
+
+
+@gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_hip_flexicubes_fuzz_random_fields(seed):
+    """Random trigonometric SDF fields at small resolutions: all 256 cube cases incl. the ambiguous ones, several components,
+    surfaces touching the grid boundary, values exactly zero on grid points (zero counts as outside: s < 0 is inside).
+    Triangles index for index, vertices bit for bit."""
+    from followmyhold_amd import ops
+    rng = np.random.default_rng(500 + seed)
+    res = [6, 9, 12, 16][seed % 4]
+    x, _ = _grid(res)
+    k = rng.uniform(2.0, 9.0, size=(4, 3))
+    ph = rng.uniform(0, 6.28, size=4)
+    xt = x.numpy().astype(np.float64)
+    s = sum(np.sin(xt @ k[i] + ph[i]) for i in range(4)) * 0.25 + rng.uniform(-0.3, 0.3)
+    s = torch.from_numpy(s.astype(np.float32))
+    s[torch.from_numpy(rng.random(len(s)) < 0.02)] = 0.0                       # exact zeros
+    if seed % 2:
+        s = torch.round(s * 4) / 4                                            # many ties and exact zeros
+    V, F, D = FR.flexicubes(x, s, res)
+    v, f, ld = ops.flexicubes(x.cuda(), s.cuda(), res)
+    assert len(V) > 20
+    assert torch.equal(f.cpu(), F) and torch.equal(v.cpu(), V)
+    assert np.allclose(ld.cpu().numpy(), D.numpy(), atol=1e-6)

@@ -186,3 +186,58 @@ def test_lbs_large_batch_matrix_core_tiles():
     assert torch.equal(v_big[150:], v_tail)
     v_valu, _ = ops.lbs(betas, rot, model, use_mfma=0)
     assert (v_big - v_valu).abs().max() < 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_inside_and_distance_fuzz_with_grid_aligned_geometry(seed):
+    """Worst case for a ray-parity inside test: an axis-aligned box whose vertices, edges and faces coincide with grid
+    lines, planes through grid points, plus a sphere; query points on the same lattice (rays through vertices and along
+    edges and faces).  Inside flags, squared distances and nearest-face ids equal the C oracle bit for bit."""
+    from followmyhold_amd import ops
+    rng = np.random.default_rng(900 + seed)
+    n = 9 + seed
+    lin = np.linspace(-1.0, 1.0, n).astype(np.float32)
+    grid = np.stack(np.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    lo, hi = lin[2], lin[-3]
+    bv = np.array([[x, y, z] for x in (lo, hi) for y in (lo, hi) for z in (lo, hi)], np.float32)
+    bf = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+                   [1, 5, 7], [1, 7, 3]], np.int64)
+    sv, sf = synthetic.icosphere(1 + seed % 2, 0.45)
+    sv = sv + rng.choice(lin, 3).astype(np.float32) * 0.25
+    for v, f in ((bv, bf), (sv.astype(np.float32), sf), (np.concatenate([bv, sv]).astype(np.float32), np.concatenate([bf, sf + 8]))):
+        tv, tf, tg = torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda(), torch.from_numpy(grid).cuda()
+        ins = ops.inside_points(tv, tf, tg).cpu().numpy()
+        assert np.array_equal(ins, clib.inside(v, f.astype(np.int32), grid))
+        d2, fi = ops.point_mesh_dist(tv, tf, tg)
+        rd2, rfi = clib.point_mesh_dist(v, f.astype(np.int32), grid)
+        assert np.array_equal(d2.cpu().numpy(), rd2) and np.array_equal(fi.cpu().numpy(), rfi)
+
+
+@gpu
+@pytest.mark.parametrize("res,shift", [(16, 0.0), (24, 0.013), (32, -0.02), (64, 0.0)])
+def test_fused_intersection_count_with_an_axis_aligned_box_object(res, shift):
+    """The joint grid spans the joint AABB, so the extreme faces of an axis-aligned box lie exactly ON boundary grid
+    planes and its edges on grid lines whenever the box sets the AABB: the tie cases of the ray-parity test, inside the
+    fused step's column-parity path.  The count equals the oracle's (kaolin check_sign restatement) exactly."""
+    from followmyhold_amd import engine as E
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_scene
+    sc = make_scene("ico2", 64, 64, seed=5)
+    hv = sc["hand_verts"].numpy()
+    lo, hi = hv.min(0) - 0.01, hv.max(0) + 0.01                   # the box encloses the hand: every hand-inside point counts
+    lo[0] += shift
+    bv = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
+    bf = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+                   [1, 5, 7], [1, 7, 3]], np.int64)
+    scn = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+    scn["obj_verts"], scn["obj_faces"], scn["T_h2m"] = bv, bf, np.eye(4, dtype=np.float32)
+    gb = E.GuidanceBatch([scn], grid_res=res)
+    cfg, _ = E.phase_cfg("C", do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    world = gb.region("world", torch.float32, (-1, 3)).cpu()
+    assert np.abs(world[778:].numpy() - bv).max() < 1e-7           # identity transforms up to (v - c) + c rounding
+    want = R.intersection_count(world[:778], sc["hand_faces"], world[778:], torch.from_numpy(bf), res)
+    assert want > 0 and int(gb.loss_dict(0)["n_intersect"]) == want
