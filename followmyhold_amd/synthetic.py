@@ -139,8 +139,8 @@ def make_object(kind, seed=2):
     high-valence poles, so no pixel sees more than K=100 faces)."""
     if kind == "ico4":
         return icosphere(4, 0.05)
-    if kind == "ico2":
-        return icosphere(2, 0.05)
+    if kind in ("ico1", "ico2", "ico3"):
+        return icosphere(int(kind[3]), 0.05)
     if kind == "20k":
         v, f = icosphere(5)
         return displaced_sphere(v, f, 0.05, seed)

@@ -357,3 +357,40 @@ def test_multi_iteration_graph_and_stream_groups_equal_plain_stepping():
         assert np.allclose(l, ref_l, rtol=1e-3), joint
         for b in grp.batches:
             b.raise_on_flags()
+
+
+@gpu
+@pytest.mark.parametrize("seed,size,obj", [(11, (48, 80), "ico2"), (12, (96, 96), "ico3"), (13, (80, 48), "ico2"), (14, (128, 128), "ico3"),
+                                           (15, (72, 72), "ico1"), (16, (64, 64), "ico3")])
+def test_fused_step_face_indices_over_random_scenes(seed, size, obj):
+    """The scatter rasteriser inside the fused step (all three renders of phase C) over other scenes, image shapes, object
+    tessellations and random similarity parameters: face ids, depths and signed distances of both K=1 renders equal the
+    oracle's bit for bit, the silhouette product matches, the loss to 1e-5."""
+    from followmyhold_amd import engine as E
+    H, W = size
+    sc = make_scene(obj, H, W, seed=seed)
+    rng = np.random.default_rng(seed)
+    q = lambda: torch.tensor(np.concatenate([[1.0], rng.normal(size=3) * 0.05]), dtype=torch.float32)
+    p = S.make_params(scale_hand=torch.tensor([1.0 + 0.05 * rng.normal()], dtype=torch.float32),
+                      trans_hand=torch.tensor(rng.normal(size=3) * 0.004, dtype=torch.float32), rot_hand=q(),
+                      scale_obj=torch.tensor([1.0 + 0.05 * rng.normal()], dtype=torch.float32),
+                      trans_obj=torch.tensor(rng.normal(size=3) * 0.004, dtype=torch.float32), rot_obj=q())
+    total, terms, aux = S.phase_c_loss(sc, p, sc["obj_verts"], R.unique_edges(sc["obj_faces"]), denoise_i=19, grid_res=16)
+    gb = E.GuidanceBatch([_np_scene(sc)], grid_res=16)
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    P = H * W
+    p2f = gb.region("p2f", torch.int32, (2, P)).cpu().numpy()
+    zb = gb.region("zbuf", torch.float32, (2, P)).cpu().numpy()
+    sd = gb.region("sdist", torch.float32, (2, P)).cpu().numpy()
+    for r, ren in enumerate([aux["hand"]["render"], aux["render"]]):
+        ref = ren["sel"]["pix_to_face"].reshape(-1)
+        hit = ref >= 0
+        assert hit.sum() > 20 and np.array_equal(p2f[r], ref)
+        assert np.array_equal(zb[r][hit], ren["sel"]["zbuf"].reshape(-1)[hit]) and np.array_equal(sd[r][hit], ren["sel"]["dists"].reshape(-1)[hit])
+    l = gb.loss_dict(0)
+    assert int(l["n_intersect"]) == aux["n_int"]
+    assert abs(l["total"] - float(total)) <= 1e-5 * abs(float(total))
