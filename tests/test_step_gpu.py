@@ -365,7 +365,7 @@ def test_multi_iteration_graph_and_stream_groups_equal_plain_stepping():
 def test_fused_step_face_indices_over_random_scenes(seed, size, obj):
     """The scatter rasteriser inside the fused step (all three renders of phase C) over other scenes, image shapes, object
     tessellations and random similarity parameters: face ids, depths and signed distances of both K=1 renders equal the
-    oracle's bit for bit, the silhouette product matches, the loss to 1e-5."""
+    oracle's bit for bit, the loss to 1e-5, all gradients to the 1e-4 class."""
     from followmyhold_amd import engine as E
     H, W = size
     sc = make_scene(obj, H, W, seed=seed)
@@ -375,7 +375,8 @@ def test_fused_step_face_indices_over_random_scenes(seed, size, obj):
                       trans_hand=torch.tensor(rng.normal(size=3) * 0.004, dtype=torch.float32), rot_hand=q(),
                       scale_obj=torch.tensor([1.0 + 0.05 * rng.normal()], dtype=torch.float32),
                       trans_obj=torch.tensor(rng.normal(size=3) * 0.004, dtype=torch.float32), rot_obj=q())
-    total, terms, aux = S.phase_c_loss(sc, p, sc["obj_verts"], R.unique_edges(sc["obj_faces"]), denoise_i=19, grid_res=16)
+    st = S.JointStepper(sc, p, denoise_i=19, grid_res=16)
+    total, terms, aux, grads = st.step(update=False)
     gb = E.GuidanceBatch([_np_scene(sc)], grid_res=16)
     gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
@@ -394,3 +395,11 @@ def test_fused_step_face_indices_over_random_scenes(seed, size, obj):
     l = gb.loss_dict(0)
     assert int(l["n_intersect"]) == aux["n_int"]
     assert abs(l["total"] - float(total)) <= 1e-5 * abs(float(total))
+    # gradients of the 16 similarity parameters and of the object vertices (1e-4 relative, north-star tolerance x 5 on
+    # the small parameter blocks whose gradient is a sum of cancelling terms)
+    g = gb.grad_params[0].cpu().numpy()
+    gref = np.concatenate([grads[k].numpy().reshape(-1) for k in E.PARAM_NAMES])
+    assert rel_err(g, gref) < RTOL
+    for k, sl in E.PARAM_SLICES.items():
+        assert rel_err(g[sl], gref[sl]) < 5 * RTOL, (k, g[sl], gref[sl])
+    assert rel_err(gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()) < 5 * RTOL
