@@ -107,6 +107,7 @@ constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd
 constexpr int VP_CAP = 1024;          // (vertex, incident face) pairs staged in LDS per round of k_vert_bwd
 constexpr int SIM_ROWS_MAX = VERT_BLOCKS_MAX * (256 / VB);  // partial rows per (image, mesh)
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
+constexpr int PIX_BWD_TILE_BLOCKS = 256;  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
 constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
@@ -141,7 +142,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol, tile_hit;
+    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -169,6 +170,7 @@ static WS make_ws(const foho_dims& d) {
     // --- zeroed every step (atomic accumulators) ---
     w.zero_begin = o;
     w.frac_count = take(R * B * 4);
+    w.hit_count = take(R * B * 4);  // tiles with at least one hit pixel, per (render, image)
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
     w.g_world = take(V3);
@@ -199,7 +201,7 @@ static WS make_ws(const foho_dims& d) {
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
     w.prod = take(R * B * P * 4);
-    w.tile_hit = take(R * B * (size_t)w.nbtiles);  // 1 = the tile holds at least one hit pixel
+    w.hit_list = take(R * B * (size_t)w.nbtiles * 4);  // ids of those tiles (k_resolve appends, k_pix_bwd walks the list)
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
@@ -270,7 +272,8 @@ struct Ctx {
     float* face_ndc;
     int32_t* p2f;
     float *zbuf, *sdist, *prod, *pcol;
-    uint8_t* tile_hit;
+    int* hit_list;
+    unsigned* hit_count;
     unsigned long long* zkey;
     unsigned* fcnt;
     float *psum, *plog;

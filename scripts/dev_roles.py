@@ -22,7 +22,7 @@ print("zmin", fv[:, :, 2].min(), "hand box px: mean %.1f max %.0f sum %.0f | obj
     area[:Fh].mean(), area[:Fh].max(), area[:Fh].sum(), area[Fh:].mean(), area[Fh:].max(), area[Fh:].sum()))
 print("per-block T: hand(8) max %.0f  obj(64) max %.0f" % (max(area[i:i + 8].sum() for i in range(0, Fh, 8)),
       max(area[Fh + i:Fh + i + 64].sum() for i in range(0, len(area) - Fh, 64))))
-masks = [0, 1, 2, 4, 32, 1 | 2, 2 | 32, 59, 61, 31, 62]
+masks = [int(x) for x in os.environ["MASKS"].split(",")] if os.environ.get("MASKS") else [0, 1, 2, 4, 32, 1 | 2, 2 | 32, 59, 61, 31, 62]
 res = {m: [] for m in masks}
 for rep in range(5):
     for m in masks:
