@@ -142,7 +142,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count;
+    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -188,6 +188,8 @@ static WS make_ws(const foho_dims& d) {
     w.fcnt = take(R * B * P * 4);  // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
     w.psum = take(R * B * P * 4);  // sum of (1 - p) over the fractional fragments (exact product for one fragment)
     w.plog = take(R * B * P * 4);  // sum of log(1 - p) over the fractional fragments (product for several)
+    w.tile_touched = take(R * B * (size_t)w.nbtiles);  // 1 = a face's pixel box overlaps the tile this step (raster setup)
+    w.tile_clean = take(R * B * (size_t)w.nbtiles);    // 1 = the tile's p2f entries are known to be all -1
     w.clean_end = o;
     // --- plain scratch ---
     w.mesh_info = take(B * 2 * sizeof(MeshInfo));
@@ -274,6 +276,7 @@ struct Ctx {
     float *zbuf, *sdist, *prod, *pcol;
     int* hit_list;
     unsigned* hit_count;
+    uint8_t *tile_touched, *tile_clean;
     unsigned long long* zkey;
     unsigned* fcnt;
     float *psum, *plog;
