@@ -31,19 +31,27 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
-SCENE = dict(obj_kind="ico2", H=64, W=64, seed=3)
 RADIUS = 0.35           # Hunyuan-space radius of the stand-in decoder's sphere prior
-SCHEDULE = dict(num_inference_steps=4, guidance_start_step=2, handopt_start_step=1, guidance_end_step=4,
-                optimization_steps_hand=3, optimization_steps_scale=2, optimization_steps_joint=2)
 VAE_KW = dict(num_latents=16, embed_dim=4, width=16, heads=2, layers=1, num_freqs=3, radius=RADIUS, sharpness=4.0, gain=0.1)
+# variant 0: one joint denoising step, intersection term on; variant 1: another scene and image size, two joint denoising
+# steps (scheduler.step between them, CFG scale decaying), intersection term off
+VARIANTS = [
+    dict(tag="", scene=dict(obj_kind="ico2", H=64, W=64, seed=3), config={},
+         schedule=dict(num_inference_steps=4, guidance_start_step=2, handopt_start_step=1, guidance_end_step=4,
+                       optimization_steps_hand=3, optimization_steps_scale=2, optimization_steps_joint=2)),
+    dict(tag="_v1", scene=dict(obj_kind="ico2", H=80, W=80, seed=8), config=dict(use_intersection_loss=False),
+         schedule=dict(num_inference_steps=5, guidance_start_step=2, handopt_start_step=1, guidance_end_step=5,
+                       optimization_steps_hand=2, optimization_steps_scale=2, optimization_steps_joint=2)),
+]
+SCENE, SCHEDULE = VARIANTS[0]["scene"], VARIANTS[0]["schedule"]
 
 
-def build_inputs(root):
+def build_inputs(root, scene=None):
     """Scene files in the reference's formats + the RGBA object crop; shared with tests/test_pipeline.py."""
     from helpers import oracle_render_fn
     from followmyhold_amd import synthetic
     from test_pipeline import _write
-    sc = synthetic.build_scene(oracle_render_fn, **SCENE)
+    sc = synthetic.build_scene(oracle_render_fn, **(scene or SCENE))
     T = sc["T_h2m"].astype(np.float64)
     ov_moge = sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
     r_moge = np.linalg.norm(ov_moge - ov_moge.mean(0), axis=1).mean()
@@ -109,9 +117,15 @@ def main():
         setattr(PL, k, v)
     sys.modules["pytorch3d.io.experimental_gltf_io"] = types.SimpleNamespace(_read_header=None, MeshGlbFormat=lambda: None)
 
+    for variant in VARIANTS:
+        run_variant(variant, PL, SCH, OptimizationConfig, P, standins)
+
+
+def run_variant(variant, PL, SCH, OptimizationConfig, P, standins):
+    from PIL import Image
     with tempfile.TemporaryDirectory() as root, contextlib.ExitStack() as stack:
         import pathlib
-        sc, paths = build_inputs(pathlib.Path(root))
+        sc, paths = build_inputs(pathlib.Path(root), variant["scene"])
         # the reference torch.load()s ./third_party/estimator/hamer/J_regressor_hamer.pt relative to the cwd (PL:1218)
         os.makedirs(os.path.join(root, "third_party/estimator/hamer"))
         torch.save(torch.from_numpy(sc["J_regressor"]), os.path.join(root, "third_party/estimator/hamer/J_regressor_hamer.pt"))
@@ -125,7 +139,7 @@ def main():
         pipe.scheduler = SCH.FlowMatchEulerDiscreteScheduler()
         pipe.device, pipe.dtype = torch.device("cpu"), torch.float32
         cfg = OptimizationConfig()
-        for k, v in SCHEDULE.items():
+        for k, v in {**variant["schedule"], **variant["config"]}.items():
             setattr(cfg, k, v)
         renderer = P.NormalRenderer(sc["fov"], sc["H"], sc["W"])
         sil_renderer = P.SilhouetteRenderer(sc["fov"], sc["H"], sc["W"])
@@ -164,9 +178,9 @@ def main():
         big = [p for p in params if p.numel() > 4]
         if big:
             arrays[f"opt{n}_noise"] = big[0].detach().float().numpy()
-    np.savez_compressed(os.path.join(OUT, "ref_pipeline.npz"), **arrays)
-    with open(os.path.join(OUT, "ref_pipeline.json"), "w") as f:
-        json.dump(dict(scene=SCENE, radius=RADIUS, schedule=SCHEDULE, vae_kw=VAE_KW, log=lines, optimizers=[m[0] for m in made],
+    np.savez_compressed(os.path.join(OUT, f"ref_pipeline{variant['tag']}.npz"), **arrays)
+    with open(os.path.join(OUT, f"ref_pipeline{variant['tag']}.json"), "w") as f:
+        json.dump(dict(scene=variant["scene"], radius=RADIUS, schedule=variant["schedule"], config=variant["config"], vae_kw=VAE_KW, log=lines, optimizers=[m[0] for m in made],
                        torch=torch.__version__), f, indent=1)
     print("hand", arrays["hand_verts"].shape, "object", arrays["obj_counts"], arrays["obj_stats"])
 

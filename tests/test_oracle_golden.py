@@ -345,9 +345,10 @@ def test_golden_files_regenerate_from_the_reference(tmp_path):
     for k in G.files:
         assert np.array_equal(new[k], G[k], equal_nan=True), k
     assert json.load(open(tmp_path / "ref_meta.json")) == META
-    old_p, new_p = np.load(os.path.join(gdir, "ref_pipeline.npz")), np.load(str(tmp_path / "ref_pipeline.npz"))
-    assert sorted(old_p.files) == sorted(new_p.files)
-    for k in old_p.files:
-        assert np.allclose(new_p[k], old_p[k], rtol=1e-5, atol=1e-6), k
-    jo, jn = json.load(open(os.path.join(gdir, "ref_pipeline.json"))), json.load(open(tmp_path / "ref_pipeline.json"))
-    assert jo["schedule"] == jn["schedule"] and jo["optimizers"] == jn["optimizers"] and len(jo["log"]) == len(jn["log"])
+    for tag in ("", "_v1"):
+        old_p, new_p = np.load(os.path.join(gdir, f"ref_pipeline{tag}.npz")), np.load(str(tmp_path / f"ref_pipeline{tag}.npz"))
+        assert sorted(old_p.files) == sorted(new_p.files)
+        for k in old_p.files:
+            assert np.allclose(new_p[k], old_p[k], rtol=1e-5, atol=1e-6), (tag, k)
+        jo, jn = json.load(open(os.path.join(gdir, f"ref_pipeline{tag}.json"))), json.load(open(tmp_path / f"ref_pipeline{tag}.json"))
+        assert jo["schedule"] == jn["schedule"] and jo["optimizers"] == jn["optimizers"] and len(jo["log"]) == len(jn["log"])

@@ -267,12 +267,14 @@ def test_guidance_stage_driver_with_standin_networks(tmp_path, monkeypatch):
 
 
 @gpu
-def test_replay_of_the_reference_loop_trajectory(tmp_path):
-    """tests/golden/ref_pipeline.npz holds what the REFERENCE's own `__call__` (PL:1044-1679) returned and printed when it
-    was executed in the build container on this scene with the CPU restatement standing in for pytorch3d / kaolin
-    (tests/golden/make_pipeline_golden.py).  The same inputs through GuidedShapePipeline on the GPU must give the same
-    first-iteration losses of phases B and C (they depend on everything before them: DiT call, CFG mix, scheduler,
-    latent -> SDF -> FlexiCubes, phase A / B optimisation, scheduler.step), the same final hand and the same final object."""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
+    """tests/golden/ref_pipeline*.npz hold what the REFERENCE's own `__call__` (PL:1044-1679) returned and printed when it
+    was executed in the build container on these scenes with the CPU restatement standing in for pytorch3d / kaolin
+    (tests/golden/make_pipeline_golden.py; variant 1 has two joint denoising steps and the intersection term off).  The
+    same inputs through GuidedShapePipeline on the GPU must give the same first-iteration losses of every phase (they
+    depend on everything before them: DiT call, CFG mix, scheduler, latent -> SDF -> FlexiCubes, the optimisation of the
+    earlier phases, scheduler.step), the same per-phase parameters, the same final hand and the same final object."""
     import json
     import re
     import sys
@@ -281,22 +283,22 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path):
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     sys.path.insert(0, gdir)
     import make_pipeline_golden as MPG
-    ref = np.load(os.path.join(gdir, "ref_pipeline.npz"))
-    meta = json.load(open(os.path.join(gdir, "ref_pipeline.json")))
-    sc, paths = MPG.build_inputs(tmp_path)
+    var = MPG.VARIANTS[variant]
+    ref = np.load(os.path.join(gdir, f"ref_pipeline{var['tag']}.npz"))
+    meta = json.load(open(os.path.join(gdir, f"ref_pipeline{var['tag']}.json")))
+    sc, paths = MPG.build_inputs(tmp_path, var["scene"])
     chk = np.array([float(np.abs(sc[k].astype(np.float64)).sum()) for k in ("hand_verts", "obj_verts", "moge_normal", "moge_disp", "kps_2d", "T_h2m")])
     assert np.allclose(chk, ref["scene_checksum"], rtol=1e-6), "the synthetic scene differs from the one the fixture was made on"
     pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1, **MPG.VAE_KW)
     wchk = np.array([float(sum(p.detach().double().abs().sum() for p in m.parameters())) for m in (pipe.vae, pipe.model, pipe.conditioner)])
     assert np.allclose(wchk, ref["weights_checksum"], rtol=1e-6), "stand-in network initialisation differs"
     cfg = E.OptimizationConfig()
-    for k, v in MPG.SCHEDULE.items():
+    for k, v in {**var["schedule"], **var["config"]}.items():
         setattr(cfg, k, v)
-    # Phase A takes three Adam steps with a quaternion learning rate of 0.5 on a 64 x 64 render: its result agrees with the
+    # Phase A takes a few Adam steps with a quaternion learning rate of 0.5 on a small render: its result agrees with the
     # reference's to a few 1e-3 (Adam with eps = 1e-4 turns a 1e-6 difference in a small gradient component into a 1e-3
-    # step), and a difference of that size moves enough pixels between faces to change the later
-    # (much smaller) phase-C hand gradients.  To compare phases B and C like for like, they are started from the
-    # reference's own phase-A result.
+    # step), and a difference of that size moves enough pixels between faces to change the later (much smaller) phase-C
+    # hand gradients.  To compare the later phases like for like, they are started from the reference's own phase-A result.
     after_a = {}
 
     def align(phase, i, gb):
@@ -307,34 +309,50 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path):
     obj, hand = pipe(image=[Image.open(paths["cropped_obj_img_path"])], mc_algo="mc", generator=torch.manual_seed(2), config=cfg,
                      renderer=_renderer(sc["fov"]), sil_renderer=None, J_regressor=sc["J_regressor"], enable_pbar=False,
                      on_phase_end=align, **paths)
-    assert pipe.stats == {"inner_iterations": 3 + 2 + 2, "skipped_empty": 0}
-    print("A", after_a["params"].cpu().numpy(), ref["opt0_small"])
+    sch = var["schedule"]
+    n_joint = sch["num_inference_steps"] - sch["handopt_start_step"] - 2
+    assert pipe.stats == {"inner_iterations": sch["optimization_steps_hand"] + sch["optimization_steps_scale"]
+                          + n_joint * sch["optimization_steps_joint"], "skipped_empty": 0}
     assert np.allclose(after_a["params"].cpu().numpy(), ref["opt0_small"], atol=6e-3)
-    # first-iteration losses the reference printed (PL:1446-1450, 1594-1598)
+    # first-iteration losses the reference printed (PL:1351-1355, 1446-1450, 1594-1598)
     num = lambda line: dict((k.strip(), float(v)) for k, v in re.findall(r"([A-Za-z_ 0-9]+): ([-+0-9.eE]+)", line.split(",", 1)[1]))
-    opt = [l for l in meta["log"] if l.startswith("Opt step 0")]
-    ref_a, ref_b, ref_c = num(opt[0]), num(opt[1]), num(opt[2])
-    (pa_, ia, ka, la), (pb, ib, kb, lb), (pc, ic, kc, lc) = pipe.loss_log
-    assert (pa_, ia, ka, pb, ib, kb, pc, ic, kc) == ("A", 1, 0, "B", 2, 0, "C", 3, 0)
-    close = lambda a, b, tol: abs(a - b) <= tol * abs(b)
-    assert close(la["kps"], ref_a["loss_2d_kps"], 1e-4) and close(la["normal0"], ref_a["loss_normal_hand"], 1e-4)
-    assert close(la["disp0"], ref_a["loss_disp_hand"], 1e-4)
-    assert close(lb["edge"], ref_b["object loss"], 1e-4) and close(lb["normal0"], ref_b["loss_normal_obj"], 1e-4)
-    assert close(lb["disp0"], ref_b["loss_disp"], 1e-4)
-    assert close(lc["edge"], ref_c["object loss"], 2e-3) and close(lc["normal1"], ref_c["loss_normal_hoi"], 2e-3)
-    assert close(lc["disp1"], ref_c["loss_disp"], 2e-3) and close(lc["n_intersect"] / 1000.0, ref_c["loss_intersection"], 2e-2)
+    opt = [num(l) for l in meta["log"] if l.startswith("Opt step 0")]
+    assert [(p_, k_) for p_, _, k_, _ in pipe.loss_log] == [("A", 0), ("B", 0)] + [("C", 0)] * n_joint and len(opt) == 2 + n_joint
+    close = lambda a, b, tol: abs(a - b) <= tol * abs(b) + 1e-12
+    la, lb = pipe.loss_log[0][3], pipe.loss_log[1][3]
+    assert close(la["kps"], opt[0]["loss_2d_kps"], 1e-4) and close(la["normal0"], opt[0]["loss_normal_hand"], 1e-4)
+    assert close(la["disp0"], opt[0]["loss_disp_hand"], 1e-4)
+    assert close(lb["edge"], opt[1]["object loss"], 1e-4) and close(lb["normal0"], opt[1]["loss_normal_obj"], 1e-4)
+    assert close(lb["disp0"], opt[1]["loss_disp"], 1e-4)
+    for j in range(n_joint):
+        lc, rc = pipe.loss_log[2 + j][3], opt[2 + j]
+        tol = 2e-3 * (1 + 4 * j)          # each further joint step inherits the differences of the one before
+        assert close(lc["edge"], rc["object loss"], tol) and close(lc["normal1"], rc["loss_normal_hoi"], tol), (j, lc, rc)
+        assert close(lc["disp1"], rc["loss_disp"], tol)
+        if cfg.use_intersection_loss:
+            assert close(lc["n_intersect"] / 1000.0, rc["loss_intersection"], 2e-2)
+        else:
+            assert rc["loss_intersection"] == 0.0
     # parameters each phase ended with (the reference's per-phase leaf tensors, PL:1300-1318, 1366-1384, 1461-1478)
-    (_, _, pa, _), (_, _, pb_, nb), (_, _, pc_, nc) = pipe.param_log
-    print("B", pb_[8:].cpu().numpy(), ref["opt1_small"])
-    print("C", pc_.cpu().numpy(), ref["opt2_small"])
+    assert len(pipe.param_log) == 2 + n_joint and meta["optimizers"] == ["Adam"] + ["AdamW"] * (1 + n_joint)
+    _, _, pb_, nb = pipe.param_log[1]
     assert np.allclose(pb_[8:].cpu().numpy(), ref["opt1_small"], atol=2e-4) and np.allclose(nb.cpu().numpy(), ref["opt1_noise"], atol=2e-4)
-    assert np.allclose(pc_.cpu().numpy(), ref["opt2_small"], atol=5e-4) and np.allclose(nc.cpu().numpy(), ref["opt2_noise"], atol=5e-3)
+    # The first joint phase starts from matched states and is compared tightly.  A later one inherits 1e-4-level differences,
+    # and where a gradient component is near zero Adam (eps 1e-4) turns those into a different step of size lr (1e-2 for the
+    # object translation / rotation): only the hand (lr 1e-4 / 1e-2, well-conditioned) stays tight there.
+    for j in range(n_joint):
+        _, _, pc_, nc = pipe.param_log[2 + j]
+        atol = np.full(16, 5e-4) if j == 0 else np.concatenate([np.full(8, 2e-3), np.full(8, 2.5e-2)])
+        diff = np.abs(pc_.cpu().numpy() - ref[f"opt{2 + j}_small"])
+        assert (diff <= atol).all(), (j, pc_.cpu().numpy(), ref[f"opt{2 + j}_small"])
+        assert np.allclose(nc.cpu().numpy(), ref[f"opt{2 + j}_noise"], atol=5e-3 if j == 0 else 5e-2)
     # final hand: the MoGe-space MANO under the optimised similarity; final object: res-384 decode under its similarity
+    tol_v = 2e-4 * (1 + 10 * (n_joint - 1))
     hv = hand.verts_packed().cpu().numpy()
     assert np.array_equal(hand.faces_packed().cpu().numpy(), ref["hand_faces"])
-    assert np.abs(hv - ref["hand_verts"]).max() < 2e-4, np.abs(hv - ref["hand_verts"]).max()
+    assert np.abs(hv - ref["hand_verts"]).max() < tol_v, np.abs(hv - ref["hand_verts"]).max()
     ov, of = obj.verts_packed().cpu().numpy(), obj.faces_packed().cpu().numpy()
     assert abs(len(ov) - ref["obj_counts"][0]) <= 0.002 * ref["obj_counts"][0]
     st, want = MPG.object_stats(ov, of), ref["obj_stats"]
-    assert np.abs(st[:9] - want[:9]).max() < 1e-3                                  # centroid and bounding box (metres)
-    assert np.allclose(st[9:], want[9:], rtol=2e-2)                                # radius mean / std, area, volume
+    assert np.abs(st[:9] - want[:9]).max() < (1e-3 if n_joint == 1 else 2.5e-2)      # centroid and bounding box (metres)
+    assert np.allclose(st[9:], want[9:], rtol=2e-2 if n_joint == 1 else 0.15)        # radius mean / std, area, volume
