@@ -142,7 +142,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean;
+    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean, pair_v;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -199,6 +199,7 @@ static WS make_ws(const foho_dims& d) {
     w.vn_raw = take(V3);
     w.vn = take(V3);
     w.face_ndc = take((size_t)d.Ftot * 9 * 4);
+    w.pair_v = take((size_t)d.Ftot * 3 * 16);  // per (vertex, incident face) pair, CSR order: the face's 3 vertex ids + the corner
     w.p2f = take(R * B * P * 4);
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
@@ -277,6 +278,7 @@ struct Ctx {
     int* hit_list;
     unsigned* hit_count;
     uint8_t *tile_touched, *tile_clean;
+    int4* pair_v;
     unsigned long long* zkey;
     unsigned* fcnt;
     float *psum, *plog;
