@@ -152,8 +152,10 @@ enum {
 enum {
     FOHO_STAGE_VERTEX = 1, FOHO_STAGE_RASTER = 2, FOHO_STAGE_LOSS = 4, FOHO_STAGE_BACKWARD = 8,
     FOHO_STAGE_INSIDE = 16, FOHO_STAGE_FINAL = 32,
-    FOHO_STAGE_BBOX = 64,            /* AABB of verts_in (centre of the similarity transform, PL:111): needed once
-                                        and again whenever the caller rewrites verts_in                        */
+    FOHO_STAGE_BBOX = 64,            /* per-input state in the workspace: AABB of verts_in (centre of the similarity
+                                        transform, PL:111), clean rasteriser planes, the (vertex, face) pair table of
+                                        the topology: needed once per workspace and again whenever the caller
+                                        rewrites verts_in, faces or the incidence tables                         */
     FOHO_STAGE_STEP = 63,            /* one optimisation step with a cached AABB                               */
     FOHO_STAGE_ALL = 127
 };
