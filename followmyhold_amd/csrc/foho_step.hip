@@ -147,7 +147,7 @@ struct WS {
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t g_ndc, g_nrm, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket, knn_ticket, knn_inv;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -180,6 +180,8 @@ static WS make_ws(const foho_dims& d) {
     w.int_count = take(B * 4);
     w.loss_ticket = take(R * B * 4);
     w.final_ticket = take(B * 4);
+    w.knn_ticket = take(B * 4);
+    w.knn_inv = take(B * (size_t)std::max(d.Vh_max, 1) * 8);  // ~(d2 bits << 32 | index) of the nearest object vertex, atomicMax
     w.zero_end = o;
     // --- scatter planes of the rasteriser: all-zero outside [k_stage2, k_resolve]; k_resolve puts back to zero what
     // it consumed, FOHO_STAGE_BBOX clears everything (first use / after an aborted step)
@@ -292,7 +294,8 @@ struct Ctx {
     float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special;
     unsigned long long* parity;
     int32_t* int_count;
-    unsigned *loss_ticket, *final_ticket;
+    unsigned *loss_ticket, *final_ticket, *knn_ticket;
+    unsigned long long* knn_inv;
     int btiles_x;
 };
 
