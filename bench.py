@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--streams", type=int, default=0, help="independent image groups, one HIP stream + hipGraph each "
-                    "(0 = auto: 1 below 4 images per GPU, 2 below 16, else 4)")
+                    "(0 = auto: min(4, images per GPU))")
     ap.add_argument("--obj", default="20k", choices=["ico4", "20k", "40k"])
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--joint-graph", action="store_true", help="one hipGraph with a branch per stream instead of one graph "
@@ -119,7 +119,8 @@ def main():
     render_fn = E.hip_render_fn(dev)
     # image-sharded: global image index = rank * ipg + j (seed per image)
     scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=rank * ipg + j) for j in range(ipg)]
-    n_streams = args.streams if args.streams > 0 else (1 if ipg < 4 else (2 if ipg < 16 else 4))
+    # measured (8 images: 1 / 2 / 4 / 8 streams = 38 / 48 / 58 / 40 k steps/s): up to four independent groups overlap well
+    n_streams = args.streams if args.streams > 0 else min(4, ipg)
     group = E.GuidanceGroup(scenes, n_streams, device=dev)
     gb = group.batches[0]
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
