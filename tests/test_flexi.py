@@ -252,3 +252,43 @@ def test_hip_flexicubes_fuzz_random_fields(seed):
     assert len(V) > 20
     assert torch.equal(f.cpu(), F) and torch.equal(v.cpu(), V)
     assert np.allclose(ld.cpu().numpy(), D.numpy(), atol=1e-6)
+
+
+@gpu
+@pytest.mark.parametrize("seed", range(5))
+def test_topology_tables_fuzz_on_flexicubes_meshes(seed):
+    """Meshes as the pipeline produces them (FlexiCubes on random fields: several components, all valences dual marching
+    cubes emits, surfaces cut by the grid boundary -> open meshes) through GuidanceBatch.update_object: the incidence and
+    neighbour tables equal the numpy builders', whichever path (closed-manifold device kernel or general sort) was taken."""
+    from followmyhold_amd import engine as E, ops
+    from helpers import make_scene
+    rng = np.random.default_rng(700 + seed)
+    res = [10, 14, 18, 12, 16][seed]
+    x, _ = _grid(res)
+    k = rng.uniform(2.0, 7.0, size=(3, 3))
+    xt = x.numpy().astype(np.float64)
+    s = sum(np.sin(xt @ k[i] + rng.uniform(0, 6.28)) for i in range(3)) / 3.0 + rng.uniform(-0.2, 0.2)
+    if seed % 2 == 0:      # closed: push the boundary layer outside
+        edge = (np.abs(xt).max(1) > 1.1 * (1 - 1.5 / res))
+        s = np.where(edge, 1.0, s)
+    v, f, _ = ops.flexicubes(x.cuda(), torch.from_numpy(s.astype(np.float32)).cuda(), res)
+    assert len(f) > 50
+    sc = {k_: (v_.numpy() if isinstance(v_, torch.Tensor) else v_) for k_, v_ in make_scene("ico2", 64, 64, seed=0).items()}
+    gb = E.GuidanceBatch([sc], grid_res=16)
+    gb.update_object(v * 0.04, f)
+    of = f.cpu().numpy()
+    Vh, Vtot = gb.meta[0]["Vh"], gb.Vtot
+    faces = gb.faces.cpu().numpy().astype(np.int64)
+    inc_off, inc_fc = E.incidence_csr(faces, Vtot)
+    assert np.array_equal(gb.inc_off.cpu().numpy(), inc_off) and np.array_equal(gb.inc_fc.cpu().numpy(), inc_fc)
+    edges = E.unique_edges(of)
+    assert gb.meta[0]["n_edges"] == len(edges)
+    off, idx = E.neighbour_csr(edges + Vh, Vtot)
+    d_off, d_idx = gb.nbr_off.cpu().numpy(), gb.nbr_idx.cpu().numpy()
+    for vv in range(Vh, Vtot):
+        assert np.array_equal(np.sort(d_idx[d_off[vv]:d_off[vv + 1]]), idx[off[vv]:off[vv + 1]]), vv
+    # and the step runs on them
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    assert np.isfinite(gb.loss_dict(0)["total"]) and np.isfinite(gb.grad_obj_verts(0).cpu().numpy()).all()
