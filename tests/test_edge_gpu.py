@@ -288,3 +288,39 @@ def test_rasteriser_fuzz_bit_exact(seed):
     assert hit.sum() > 50
     assert np.array_equal(zb, ref["zbuf"].reshape(-1)) and np.array_equal(di, ref["dists"].reshape(-1))
     assert np.array_equal(ba, ref["bary"].reshape(-1, 3))
+
+
+@gpu
+def test_large_frame_walks_several_hit_tiles_per_workgroup():
+    """1024 x 640, zoomed in: several hundred hit tiles per render, four per k_pix_bwd workgroup (the strided walk over the hit-tile
+    list with its table reuse), 2 560 resolve tiles of which most are skipped by the touched / clean flags.  Loss, face ids
+    and every gradient against the oracle."""
+    from followmyhold_amd import engine as E
+    H, W = 640, 1024
+    sc = make_scene("ico3", H, W, seed=21, fov=22.0)          # zoomed in: the hand and the object fill the frame
+    p = S.make_params(rot_hand=torch.tensor([0.999, 0.01, -0.02, 0.015]), trans_obj=torch.tensor([0.002, -0.001, 0.003]))
+    st = S.JointStepper(sc, p, denoise_i=19, grid_res=16)
+    total, terms, aux, grads = st.step(update=False)
+    gb = E.GuidanceBatch([{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}], grid_res=16)
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    for _ in range(2):          # twice: the second pass runs on the tile flags the first one left behind
+        gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    P = H * W
+    p2f = gb.region("p2f", torch.int32, (2, P)).cpu().numpy()
+    hits = []
+    for r, ren in enumerate([aux["hand"]["render"], aux["render"]]):
+        ref = ren["sel"]["pix_to_face"].reshape(-1)
+        assert np.array_equal(p2f[r], ref)
+        hit_tiles = (ref.reshape(H // 8, 8, W // 32, 32) >= 0).any(axis=(1, 3)).sum()
+        hits.append(int(hit_tiles))
+    assert hits[1] > 256 * 2, hits                                   # more than two tiles per workgroup of the HOI render
+    l = gb.loss_dict(0)
+    assert abs(l["total"] - float(total)) <= 1e-5 * abs(float(total))
+    g = gb.grad_params[0].cpu().numpy()
+    gref = np.concatenate([grads[k].numpy().reshape(-1) for k in E.PARAM_NAMES])
+    assert np.linalg.norm(g - gref) <= 1e-4 * np.linalg.norm(gref)
+    gv, gvr = gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()
+    assert np.linalg.norm(gv - gvr) <= 5e-4 * np.linalg.norm(gvr)
