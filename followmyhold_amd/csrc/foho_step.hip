@@ -107,6 +107,8 @@ constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd
 constexpr int VP_CAP = 1024;          // (vertex, incident face) pairs staged in LDS per round of k_vert_bwd
 constexpr int SIM_ROWS_MAX = VERT_BLOCKS_MAX * (256 / VB);  // partial rows per (image, mesh)
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
+constexpr int SIM_ACC = 40;            // floats per image and parity in the deferred-update accumulators (36 used)
+constexpr int STATE_NEXT = 64;         // floats per image in the deferred-update staging area
 constexpr int PIX_BWD_TILE_BLOCKS = 256;  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
 constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
 
@@ -142,7 +144,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean, pair_v;
+    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -192,6 +194,8 @@ static WS make_ws(const foho_dims& d) {
     w.plog = take(R * B * P * 4);  // sum of log(1 - p) over the fractional fragments (product for several)
     w.tile_touched = take(R * B * (size_t)w.nbtiles);  // 1 = a face's pixel box overlaps the tile this step (raster setup)
     w.tile_clean = take(R * B * (size_t)w.nbtiles);    // 1 = the tile's p2f entries are known to be all -1
+    w.sim_acc = take(2 * B * (size_t)SIM_ACC * 4);     // deferred update: per step parity, the 36 partial sums of the final stage (float atomics)
+    w.pending = take(B * 4);                           // 1 = a deferred update of image b waits for the next k_xform / finalize
     w.clean_end = o;
     // --- plain scratch ---
     w.mesh_info = take(B * 2 * sizeof(MeshInfo));
@@ -201,6 +205,7 @@ static WS make_ws(const foho_dims& d) {
     w.vn_raw = take(V3);
     w.vn = take(V3);
     w.face_ndc = take((size_t)d.Ftot * 9 * 4);
+    w.state_next = take(B * (size_t)STATE_NEXT * 4);   // deferred update: params 16 | adam m 16 | adam v 16 | t | flags, written by k_xform
     w.pair_v = take((size_t)d.Ftot * 3 * 16);  // per (vertex, incident face) pair, CSR order: the face's 3 vertex ids + the corner
     w.p2f = take(R * B * P * 4);
     w.zbuf = take(R * B * P * 4);
@@ -281,6 +286,9 @@ struct Ctx {
     unsigned* hit_count;
     uint8_t *tile_touched, *tile_clean;
     int4* pair_v;
+    int* pending;
+    float* state_next;
+    float* sim_acc;
     unsigned long long* zkey;
     unsigned* fcnt;
     float *psum, *plog;
@@ -339,6 +347,7 @@ __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (
 #include "k_raster.inc"
 #include "k_loss.inc"
 #include "k_final.inc"
+#include "k_xform.inc"
 #include "k_backward.inc"
 #include "host.inc"
 #include "ops.inc"

@@ -11,6 +11,7 @@ src/foho/configs/guid_config.py (CFG) of the reference:
   phase "C"  joint        PL:1480-1588, AdamW (CFG phase2_hand_lrs + obj_lrs)  <- the "guidance step"
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -489,11 +490,28 @@ class GuidanceBatch:
         torch.cuda.synchronize(self.device)
         for t, saved in zip((self.params, self.adam_m, self.adam_v, self.adam_t, self.flags), state):
             t.copy_(saved)
+        # Several iterations in one graph: every iteration but the last leaves its final stage (loss assembly, parameter
+        # gradients, Adam) to the prologue of the next one (foho_step_cfg.deferred_update) -- the serial last-workgroup
+        # tail of k_vert_bwd disappears from the chain -- and one foho_step_finalize launch closes the graph.
+        deferred = steps_per_graph > 1 and os.environ.get("FOHO_NO_DEFERRED_UPDATE") != "1"
+        def numbered(k):        # deferred_update = 1 + parity of the iteration: its accumulators are double buffered
+            c2 = L.FohoStepCfg.from_buffer_copy(bytes(cfg))
+            c2.deferred_update = 1 + (k & 1)
+            return c2
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(steps_per_graph):
-                self.step(cfg)
+            for k in range(steps_per_graph):
+                self.step(numbered(k) if deferred else cfg)
+            if deferred:
+                self.finalize(numbered(steps_per_graph - 1))
         return g
+
+    def finalize(self, cfg, stream=None):
+        """Apply the update a deferred_update step left pending (no-op when nothing is pending)."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.foho_step_finalize(ctypes.byref(self.desc()), ctypes.byref(cfg), ctypes.c_void_p(stream)),
+                "foho_step_finalize")
 
     def step_profiled(self, cfg):
         """One iteration with a hipEvent after every kernel; returns {kernel name: milliseconds}."""

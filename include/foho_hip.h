@@ -108,6 +108,13 @@ typedef struct {
     int32_t world_space_input;       /* 1: the similarity transform is skipped (vertices are used as they are, after
                                         T_h2m for the object) -- rendering target maps of a fixed mesh (PL:1247-1256),
                                         where the reference does not apply transform_mesh_around_center either      */
+    int32_t deferred_update;         /* 1 + (k & 1) for the k-th step of a sequence, 0 = off.  The step ends after k_vert_bwd
+                                        has accumulated its partial sums (double buffered by that parity); loss assembly,
+                                        parameter gradients and the optimiser update are applied by the prologue of the
+                                        NEXT step's first kernel (every workgroup recomputes them, one stores them) --
+                                        for back-to-back steps inside one hipGraph, where it removes the serial tail of
+                                        the last-workgroup stage.  params / adam / losses / flags of the last step only
+                                        become visible after foho_step_finalize()                                    */
 } foho_step_cfg;
 
 /* ---- buffers of one batched step -------------------------------------------------------------- */
@@ -171,6 +178,9 @@ size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
 int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
+/* Applies the update a deferred_update step left pending (no-op per image when nothing is pending): one small launch;
+ * cfg->deferred_update must carry the number of the LAST step run. */
+int foho_step_finalize(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream);
 /* Same as foho_step_run(FOHO_STAGE_STEP) but brackets every launch with hipEvents on `stream`, synchronises
  * the stream and returns the duration of each launch in milliseconds (measurement aid for bench.py);
  * foho_kernel_name(i) names the i-th launch of the calling thread's last profiled run ("" past the end). */
