@@ -149,7 +149,7 @@ struct WS {
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t g_ndc, g_nrm, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, loss_ticket, final_ticket, knn_inv, loss_acc;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -180,7 +180,6 @@ static WS make_ws(const foho_dims& d) {
     w.g_nrm = take(V3);  // dL/d(unit vertex normal) = sum of the colour gradients of the incident faces
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
-    w.loss_ticket = take(R * B * 4);
     w.final_ticket = take(B * 4);
     w.loss_acc = take(R * B * NPART * 8);  // 12 loss sums per render (double atomics of k_loss, read by k_pix_bwd)
     w.knn_inv = take(B * (size_t)std::max(d.Vh_max, 1) * 8);  // ~(d2 bits << 32 | index) of the nearest object vertex, atomicMax
@@ -302,7 +301,7 @@ struct Ctx {
     float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special;
     unsigned long long* parity;
     int32_t* int_count;
-    unsigned *loss_ticket, *final_ticket;
+    unsigned* final_ticket;
     unsigned long long* knn_inv;
     double* loss_acc;
     int btiles_x;

@@ -17,3 +17,7 @@ python scripts/summarize_pmc.py $(find gpurun_out/prof_fetch gpurun_out/prof_wri
 head -30 gpurun_out/kernel_stats.csv
 cat gpurun_out/pmc_summary.csv
 tail -c 1500 gpurun_out/r01_bench_b1.json
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --images-per-gpu 64 > gpurun_out/r01_bench_b64.json 2>/dev/null
+bash scripts/dev_profile_b16.sh > gpurun_out/profile_b16.log 2>&1
+tail -c 400 gpurun_out/r01_bench_b8.json; tail -c 400 gpurun_out/r01_bench_b32.json; tail -c 400 gpurun_out/r01_bench_b64.json; tail -c 400 gpurun_out/r01_bench_40k.json
+head -8 gpurun_out/kernel_stats_b16.csv
