@@ -447,3 +447,46 @@ def test_deferred_update_graph_replays_equal_plain_stepping(n, monkeypatch):
     ref.step(cfg)
     torch.cuda.synchronize()
     assert gd.adam_t.cpu().tolist() == [2 * n + 1] * 2 and np.allclose(gd.params.cpu().numpy(), ref.params.cpu().numpy(), atol=3e-4)
+
+
+@gpu
+@pytest.mark.parametrize("layout", ["concatenated", "interleaved", "reversed"])
+def test_knn_role_ties_keep_lowest_index(layout):
+    """Duplicated object vertices make every nearest neighbour a tie (knn_points keeps the first minimum, PL:1529-1532):
+    the duplicates sit in different chunks / waves (concatenated, reversed) or in the same selection group (interleaved).
+    Checked for both homes of the key decode: k_knn_decode (vertex stage alone) and the passengers of k_resolve."""
+    from followmyhold_amd import engine as E
+    sc = _np_scene(make_scene("ico3", 64, 64, seed=3))
+    ov, of = sc["obj_verts"], sc["obj_faces"]
+    N = ov.shape[0]
+    if layout == "concatenated":
+        src = np.concatenate([np.arange(N), np.arange(N)])
+    elif layout == "reversed":
+        src = np.concatenate([np.arange(N), np.arange(N)[::-1]])
+    else:
+        src = np.repeat(np.arange(N), 2)
+    first = np.full(N, -1)
+    for j in range(2 * N - 1, -1, -1):
+        first[src[j]] = j                                  # lowest index holding each base vertex
+    second = np.array([np.nonzero(src == i)[0][1] for i in range(N)])
+    sc["obj_verts"] = np.ascontiguousarray(ov[src])
+    sc["obj_faces"] = np.concatenate([first[of], second[of]], 0).astype(of.dtype)
+    gb = E.GuidanceBatch([sc], grid_res=16)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    out = {}
+    for name, stages in (("decode kernel", E.L.STAGE_VERTEX), ("k_resolve", None)):
+        gb.step(cfg) if stages is None else gb.step(cfg, stages=stages)
+        torch.cuda.synchronize()
+        world = gb.region("world", torch.float32, (-1, 3)).cpu().numpy()
+        Vh = gb.meta[0]["Vh"]
+        h, o = world[:Vh], world[Vh:Vh + 2 * N]
+        d = h[:, None, :] - o[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]   # fp32, the kernel's order
+        ref = d2.argmin(1)                                  # first minimum
+        idx = gb.region("knn_idx", torch.int32)[:Vh].cpu().numpy()
+        kd2 = gb.region("knn_d2", torch.float32)[:Vh].cpu().numpy()
+        assert np.array_equal(idx, ref), f"{layout} / {name}: {np.count_nonzero(idx != ref)} indices differ"
+        assert np.array_equal(kd2, d2[np.arange(Vh), ref])
+        assert np.array_equal(idx, first[src[idx]])         # never the later copy
+        out[name] = idx
+    assert np.array_equal(out["decode kernel"], out["k_resolve"])
