@@ -70,8 +70,8 @@ def measured_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--streams", type=int, default=0, help="independent image groups, one HIP stream + hipGraph each "
                     "(0 = auto: min(4, images per GPU))")
@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=0, help="cap on the iterations captured per hipGraph (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=30)
     args = ap.parse_args()
 
     import numpy as np
