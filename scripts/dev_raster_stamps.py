@@ -22,5 +22,5 @@ for m in os.environ.get("MASKS", "0,61").split(","):
         d = lambda i, j: (a[j] - a[i]) / 100.0
         print("mask %s stage2 %.1f us" % (m, t["k_stage2"] * 1e3))
         for nm, o in (("hand", 50), ("obj", 60)):
-            print("   raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f (T=%d candidates)" % (
-                nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), a[o + 8]))
+            print("   raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f [loop %.2f, barrier %.2f, reserve + stores %.2f] (T=%d candidates)" % (
+                nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), d(o + 4, o + 6), d(o + 6, o + 7), d(o + 7, o + 5), a[o + 8]))
