@@ -1,7 +1,7 @@
 set -x
 cd /root/repo
 mkdir -p gpurun_out
-python bench.py --steps 200 --warmup 10 > gpurun_out/r01_bench_b1.json 2> gpurun_out/b1.err
+python bench.py > gpurun_out/r01_bench_b1.json 2> gpurun_out/b1.err
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --images-per-gpu 8 > gpurun_out/r01_bench_b8.json 2>/dev/null
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --images-per-gpu 32 > gpurun_out/r01_bench_b32.json 2>/dev/null
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --obj 40k > gpurun_out/r01_bench_40k.json 2>/dev/null
