@@ -20,12 +20,16 @@ def each_source(directory: str, pattern: str, what: str):
     return [(p, os.path.basename(p).split("_")[0], os.path.splitext(os.path.basename(p))[0]) for p in found]
 
 
-def cli(run_fn, *flags) -> None:
+def build_parser(*flags) -> argparse.ArgumentParser:
     """The stages take only required --<name> directory flags (h2m.py:57-68, mano.py:46-57)."""
     parser = argparse.ArgumentParser()
     for flag in flags:
         parser.add_argument(f"--{flag}", required=True)
-    run_fn(**vars(parser.parse_args()))
+    return parser
+
+
+def cli(run_fn, *flags, argv=None) -> None:
+    run_fn(**vars(build_parser(*flags).parse_args(argv)))
 
 
 def pick_moge_target(moge_dir: str):
@@ -52,8 +56,11 @@ def run(hunyuan_mesh_dir: str, moge_out_dir: str, h2m_rt_dir: str) -> None:
                           transformed_mesh_path=None, **ICP_SETTINGS)
 
 
+FLAGS = ("hunyuan_mesh_dir", "moge_out_dir", "h2m_rt_dir")
+
+
 def main() -> None:
-    cli(run, "hunyuan_mesh_dir", "moge_out_dir", "h2m_rt_dir")
+    cli(run, *FLAGS)
 
 
 if __name__ == "__main__":

@@ -16,8 +16,11 @@ def run(hamer_out_dir: str, hunyuan_mesh_dir: str, aligned_mano_dir: str) -> Non
                           **ICP_SETTINGS)
 
 
+FLAGS = ("hamer_out_dir", "hunyuan_mesh_dir", "aligned_mano_dir")
+
+
 def main() -> None:
-    cli(run, "hamer_out_dir", "hunyuan_mesh_dir", "aligned_mano_dir")
+    cli(run, *FLAGS)
 
 
 if __name__ == "__main__":

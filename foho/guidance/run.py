@@ -4,8 +4,12 @@ reference's src/foho/guidance/run.py; RUN below), with the optimisation-in-the-l
 What is kept from the reference: the nine required flags + --task_list_file (RUN:264-289), `run(**paths)`
 (RUN:188-199), the per-image path derivation from `{index} = filename.split("_")[0]` (RUN:210-222), the skip rules
 (outputs exist RUN:224-226, empty masks RUN:232-236), the per-image try/except-continue (RUN:257-259) and
-`_load_task_list` (RUN:178-185).  Added: when launched under torch.distributed (one process per GPU) every rank
-takes its round-robin share of the image list and rank 0 prints the all-reduced batch metrics.
+`_load_task_list` (RUN:178-185).  Added (the MI355X counterpart of the reference's SLURM array, RUN:178-185): when
+launched as one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m foho.guidance.run ...`) every
+rank binds to GPU LOCAL_RANK, takes its round-robin share of the image list, and at the end of the batch ONE
+all-reduce(SUM) of the metrics vector (followmyhold_amd.sharding.METRIC_NAMES; RCCL over xGMI, "nccl") lets rank 0
+print the batch totals.  There is no collective on the data path.  FOHO_DIST_BACKEND=gloo runs the same code with a
+CPU-side reduce (several ranks on one GPU / no GPU: tests).
 
 `run_hunyuan_w_guid` runs followmyhold_amd.pipeline.GuidedShapePipeline -- the patched Hunyuan pipeline's __call__ with
 the guidance arithmetic on HIP -- over the Hunyuan3D-2 DiT + ShapeVAE (PyTorch networks outside the hot path, SURVEY.md
@@ -17,10 +21,81 @@ import json
 import os
 from typing import Dict, List, Optional
 
+import time
+
 import numpy as np
 
 from followmyhold_amd import sharding
 from foho.configs import OptimizationConfig
+
+# Per-process tally behind the end-of-batch all-reduce: run_hunyuan_w_guid adds the loss terms of every image it
+# finishes (sharding.METRIC_NAMES order), run() adds wall time and failures.
+_METRICS = np.zeros(len(sharding.METRIC_NAMES), np.float64)
+
+
+def _tally(vec) -> None:
+    global _METRICS
+    _METRICS = _METRICS + np.asarray(vec, np.float64)
+
+
+def _dist_setup():
+    """Bind this process to its GPU and join the process group when launched under torch.distributed.
+    Returns (rank, world_size, device string, dist module or None, whether this call created the group)."""
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank if world > 1 else 0))
+    has_gpu = torch.cuda.is_available()
+    backend = os.environ.get("FOHO_DIST_BACKEND", "nccl" if has_gpu else "gloo")
+    device = "cuda"
+    if has_gpu:
+        n = torch.cuda.device_count()
+        if backend == "nccl" and world > 1 and local_rank >= n:
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {n} GPUs are visible: launch one process per GPU")
+        local_rank %= n                      # gloo: several ranks may share one GPU (tests, development)
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+    dist, created = None, False
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            created = True
+    return rank, world, device, dist, created
+
+
+def _reduce_and_report(rank, world, device, dist, created) -> Optional[Dict[str, float]]:
+    """End of batch: all-reduce(SUM) of the metrics vector; rank 0 prints and returns the totals."""
+    import torch
+    on_gpu = dist is not None and dist.get_backend() == "nccl"
+    vec = torch.tensor(_METRICS, dtype=torch.float64, device=device if on_gpu else "cpu")
+    vec = sharding.all_reduce_metrics(vec, dist)
+    out = None
+    if rank == 0:
+        out = dict(zip(sharding.METRIC_NAMES, vec.tolist()))
+        out["world_size"] = world
+        print("Batch metrics: " + json.dumps(out), flush=True)
+    if dist is not None and created:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def _setup_sys_path(project_root: str) -> None:
+    """RUN:57-64: the checkout's third_party trees (Hunyuan3D-2 / hy3dgen, the HaMeR estimator) and the project root
+    become importable -- that is where the DiT / ShapeVAE networks come from when they are installed."""
+    import sys
+    from foho.configs import third_party_root
+    tp = third_party_root()
+    hy3dgen_root = os.path.join(tp, "Hunyuan3D-2")
+    for p in (tp, os.path.join(tp, "estimator"), hy3dgen_root, os.path.join(hy3dgen_root, "hy3dgen"), project_root):
+        if p and p not in sys.path:
+            sys.path.append(p)
 
 
 def derive_paths(cropped_obj_img: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str,
@@ -90,6 +165,9 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
         hamer_for_guid_path=hamer_for_guid_path, aligned_mano_mesh_path=aligned_mano_mesh_path,
         obj_mask_path=cropped_obj_mask_path, hand_mask_path=cropped_hand_mask_path, moge_mesh_path=moge_mesh_path,
         h2m_rt_path=T_h2m_path, hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path)
+    gb = getattr(pipeline, "guidance_batch", None)
+    if out is not None and gb is not None:
+        _tally(sharding.local_metrics(gb, n_steps=int(pipeline.stats["inner_iterations"]), wall_ms=0.0).cpu().numpy())
     obj_mesh, hand_mesh = out       # a None return (NaN in phase B, PL:1442-1444) raises here like in the reference
     try:    # RUN:159-166: floaters, degenerate faces, decimation to 40k faces, export
         from followmyhold_amd import postprocess as pp
@@ -168,15 +246,23 @@ def _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, crop
     scene = inputs.load_scene_from_files(p, inputs.load_j_regressor(), E.hip_render_fn(device))
     scene["fov"] = float(fovx)
     gb = inputs.run_mesh_guidance([scene], config, device=device)
+    n_iter = int(config.optimization_steps_hand) + int(config.optimization_steps_scale) + \
+        int(config.optimization_steps_joint) * max(0, int(config.num_inference_steps) - int(config.guidance_start_step) - 1)
+    _tally(sharding.local_metrics(gb, n_steps=n_iter, wall_ms=0.0).cpu().numpy())
     return inputs.export_meshes(gb, 0, save_path_obj, save_path_hand)
 
 
 def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str, hunyuan_hoi_mesh_dir: str,
         hamer_out_dir: str, h2m_rt_dir: str, aligned_mano_dir: str, guidance_out_dir: str,
-        task_list_file: Optional[str] = None) -> None:
+        task_list_file: Optional[str] = None) -> Optional[Dict[str, float]]:
+    global _METRICS
+    _METRICS = np.zeros(len(sharding.METRIC_NAMES), np.float64)
+    _setup_sys_path(project_root)
+    rank, world, device, dist, created = _dist_setup()
     config = OptimizationConfig()
     os.makedirs(guidance_out_dir, exist_ok=True)
-    assigned_imgs = _load_task_list(task_list_file, cropped_obj_img_dir)
+    assigned_imgs = _load_task_list(task_list_file, cropped_obj_img_dir)   # this rank's share when WORLD_SIZE > 1
+    t_start = time.perf_counter()
     for cropped_obj_img in assigned_imgs:
         try:
             p = derive_paths(cropped_obj_img, cropped_obj_img_dir, mask_dir, moge_out_dir, hunyuan_hoi_mesh_dir,
@@ -196,7 +282,7 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                 aligned_mano_mesh_path=p["aligned_mano_mesh_path"], cropped_obj_mask_path=p["cropped_obj_mask_path"],
                 cropped_hand_mask_path=p["cropped_hand_mask_path"], moge_mesh_path=p["moge_mesh_path"],
                 T_h2m_path=p["T_h2m_path"], hunyuan_hoi_mesh_path=p["hunyuan_hoi_mesh_path"],
-                save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"], config=config)
+                save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"], config=config, device=device)
             if obj_mesh is None or hand_mesh is None:
                 print(f"Error in reconstruction for {index}")
                 continue
@@ -204,16 +290,23 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
         except Exception as e:  # RUN:257-259
             print(f"Error in processing {cropped_obj_img} : {e}")
             continue
+    _tally([0.0] * 12 + [(time.perf_counter() - t_start) * 1e3, 0.0, 0.0])
     print("Finished processing all images")
+    return _reduce_and_report(rank, world, device, dist, created)
 
 
-def main() -> None:
+def build_parser() -> argparse.ArgumentParser:
+    """The reference's command line (RUN:264-289): nine required flags + --task_list_file."""
     parser = argparse.ArgumentParser(description="Hunyuan3D-2 guidance")
     for flag in ["project_root", "cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
                  "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]:
         parser.add_argument(f"--{flag}", required=True)
     parser.add_argument("--task_list_file", default=None)
-    a = parser.parse_args()
+    return parser
+
+
+def main() -> None:
+    a = build_parser().parse_args()
     run(**vars(a))
 
 

@@ -276,6 +276,10 @@ class GuidedShapePipeline:
                             graph.replay()
                         stats["inner_iterations"] += n
                         torch.cuda.synchronize(device)
+                        # the reference has no NaN guard in phase A (PL:1320-1358): a NaN loss there poisons the hand pose;
+                        # here the sticky flag freezes the parameters instead -- say so rather than continue silently
+                        if int(gb.raise_on_flags(strict_k=False)[0]) & 1:
+                            say("Total loss is NaN in the hand-only phase: hand parameters frozen at their last finite value")
                         l = gb.loss_dict(0)
                         say(f"Opt step {n - 1}, loss_2d_kps: {l.get('kps', 0.0)}, total: {l['total']}")
                         param_log.append(("A", i, gb.params[0].detach().clone(), None))

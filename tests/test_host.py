@@ -186,3 +186,80 @@ def test_metrics_all_reduce_world_size_2_gloo(tmp_path):
         exp[13] += n * (r & 1)
         exp[14] += n * (1 if (r & 6) else 0)
     assert np.allclose(got, exp)
+
+
+DRIVER_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+root = sys.argv[2]
+import numpy as np
+from PIL import Image
+from foho.guidance import run as G
+from followmyhold_amd import sharding
+
+seen = []
+def fake_run_hunyuan_w_guid(**kw):      # stands in for the GPU work of one image; same keyword contract as RUN:65-79
+    idx = int(os.path.basename(kw["save_path_obj"]).split("_")[0])
+    assert kw["device"] in ("cuda", "cuda:0", "cuda:1") or kw["device"].startswith("cuda")
+    seen.append(idx)
+    v = np.zeros(len(sharding.METRIC_NAMES)); v[0] = 1; v[1] = 750; v[2] = float(idx)
+    G._tally(v)
+    open(kw["save_path_obj"], "w").write("x"); open(kw["save_path_hand"], "w").write("x")
+    return object(), object()
+G.run_hunyuan_w_guid = fake_run_hunyuan_w_guid
+d = {n: os.path.join(root, n) for n in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                        "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]}
+out = G.run(project_root=root, task_list_file=None, **d)
+print("SEEN", int(os.environ["RANK"]), sorted(seen), flush=True)
+if int(os.environ["RANK"]) == 0:
+    print("TOTALS", json.dumps(out), flush=True)
+else:
+    assert out is None
+"""
+
+
+def test_guidance_driver_world_size_2_gloo(tmp_path):
+    """foho.guidance.run.run() as two ranks (gloo, 127.0.0.1): every rank processes its round-robin share of the image
+    list (the torch.distributed counterpart of the SLURM array, RUN:178-185), the metrics vector is all-reduced once
+    at the end of the batch and rank 0 reports the totals."""
+    from PIL import Image
+    root = tmp_path / "tree"
+    dirs = {n: root / n for n in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                  "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir"]}
+    for p in dirs.values():
+        p.mkdir(parents=True)
+    idxs = [3, 10, 11, 25, 40]
+    for i in idxs:
+        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(dirs["cropped_obj_img_dir"] / f"{i:04d}_cropped_hoi_1.png")
+        m = np.full((8, 8), 255, np.uint8)
+        if i == 25:
+            m[:] = 0                                             # empty hand mask: skipped (RUN:232-236)
+        Image.fromarray(m).save(dirs["mask_dir"] / f"{i:04d}_cropped_hand_mask.png")
+        Image.fromarray(np.full((8, 8), 255, np.uint8)).save(dirs["mask_dir"] / f"{i:04d}_cropped_obj_mask.png")
+        (dirs["moge_out_dir"] / f"{i:04d}_cropped_hoi").mkdir()
+        (dirs["moge_out_dir"] / f"{i:04d}_cropped_hoi" / "fov.json").write_text('{"fov_x": 60.0}')
+    script = tmp_path / "w.py"
+    script.write_text(DRIVER_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FOHO_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(root)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    seen = {}
+    for o in outs:
+        for l in o.splitlines():
+            if l.startswith("SEEN"):
+                seen[int(l.split()[1])] = eval(l.split(None, 2)[2])
+    assert seen == {0: [3, 11, 40], 1: [10]}                    # sorted list [3,10,11,25,40] dealt round-robin; 25 skipped
+    assert "Skipping 0025 due to empty mask" in outs[1]
+    assert sum("Batch metrics:" in o for o in outs) == 1        # rank 0 only
+    import json
+    tot = json.loads([l for l in outs[0].splitlines() if l.startswith("TOTALS")][0][len("TOTALS "):])
+    assert tot["world_size"] == 2 and tot["n_images"] == 4 and tot["n_steps"] == 3000
+    assert tot["sum_total_loss"] == 3 + 11 + 40 + 10 and tot["sum_wall_ms"] > 0
+    for i in [3, 10, 11, 40]:
+        assert (root / "guidance_out_dir" / f"{i:04d}_obj.ply").exists()

@@ -160,3 +160,43 @@ def test_image_mesh_target_render_matches_oracle():
     assert (p_ref >= 0).mean() > 0.7
     assert np.array_equal(p_hip, p_ref)
     assert np.abs(d_hip - d_ref).max() < 1e-5 and np.abs(n_hip - n_ref).max() < 1e-4
+
+
+@gpu
+def test_guidance_driver_under_torchrun_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m foho.guidance.run ...` on a two-image tree (the product
+    driver's N>1 path; RUN:178-185, 208-259): each rank binds a GPU (both share the one GPU of this box, so the
+    metrics all-reduce goes through gloo; on a node with one rank per GPU it is RCCL), writes its image's meshes, and
+    rank 0 prints the all-reduced totals.  Full reference schedule: 200 + 100 + 9 x 50 iterations per image."""
+    import subprocess
+    import sys
+    from followmyhold_amd import engine as E
+    d = _dirs(tmp_path)
+    jr = None
+    for k, idx in enumerate(["0004", "0009"]):
+        sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="ico3", H=96, W=96, seed=20 + k)
+        mv, mf = _gt_mesh(sc)
+        inputs.save_scene_files(sc, mv, mf, {k2: v for k2, v in d.items() if k2 != "guidance_out_dir"}, idx)
+        jr = sc["J_regressor"]
+    jr_path = str(tmp_path / "J.npy")
+    np.save(jr_path, jr)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FOHO_J_REGRESSOR=jr_path, FOHO_MESH_LEVEL_GUIDANCE="1", FOHO_DIST_BACKEND="gloo",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", "-m", "foho.guidance.run", "--project_root", str(tmp_path)]
+    for k, v in d.items():
+        cmd += [f"--{k}", v]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-4000:]
+    for idx in ["0004", "0009"]:
+        for kind in ["obj", "hand"]:
+            v, f = meshio.load_ply(os.path.join(d["guidance_out_dir"], f"{idx}_{kind}.ply"))
+            assert np.isfinite(v).all() and len(f) > 0
+    line = [l for l in r.stdout.splitlines() if "Batch metrics:" in l]
+    assert len(line) == 1, r.stdout[-4000:]
+    tot = json.loads(line[0].split("Batch metrics:", 1)[1])
+    assert tot["world_size"] == 2 and tot["n_images"] == 2 and tot["n_steps"] == 2 * 750
+    assert np.isfinite(tot["sum_total_loss"]) and tot["sum_total_loss"] > 0 and tot["n_nan"] == 0
