@@ -282,7 +282,7 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                 aligned_mano_mesh_path=p["aligned_mano_mesh_path"], cropped_obj_mask_path=p["cropped_obj_mask_path"],
                 cropped_hand_mask_path=p["cropped_hand_mask_path"], moge_mesh_path=p["moge_mesh_path"],
                 T_h2m_path=p["T_h2m_path"], hunyuan_hoi_mesh_path=p["hunyuan_hoi_mesh_path"],
-                save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"], config=config, device=device)
+                save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"], config=config)   # device: "cuda" = the GPU _dist_setup() bound
             if obj_mesh is None or hand_mesh is None:
                 print(f"Error in reconstruction for {index}")
                 continue
