@@ -11,9 +11,17 @@ vector at the end of the batch).
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (hipEvent-timed on the launch
-stream), `cpu_baseline` the CPU oracle ("port" of the reference path) on a bounded sample of the same
-workload.
+Prints ONE JSON line on rank 0.  Besides the contract's fields:
+  roofline            the dominant kernel: algorithmic bytes per launch / hipEvent-timed duration on the launch stream
+  kernels             every launch of the step the same way
+  step_roofline_frac  SURVEY 8(d)'s B_step x steps/s / HBM peak;  step_traffic_frac: the MEASURED bytes per step
+                      (rocprofv3 PMC summary under profiles/) x steps/s / HBM peak
+  parity              first step of the benchmark scene, HIP vs the CPU oracle: loss_rel_err_vs_oracle,
+                      pix_to_face_mismatch (the metric's "loss match vs ref")
+  cpu_baseline        the CPU oracle ("port" of the reference path) on this box's host cores, bounded sample;
+  cpu_baseline_1t     the same with one thread, the reference's own thread policy (src/foho/main.py:65-68)
+  batched             configs[2]'s per-GPU regime: 8 frames per GPU, 4 streams x 2 frames
+  topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
 """
 import argparse
 import json
@@ -25,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
+PMC_CSV = os.path.join("profiles", "r02_rocprofv3_pmc_fetch_write_b1.csv")
+PMC_CSV_FALLBACK = os.path.join("profiles", "r01_rocprofv3_pmc_fetch_write_b1.csv")
 
 
 def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
@@ -32,39 +42,85 @@ def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
     return 206 * H * W + 96 * (Vh + Vo) + 48 * (Fh + Fo) + 12 * Fo
 
 
-# Share of B_step that each kernel of the step touches algorithmically (DESIGN.md "Kernels"); per pixel P,
-# per vertex V, per face F, for the two live renders of phase C.
-def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo):
+def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo, hits=None, grid_res=64):
+    """Compulsory HBM bytes of each launch of the step for the data structures this build uses:
+    every buffer a kernel must read or write counted once.  The G-buffer is HIT-ONLY: face ids exist for every pixel
+    (4 B), depth / edge distance / silhouette product / colour (24 B) only where a face was hit, and the backward pass
+    only opens tiles with a hit.  `hits` = dict(px=[hit pixels of render 0, 1], tile_px=[pixels in hit tiles]) measured
+    on the benchmark scene; without it every pixel is charged.  P pixels, V vertices, F faces; hand faces feed both
+    renders."""
     P, V, F = H * W, Vh + Vo, Fh + Fo
+    px = hits["px"] if hits else [P, P]
+    tpx = hits["tile_px"] if hits else [P, P]
+    G1 = grid_res + 1
+    zeroed = 36 * V + 2 * G1 * G1 * 16                                 # per-step accumulators cleared by k_xform's extra columns
     table = {
-        "k_xform": 36 * V,
-        # vertex normals, KNN, keypoints, edge loss; scatter rasteriser reads the faces' NDC vertices (hand faces feed
-        # both renders); inside test's face pass (ids + vertices)
-        "k_stage2": 48 * V + 60 * F + 12 * Fo + 36 * (Fh + F) + 24 * F,
-        "k_resolve": 2 * 16 * P + 12 * V,                           # write the 16 B/px G-buffer of 2 renders, read normals
-        "k_loss": (2 * 16 + 17) * P,                                # read the G-buffers of 2 renders + the targets (12+4+1 B/px) once
-        "k_pix_bwd": 2 * (16 + 17) * P + 48 * (Fh + F),             # read G-buffer + targets, accumulate 48 B/face x 2 renders
-        "k_vert_bwd": 108 * V + 12 * F,
+        "k_xform": 36 * V + zeroed,                                     # verts_in -> world, ndc
+        # normals (faces via CSR + positions -> raw + unit normals), KNN, keypoints, edge loss; scatter rasteriser (face
+        # ids + NDC gather of every face, hand faces twice; 8-B key per fragment ~ hit pixel); inside test (ids + vertices)
+        "k_stage2": 48 * V + 12 * F + 12 * Fo + 48 * (Fh + F) + 8 * (px[0] + px[1]) + 24 * F,
+        # key plane read + cleared and face id written where a tile was opened; 24 B of planes per hit pixel; normals
+        "k_resolve": (8 + 8 + 4) * (tpx[0] + tpx[1]) + 24 * (px[0] + px[1]) + 12 * V,
+        # face ids of both renders + targets (12 + 4 + 1 B/px) for every pixel, planes of the hit pixels
+        "k_loss": (2 * 4 + 17) * P + 24 * (px[0] + px[1]),
+        # hit tiles only: face ids + targets per tile pixel, planes per hit pixel, 24 B of vertex-gradient atomics per
+        # (face, corner) reached
+        "k_pix_bwd": (4 + 17) * (tpx[0] + tpx[1]) + 24 * (px[0] + px[1]) + 24 * (Fh + F),
+        # per vertex: NDC / normal / direct gradients in, world gradient + grad_verts_in out, positions; per (vertex, face)
+        # pair of the normal backward: the pair record
+        "k_vert_bwd": 108 * V + 8 * 3 * F,
         "k_final": 0,
     }
     return table.get(name)
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_rocprofv3_pmc_fetch_write_b1.csv; FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE reads half of a
-    wide coalesced stream on gfx950 -- MI355X_MICROARCH.md "HBM" -- hence 2 x FETCH + WRITE)."""
-    path = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_fetch_write_b1.csv")
-    if not os.path.exists(path):
-        return None
-    vals = {}
-    for line in open(path).read().splitlines()[1:]:
-        k, cn, _, mean = line.split(",")
-        if k == kernel:
-            vals[cn] = float(mean)
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+def pmc_table():
+    """{kernel: HBM bytes per launch} from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE /
+    WRITE_SIZE are in KiB and FETCH_SIZE reads half of a wide coalesced stream on gfx950 -- MI355X_MICROARCH.md
+    "HBM" -- hence 2 x FETCH + WRITE)."""
+    for rel in (PMC_CSV, PMC_CSV_FALLBACK):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        vals = {}
+        for line in open(path).read().splitlines()[1:]:
+            k, cn, _, mean = line.split(",")
+            vals.setdefault(k, {})[cn] = float(mean)
+        out = {k: (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in vals.items()
+               if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+        return out, rel
+    return {}, None
+
+
+def pick_spg(steps, cap=0):
+    spg = 1
+    for cand in (50, 25, 10, 5):
+        if steps % cand == 0:
+            spg = cand
+            break
+    return min(spg, cap) if cap > 0 else spg
+
+
+def make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=True, joint=False):
+    group = E.GuidanceGroup(scenes, n_streams, device=dev)
+    if graph:
+        group.capture(cfg, joint=joint, steps_per_graph=spg)
+    ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
+
+    def run_steps(n):
+        """Every CFG.joint_iters = 50 iterations the reference starts a new denoising step with a fresh AdamW
+        (PL:1478).  The pose parameters are put back to the scene's start point as well, so that the measured
+        workload stays the configs[1] scene instead of whatever the synthetic optimisation drifts to (with the
+        reference's learning rates the synthetic object shrinks away after ~150 iterations, which would make the
+        rasteriser's job easier than the benchmark claims)."""
+        done = 0
+        while done < n:
+            group.restart(ident)
+            k = min(50, n - done)
+            group.run(cfg, k)
+            done += k
+
+    return group, run_steps
 
 
 def main():
@@ -82,6 +138,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=0, help="cap on the iterations captured per hipGraph (0 = auto)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batched / topology_changing sub-records")
     ap.add_argument("--cpu-steps", type=int, default=30)
     args = ap.parse_args()
 
@@ -121,37 +178,12 @@ def main():
     scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=rank * ipg + j) for j in range(ipg)]
     # measured (8 images: 1 / 2 / 4 / 8 streams = 38 / 48 / 58 / 40 k steps/s): up to four independent groups overlap well
     n_streams = args.streams if args.streams > 0 else min(4, ipg)
-    group = E.GuidanceGroup(scenes, n_streams, device=dev)
-    gb = group.batches[0]
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
     # iterations per hipGraph: the reference's inner loop is 50 iterations per denoising step, and nothing in the step
     # needs the host, so a slice of that loop is ONE graph replay (no host work between iterations)
-    spg = 1
-    if not args.no_graph and not args.joint_graph:
-        for cand in (50, 25, 10, 5):
-            if args.steps % cand == 0:
-                spg = cand
-                break
-        spg = min(spg, args.steps_per_graph) if args.steps_per_graph > 0 else spg
-    if not args.no_graph:
-        group.capture(cfg, joint=args.joint_graph, steps_per_graph=spg)
-    ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
-
-    def new_denoise_step():
-        """Every CFG.joint_iters = 50 iterations the reference starts a new denoising step with a fresh AdamW
-        (PL:1478).  The pose parameters are put back to the scene's start point as well, so that the measured
-        workload stays the configs[1] scene instead of whatever the synthetic optimisation drifts to (with the
-        reference's learning rates the synthetic object shrinks away after ~150 iterations, which would make the
-        rasteriser's job easier than the benchmark claims)."""
-        group.restart(ident)
-
-    def run_steps(n):
-        done = 0
-        while done < n:
-            new_denoise_step()                  # every 50 iterations
-            k = min(50, n - done)
-            group.run(cfg, k)
-            done += k
+    spg = 1 if (args.no_graph or args.joint_graph) else pick_spg(args.steps, args.steps_per_graph)
+    group, run_steps = make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=not args.no_graph, joint=args.joint_graph)
+    gb = group.batches[0]
 
     run_steps(50)            # setup: let clocks / caches settle before the counted warm-up
     torch.cuda.synchronize(dev)
@@ -193,6 +225,7 @@ def main():
     }
 
     if rank == 0:
+        sizes = (H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
         # ---- roofline of the dominant kernel: hipEvents around every launch, averaged over the timed step count
         acc = {}
         nprof = 20
@@ -202,39 +235,129 @@ def main():
         for _ in range(nprof):
             for k, v in gb.step_profiled(cfg_frozen).items():
                 acc[k] = acc.get(k, 0.0) + v / nprof
+        # hit statistics of the profiled scene (the G-buffer is hit-only): hit pixels and pixels of 32x8 tiles with a hit
+        P = H * W
+        p2f = gb.region("p2f", torch.int32, (2, gb.B, H, W))[:, 0]
+        hits = {"px": [int((p2f[r] >= 0).sum()) for r in range(2)], "tile_px": []}
+        for r in range(2):
+            t = (p2f[r] >= 0)[: H // 8 * 8, : W // 32 * 32].reshape(H // 8, 8, W // 32, 32).any(3).any(1)
+            hits["tile_px"].append(int(t.sum()) * 256)
         dom = max(acc, key=lambda k: acc[k])
-        kb = kernel_bytes(dom, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
-        bstep = algorithmic_bytes(H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
+        kb = kernel_bytes(dom, *sizes, hits=hits)
+        bstep = algorithmic_bytes(*sizes)
         if kb is None:
             kb = bstep
         ipb = gb.B               # images in the profiled batch (the first stream's)
         achieved = kb * ipb / (acc[dom] * 1e-3) / 1e9
+        pmc, pmc_src = pmc_table()
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom) if ipg == 1 else None,
-                           "traffic_source": "profiles/r01_rocprofv3_pmc_fetch_write_b1.csv (2*FETCH_SIZE+WRITE_SIZE, KiB)",
-                           "kernel_ms": acc[dom],
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom) if ipg == 1 else None,
+                           "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)", "kernel_ms": acc[dom],
                            "algorithmic_bytes_per_launch": kb * ipb}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
+        out["hit_pixels"] = hits
         out["kernels"] = {}
         for k, v in acc.items():           # every launch of the step against the HBM roofline (algorithmic bytes / duration)
-            kbk = kernel_bytes(k, H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"]) or 0
+            kbk = kernel_bytes(k, *sizes, hits=hits) or 0
             gbs = kbk * ipb / (v * 1e-3) / 1e9
             out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipb / 1e6, 3), "GBs": round(gbs, 1),
-                                 "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                                 "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "traffic_MB": round(pmc[k] / 1e6, 3) if (k in pmc and ipg == 1) else None}
         out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
         out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
+        if ipg == 1 and pmc:
+            step_traffic = sum(pmc.get(k, 0.0) for k in acc)
+            out["step_traffic_MB"] = round(step_traffic / 1e6, 3)
+            out["step_traffic_frac"] = step_traffic * value / world / 1e9 / HBM_PEAK_GBS
 
+        if world == 1 and not args.no_extras:
+            out["batched"] = batched_record(E, torch, synthetic, render_fn, args, dev, cfg)
+            out["topology_changing"] = topology_record(E, torch, scenes[0], dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scenes[0], args.cpu_steps)
+            base, first = cpu_baseline(scenes[0], args.cpu_steps)
+            out["cpu_baseline"] = base
+            out["parity"] = parity_record(E, torch, np, scenes[0], dev, first)
+            out["cpu_baseline_1t"] = cpu_baseline(scenes[0], 5, threads=1, budget_s=20.0)[0]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(scene, n_steps):
+def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, steps=200):
+    """configs[2]'s per-GPU regime (64 frames image-sharded over 8 GPUs = 8 frames per GPU): 4 streams x 2 frames,
+    one hipGraph of 50 iterations per stream."""
+    H = W = args.size
+    scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=100 + j) for j in range(n_img)]
+    group, run_steps = make_runner(E, torch, scenes, 4, dev, cfg, 50)
+    run_steps(100)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run_steps(steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    for g in group.batches:
+        g.raise_on_flags()
+    m = group.batches[0].meta[0]
+    bstep = algorithmic_bytes(H, W, m["Vh"], m["Vo"], m["Fh"], m["Fo"])
+    v = n_img * steps / dt
+    return {"images_per_gpu": n_img, "streams": 4, "steps": steps, "value": v, "unit": "guidance-steps/s",
+            "ms_per_batch_step": dt * 1e3 / steps, "step_roofline_frac": bstep * v / 1e9 / HBM_PEAK_GBS}
+
+
+def topology_record(E, torch, scene, dev, steps=100):
+    """The iteration the guided pipeline actually runs (PL:1507-1601): the object is re-extracted from the SDF every
+    iteration, so its topology changes -- FlexiCubes forward, topology tables, AABB / pair tables, fused step, backward
+    to the SDF.  The SDF here is a sphere whose radius wobbles by iteration (res 64, 512 x 512 targets of `scene`)."""
+    from followmyhold_amd import ops
+    import numpy as np
+    res = 64
+    g = np.linspace(-1.1, 1.1, res + 1, dtype=np.float32)
+    xyz = torch.from_numpy(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)).to(dev)
+    rad = torch.linalg.norm(xyz, dim=1)
+    sc = dict(scene)
+    gb = E.GuidanceBatch([sc], device=dev)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+
+    def one(k):
+        s = (rad - (0.50 + 0.02 * ((k % 7) / 7.0))).requires_grad_(True)
+        v, f, _ = ops.flexicubes(xyz, s, res)
+        loss = gb.objective(v, f, cfg)
+        loss.backward()
+        return int(f.shape[0])
+
+    for k in range(10):
+        nf = one(k)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(k)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt * 1e3 / steps, "steps": steps, "flexicubes_res": res, "faces": nf,
+            "what": "SDF -> FlexiCubes -> topology tables -> fused joint step -> dL/dSDF, new topology every iteration"}
+
+
+def parity_record(E, torch, np, scene, dev, first):
+    """The metric's "loss match vs ref": first joint step of the benchmark scene on the HIP path against the CPU
+    oracle's first step (same start point, before any update)."""
+    gb = E.GuidanceBatch([scene], device=dev)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize(dev)
+    gb.raise_on_flags()
+    P = scene["H"] * scene["W"]
+    p2f = gb.region("p2f", torch.int32, (2, P)).cpu().numpy()
+    mism = int((p2f[0] != first["p2f_hand"]).sum() + (p2f[1] != first["p2f_hoi"]).sum())
+    tot = gb.loss_dict(0)["total"]
+    return {"loss_rel_err_vs_oracle": abs(tot - first["total"]) / abs(first["total"]), "pix_to_face_mismatch": mism,
+            "loss_hip": tot, "loss_oracle": first["total"], "pixels_compared": 2 * P}
+
+
+def cpu_baseline(scene, n_steps, threads=None, budget_s=25.0):
     """The CPU oracle (a port of the reference's PyTorch-CPU path; the reference itself cannot run without
-    pytorch3d/kaolin) timed on this box's host cores on the SAME scene: 1 warm-up + n_steps joint steps."""
+    pytorch3d/kaolin) timed on this box's host cores on the SAME scene: 1 warm-up + n_steps joint steps.
+    Returns (record, first-step results for the parity record)."""
     import torch
     from oracle import clib
     from oracle import step_ref as S
@@ -243,21 +366,23 @@ def cpu_baseline(scene, n_steps):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))  # the oracle stops scaling (and oversubscribes) beyond a few dozen threads
+    cores = threads or max(1, min(avail, 32))  # the oracle stops scaling (and oversubscribes) beyond a few dozen threads
     torch.set_num_threads(cores)
     clib.set_threads(cores)
     st = S.JointStepper(sc, S.make_params(), denoise_i=19)
     t0 = time.perf_counter()
-    st.step()
+    total, _, aux, _ = st.step()
     warm = time.perf_counter() - t0
-    n_steps = max(1, min(n_steps, int(25.0 / max(warm, 1e-3))))  # bound the sample to ~25 s of CPU work
+    first = {"total": float(total), "p2f_hand": aux["hand"]["render"]["sel"]["pix_to_face"].reshape(-1),
+             "p2f_hoi": aux["render"]["sel"]["pix_to_face"].reshape(-1)}
+    n_steps = max(1, min(n_steps, int(budget_s / max(warm, 1e-3))))  # bound the sample to ~budget_s of CPU work
     t0 = time.perf_counter()
     for _ in range(n_steps):
         st.step()
     dt = time.perf_counter() - t0
     return {"value": n_steps / dt, "unit": "guidance-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_steps} joint steps (after 1 warm-up) of the same 512x512 / 20k-face scene, oracle/step_ref.py "
-                      f"with OpenMP C rasteriser + torch CPU autograd"}
+                      f"with OpenMP C rasteriser + torch CPU autograd, {cores} thread(s)"}, first
 
 
 if __name__ == "__main__":

@@ -134,7 +134,7 @@ struct RSlot {
     unsigned pad[11];
 };
 struct RStats {
-    unsigned flags;                   // bit1 frac overflow, bit2 >K fragments on a pixel
+    unsigned flags;                   // bit1 frac overflow, bit2 >K fragments on a pixel, bit3 face across the near plane culled
     unsigned pad[3];
 };
 
@@ -190,7 +190,8 @@ static WS make_ws(const foho_dims& d) {
     w.zkey = take(R * B * P * 8);  // ~(z bits << 32 | face id), atomicMax; 0 = no fragment
     w.fcnt = take(R * B * P * 4);  // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
     w.psum = take(R * B * P * 4);  // sum of (1 - p) over the fractional fragments (exact product for one fragment)
-    w.plog = take(R * B * P * 4);  // sum of log(1 - p) over the fractional fragments (product for several)
+    w.plog = take(R * B * P * 8);  // sum of -log2(1 - p) over the fractional fragments in 2^-40 fixed point (integer atomics:
+                                   // exact, order independent) -> their product
     w.tile_touched = take(R * B * (size_t)w.nbtiles);  // 1 = a face's pixel box overlaps the tile this step (raster setup)
     w.tile_clean = take(R * B * (size_t)w.nbtiles);    // 1 = the tile's p2f entries are known to be all -1
     w.sim_acc = take(2 * B * (size_t)SIM_ACC * 4);     // deferred update: per step parity, the 36 partial sums of the final stage (float atomics)
@@ -290,7 +291,8 @@ struct Ctx {
     float* sim_acc;
     unsigned long long* zkey;
     unsigned* fcnt;
-    float *psum, *plog;
+    float* psum;
+    unsigned long long* plog;
     FracEntry* frac;
     unsigned* frac_count;
     RStats* rstats;

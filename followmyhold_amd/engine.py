@@ -463,12 +463,16 @@ class GuidanceBatch:
 
     def raise_on_flags(self, strict_k=True):
         """bit1: fractional-fragment list overflow, bit2: a pixel holds at least 100 fractional-coverage fragments, the only
-        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones.
+        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones; bit3: a
+        face straddling the near plane z = znear / 2 was culled where pytorch3d's clip_faces would have split it.
         Fails loudly instead of deviating; strict_k=False downgrades bit2 to a warning (a collapsing object -- thousands
         of sub-pixel faces on one pixel -- is outside any regime where the K=100 cut-off is meaningful)."""
         f = self.flags.detach().cpu().numpy()
         if (f & 2).any():
             raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
+        if (f & 8).any():
+            raise L.FohoError("a face crosses the near plane z = znear / 2 (images "
+                              f"{np.flatnonzero(f & 8).tolist()}): near-plane clipping is not implemented")
         if (f & 4).any():
             msg = "a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced"
             if strict_k:

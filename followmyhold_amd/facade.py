@@ -149,8 +149,12 @@ class _RasterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts_ndc, faces, H, W, blur, sigma, want_sil):
         out = ops.raster_fwd(verts_ndc, faces, H, W, blur, sigma, want_sil)
-        if int(out["overflow"].item()) and want_sil:
+        ov = int(out["overflow"].item())
+        if (ov & 4) and want_sil:
             raise ops.L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
+        if ov & 8:      # pytorch3d's clip_faces would split such a face; this rasteriser culls it
+            raise ops.L.FohoError("a face crosses the near plane z = znear / 2: near-plane clipping is not implemented, "
+                                  "keep the meshes in front of the camera")
         ctx.save_for_backward(verts_ndc.detach(), faces, out["pix_to_face"])
         ctx.mark_non_differentiable(out["pix_to_face"])
         prod = out["sil_prod"] if want_sil else torch.zeros(0, device=verts_ndc.device)

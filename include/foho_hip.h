@@ -143,7 +143,8 @@ typedef struct {
     float* losses;                   /* (B,FOHO_N_LOSS)                                              */
     float* grad_params;              /* (B,16)                                                       */
     float* grad_verts_in;            /* (Vtot,3)  dL/d verts_in (object rows are the autograd sink)  */
-    int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel */
+    int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel,
+                                        bit3 a face straddling z = znear/2 was culled instead of clipped       */
     void* workspace;
     size_t workspace_bytes;
 } foho_step_desc;
@@ -192,7 +193,10 @@ const char* foho_kernel_name(int i);
 /* pytorch3d rasterize_meshes(faces_per_pixel=1) on NDC vertices of ONE mesh.
  * verts_ndc (V,3) = (x_ndc, y_ndc, z_view); faces (F,3) int32.  Outputs (H,W): pix_to_face int64
  * (-1 background), zbuf, bary (H,W,3), dists (signed, squared NDC).  sil_prod (H,W) optional:
- * prod_k(1 - sigmoid(-d_k/sigma)) over every fragment of the pixel (SoftSilhouetteShader alpha = 1 - it). */
+ * prod_k(1 - sigmoid(-d_k/sigma)) over every fragment of the pixel (SoftSilhouetteShader alpha = 1 - it).
+ * Near plane (MeshRasterizer's z_clip_value = znear / 2 = 0.005 for the path's camera, RUN:84-105): faces with a vertex
+ * nearer than that are culled; *overflow_flag gets bit2 (4) when the K = 100 cut-off could not be reproduced and
+ * bit3 (8) when a culled face straddled the plane (pytorch3d would have clipped it into sub-triangles). */
 int foho_raster_fwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     float blur_radius, float sigma, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                     float* sil_prod, int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream);

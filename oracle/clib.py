@@ -31,6 +31,19 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
+def set_z_clip(z=0.01 * 0.5):
+    """Near plane of the restated rasteriser (default: znear / 2 of the path's camera); -inf-like values disable it."""
+    lib().foho_oracle_set_z_clip(ctypes.c_float(np.float32(z)))
+
+
+def count_near_clipped(face_verts):
+    """Faces that straddle the near plane: pytorch3d's clip_faces would split them, the restatement culls them."""
+    fv = np.ascontiguousarray(face_verts, dtype=np.float32).reshape(-1, 9)
+    f = lib().foho_oracle_count_near_clipped
+    f.restype = ctypes.c_int64
+    return int(f(_p(fv, ctypes.c_float), ctypes.c_int64(fv.shape[0])))
+
+
 def set_threads(n):
     return int(lib().foho_oracle_set_threads(int(n)))
 

@@ -170,12 +170,36 @@ static inline void kbuf_sort(frag_t* q, int n) { /* stable bubble sort by z */
             }
 }
 
+/* Near plane.  MeshRasterizer passes z_clip_value = znear / 2 to rasterize_meshes for perspective cameras
+ * (raster_settings.z_clip_value is None at reference src/foho/guidance/run.py:95-105; znear = 0.01, run.py:84-90):
+ * clip_faces() removes faces entirely nearer than the plane and SPLITS faces that straddle it.  Restated policy
+ * (SURVEY.md Appendix A.1): any face with a vertex nearer than the plane is culled; straddling faces are counted by
+ * foho_oracle_count_near_clipped() so that callers can tell when pytorch3d would have clipped instead.  The
+ * default is the path's only camera; tests may move or disable (z_clip < -1e30) the plane. */
+static float g_z_clip = 0.01f * 0.5f;
+void foho_oracle_set_z_clip(float z) { g_z_clip = z; }
+float foho_oracle_get_z_clip(void) { return g_z_clip; }
+int64_t foho_oracle_count_near_clipped(const float* face_verts, int64_t F) {
+    int64_t n = 0;
+    for (int64_t f = 0; f < F; f++) {
+        const float* v = face_verts + 9 * f;
+        const float zmin = fminf(fminf(v[2], v[5]), v[8]), zmax = fmaxf(fmaxf(v[2], v[5]), v[8]);
+        if (zmin < g_z_clip && !(zmax < g_z_clip)) n++;
+    }
+    return n;
+}
+
 /* Per-face screen boxes (inflated by sqrt(blur)); used only to skip
- * eval_pixel_face() early -- it re-tests exactly the same box. */
+ * eval_pixel_face() early -- it re-tests exactly the same box.  Near-culled faces get an empty box. */
 static float* make_face_boxes(const float* face_verts, int64_t F, float sqrt_blur) {
     float* box = (float*)malloc(sizeof(float) * 4 * (F > 0 ? F : 1));
     for (int64_t f = 0; f < F; f++) {
         const float* v = face_verts + 9 * f;
+        if (fminf(fminf(v[2], v[5]), v[8]) < g_z_clip) {
+            box[4 * f + 0] = box[4 * f + 2] = 1.0f;
+            box[4 * f + 1] = box[4 * f + 3] = 0.0f;
+            continue;
+        }
         box[4 * f + 0] = fminf(fminf(v[0], v[3]), v[6]) - sqrt_blur;
         box[4 * f + 1] = fmaxf(fmaxf(v[0], v[3]), v[6]) + sqrt_blur;
         box[4 * f + 2] = fminf(fminf(v[1], v[4]), v[7]) - sqrt_blur;

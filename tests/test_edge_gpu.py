@@ -190,8 +190,8 @@ def test_full_size_properties(obj_kind):
 @gpu
 def test_full_size_step_matches_the_oracle():
     """configs[1] itself -- 512x512, 778-vertex hand, 10 242-vertex / 20 480-face object, 65^3 grid -- one joint step against
-    the CPU oracle: face ids, depth and edge distances bit-exact, losses 1e-4, parameter / vertex gradients 1e-3 (the
-    oracle needs a few seconds here; the small-scene tests carry the tighter gradient bound)."""
+    the CPU oracle: face ids, depth and edge distances bit-exact, losses 1e-4, parameter / vertex gradients 5e-4 (the
+    bound of the small scenes; measured 1e-5 here, scripts/dev_traj50.py)."""
     from followmyhold_amd import engine as E
     from oracle import clib
     import os
@@ -225,9 +225,9 @@ def test_full_size_step_matches_the_oracle():
         assert abs(l[a] - float(terms[b])) <= 1e-4 * max(abs(float(terms[b])), 1e-6), (a, l[a], float(terms[b]))
     g = gb.grad_params[0].cpu().numpy()
     gref = np.concatenate([grads[k].numpy().reshape(-1) for k in E.PARAM_NAMES])
-    assert np.linalg.norm(g - gref) <= 1e-3 * np.linalg.norm(gref)
+    assert np.linalg.norm(g - gref) <= 5e-4 * np.linalg.norm(gref)
     gv, gvr = gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()
-    assert np.linalg.norm(gv - gvr) <= 1e-3 * np.linalg.norm(gvr)
+    assert np.linalg.norm(gv - gvr) <= 5e-4 * np.linalg.norm(gvr)
 
 
 def _raster_fwd(ndc, faces, H, W, blur):
@@ -248,6 +248,7 @@ def _raster_fwd(ndc, faces, H, W, blur):
                                 P(pr.data_ptr()), P(ov.data_ptr()), P(ws.data_ptr()), ctypes.c_size_t(nws),
                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "foho_raster_fwd")
     torch.cuda.synchronize()
+    _raster_fwd.flag = int(ov.item())
     return p2f.cpu().numpy(), zb.cpu().numpy(), ba.cpu().numpy(), di.cpu().numpy()
 
 
@@ -256,8 +257,9 @@ def _raster_fwd(ndc, faces, H, W, blur):
 def test_rasteriser_fuzz_bit_exact(seed):
     """Random triangle soups in NDC built to hit the awkward cases together: slivers, sub-pixel and screen-filling faces,
     vertices exactly on pixel centres, faces sharing an edge, coincident faces at the same depth (lowest face id wins),
-    faces straddling the border, faces behind the camera and faces crossing z = 0.  Face ids, depths, barycentric
-    coordinates and signed distances equal the C oracle bit for bit."""
+    faces straddling the border, faces behind the camera, faces crossing z = 0 and faces at the near plane z = znear / 2
+    (entirely nearer: culled like pytorch3d's clip_faces does; straddling: culled and flagged, bit 3).  Face ids, depths,
+    barycentric coordinates and signed distances equal the C oracle bit for bit."""
     from oracle import clib
     from oracle import ref_ops as R
     rng = np.random.default_rng(100 + seed)
@@ -274,7 +276,11 @@ def test_rasteriser_fuzz_bit_exact(seed):
     tri[6, :, 2] = tri[7, :, 2] = 1.5
     tri[7, 0], tri[7, 1] = tri[6, 1], tri[6, 0]                                    # shared edge, equal depth along it
     tri[8, :, 2] = -1.0                                                            # behind the camera
-    tri[9, 0, 2] = -0.2                                                            # crosses z = 0
+    if seed % 4 != 3:
+        tri[9, 0, 2] = -0.2                                                        # crosses z = 0 (and the near plane)
+        tri[12, 1, 2] = 0.004                                                      # in front of the camera, across z = znear / 2
+    tri[13, :, 2] = [0.001, 0.004, 0.0049]                                         # entirely nearer than the near plane
+    tri[14, :, 2] = [0.005, 0.3, 0.4]                                              # touches the plane: kept (strict <)
     tri[10, :, :2] = [[-3, -3], [3, -3], [0, 4]]                                   # covers the whole screen
     tri[10, :, 2] = 2.9
     tri[11, :, :2] *= 1e-3                                                         # far below a pixel
@@ -284,6 +290,9 @@ def test_rasteriser_fuzz_bit_exact(seed):
     ref = clib.render_pass(tri, H, W, blur)
     p2f, zb, ba, di = _raster_fwd(verts, faces, H, W, blur)
     assert np.array_equal(p2f, ref["pix_to_face"].reshape(-1)), np.flatnonzero(p2f != ref["pix_to_face"].reshape(-1))[:10]
+    n_straddle = clib.count_near_clipped(tri)
+    assert n_straddle == (0 if seed % 4 == 3 else 2) and bool(_raster_fwd.flag & 8) == (n_straddle > 0)
+    assert not np.isin(p2f, [8, 13]).any() and (seed % 4 == 3 or not np.isin(p2f, [9, 12]).any())
     hit = p2f >= 0
     assert hit.sum() > 50
     assert np.array_equal(zb, ref["zbuf"].reshape(-1)) and np.array_equal(di, ref["dists"].reshape(-1))

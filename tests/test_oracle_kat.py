@@ -56,6 +56,32 @@ def test_k2_nearest_wins_and_equal_depth_keeps_lower_face_id():
     assert np.all(zb2[both][:, 0] <= zb2[both][:, 1])
 
 
+def test_k2b_near_plane_policy():
+    """MeshRasterizer clips at z = znear / 2 = 0.005 (perspective camera, z_clip_value=None; RUN:84-105).  Restated policy:
+    faces with a vertex nearer than the plane are culled (pytorch3d culls the fully-near ones and splits the
+    straddling ones -- the latter are counted so that callers can flag them); a vertex ON the plane is kept."""
+    H = W = 16
+    xy = [[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]]
+    mk = lambda zs: [[x, y, z] for (x, y), z in zip(xy, zs)]
+    near, straddle, on_plane, far = mk([0.001, 0.002, 0.004]), mk([0.004, 0.3, 0.3]), mk([0.005, 0.3, 0.3]), mk([0.5, 0.5, 0.5])
+    zc = np.float32(0.01) * np.float32(0.5)
+    on_plane[0][2] = float(zc)
+    for fv, visible in [(near, False), (straddle, False), (on_plane, True), (far, True)]:
+        p2f, _, _, _ = clib.rasterize(tri([fv]), H, W, BLUR)
+        assert (p2f >= 0).any() == visible
+    assert clib.count_near_clipped(tri([near, straddle, on_plane, far])) == 1
+    # a culled face in front does not hide the face behind it
+    p2f, zb, _, _ = clib.rasterize(tri([straddle, far]), H, W, BLUR)
+    assert np.all(p2f[p2f >= 0] == 1) and (p2f >= 0).sum() > 20
+    try:        # plane disabled: the plain zmax < 0 / pz < 0 rules of the naive rasteriser remain
+        clib.set_z_clip(-1e30)
+        p2f, _, _, _ = clib.rasterize(tri([straddle]), H, W, BLUR)
+        assert (p2f >= 0).any() and clib.count_near_clipped(tri([straddle])) == 0
+    finally:
+        clib.set_z_clip()
+    assert clib.count_near_clipped(tri([straddle])) == 1
+
+
 def test_k3_pixel_centre_convention_plus_x_is_left_plus_y_is_up():
     """pytorch3d NDC: +X left, +Y up -> a triangle in the x>0, y>0 quadrant lights the TOP-LEFT image quadrant."""
     H = W = 32
