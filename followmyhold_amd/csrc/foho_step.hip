@@ -358,4 +358,5 @@ __device__ __forceinline__ int mesh_argmax(const MeshInfo& mi, int k) { return (
 #include "k_icp.inc"
 #include "k_flexi.inc"
 #include "k_topo.inc"
+#include "k_object.inc"
 #include "mesh_decimate.inc"

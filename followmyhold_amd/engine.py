@@ -170,16 +170,27 @@ class GuidanceBatch:
     moge_normal (H,W,3), moge_disp (H,W), hand_mask (H,W) bool, obj_mask (H,W) bool, fov (deg), H, W.
     """
 
-    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2, topology="auto"):
+    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2, topology="auto", obj_capacity=None):
         """topology: "auto" builds the tables on the device (foho_topology_tables; closed manifold object meshes) and falls
         back to the host builders when the validity flag says so; "host" always uses the numpy builders; "render" builds
-        the incidence lists only (target-map renders need no edge tables)."""
+        the incidence lists only (target-map renders need no edge tables).
+
+        obj_capacity=(verts, faces): CAPACITY MODE (foho_object_update): every image gets that many object vertex / face
+        slots, the actual object of an iteration -- its counts live on the device only -- is installed by
+        `SdfObjective` without a host round trip; the scenes' own obj_verts / obj_faces are ignored."""
         self.lib = L.lib()
         self.device = torch.device(device)
         self.B = B = len(scenes)
         H, W = int(scenes[0]["H"]), int(scenes[0]["W"])
         assert all(int(s["H"]) == H and int(s["W"]) == W for s in scenes), "one image size per batch"
         self.H, self.W = H, W
+        self.obj_capacity = None if obj_capacity is None else (int(obj_capacity[0]), int(obj_capacity[1]))
+        if self.obj_capacity is not None:
+            vcap, fcap = self.obj_capacity
+            if vcap < 1 or fcap < 2:
+                raise ValueError("obj_capacity: at least 1 vertex and 2 faces")
+            scenes = [dict(s, obj_verts=np.zeros((vcap, 3), np.float32), obj_faces=np.zeros((fcap, 3), np.int64)) for s in scenes]
+            topology = "capacity"
         verts, faces, images = [], [], []
         v_off = f_off = 0
         self.meta = []
@@ -220,11 +231,25 @@ class GuidanceBatch:
         for m in self.meta:
             obj_flag[m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]] = 1
         ok = False
-        if topology in ("auto", "render") and self.Ftot > 0:
+        if topology == "capacity":      # tables are (re)built on the device by foho_object_update; sized for the capacity
+            ok = True
+            self.obj_flag = t(obj_flag, torch.uint8)
+            self.inc_off = torch.zeros(self.Vtot + 1, dtype=torch.int32, device=dev)
+            self.inc_fc = torch.zeros(3 * self.Ftot, dtype=torch.int32, device=dev)
+            self.nbr_off, self.nbr_idx = self.inc_off, torch.zeros(3 * self.Ftot, dtype=torch.int32, device=dev)
+            self.obj_counts = torch.zeros(B, 3, dtype=torch.int32, device=dev)           # actual (Vo, Fo, overflow bits)
+            self.obj_faces64 = torch.zeros(B, self.obj_capacity[1], 3, dtype=torch.int64, device=dev)
+            self.lib.foho_object_workspace_bytes.restype = ctypes.c_size_t
+            self.obj_ws = torch.zeros(self.lib.foho_object_workspace_bytes(self.Vtot, self.Ftot), dtype=torch.uint8, device=dev)
+        elif topology in ("auto", "render") and self.Ftot > 0:
             ok = self._device_topology(t(obj_flag, torch.uint8) if topology == "auto" else None)
             if ok and topology == "auto":
                 ok = all(m["Fo"] % 2 == 0 for m in self.meta)
-        if ok:
+        if ok and topology == "capacity":
+            for m, im in zip(self.meta, images):     # no object yet: the records are filled in on the device
+                m.update(Vcap=m["Vo"], Fcap=m["Fo"], Vo=0, Fo=0)
+                im.Vo = im.Fo = im.n_edges = 0
+        elif ok:
             for m, im in zip(self.meta, images):
                 m["n_edges"] = im.n_edges = (3 * m["Fo"] // 2) if topology == "auto" else 0
         else:   # general meshes (boundaries, non-manifold edges): sort-based builders on the host
@@ -264,22 +289,43 @@ class GuidanceBatch:
 
         d = L.FohoDims()
         d.B, d.H, d.W, d.Vtot, d.Ftot = B, H, W, self.Vtot, self.Ftot
-        d.Vmax = max(m["Vh"] + m["Vo"] for m in self.meta)
-        d.Fmax = max(m["Fh"] + m["Fo"] for m in self.meta)
+        d.Vmax = max(m["Vh"] + m.get("Vcap", m["Vo"]) for m in self.meta)
+        d.Fmax = max(m["Fh"] + m.get("Fcap", m["Fo"]) for m in self.meta)
         d.Vh_max = max(m["Vh"] for m in self.meta)
-        d.Vo_max = max(m["Vo"] for m in self.meta)
+        d.Vo_max = max(m.get("Vcap", m["Vo"]) for m in self.meta)
         d.Fh_max = max(m["Fh"] for m in self.meta)
-        d.Fo_max = max(m["Fo"] for m in self.meta)
+        d.Fo_max = max(m.get("Fcap", m["Fo"]) for m in self.meta)
         d.grid_res, d.frac_cap, d.n_renders = grid_res, frac_cap, n_renders
         self.dims = d
         self._alloc_workspace()
+        if self.obj_capacity is not None:
+            self.adopt_objects()        # hands only for now: tables, pair table and AABB of the (still empty) scene
+            self.flags.zero_()          # ... which is not an "empty iso-surface" event (flag bit 6)
 
     # ------------------------------------------------------------------ plumbing
     def _alloc_workspace(self):
         nbytes = int(self.lib.foho_step_workspace_bytes(ctypes.byref(self.dims)))
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._desc = None
-        self._bbox_dirty = True   # the AABB of verts_in lives in the workspace (FOHO_STAGE_BBOX)
+        # the AABB of verts_in lives in the workspace (FOHO_STAGE_BBOX); capacity mode recomputes it in adopt_objects()
+        self._bbox_dirty = getattr(self, "obj_capacity", None) is None
+
+    def adopt_objects(self, stream=None):
+        """Capacity mode: install the object meshes whose vertices sit in the object slots of verts_in, whose mesh-local
+        faces sit in obj_faces64 and whose counts sit in obj_counts (all on the device, as foho_flexi_fwd leaves them):
+        image records, global face ids, topology tables, pair table, AABB.  Asynchronous, no host round trip."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        P = ctypes.c_void_p
+        self.lib.foho_object_update.restype = ctypes.c_int
+        L.check(self.lib.foho_object_update(ctypes.byref(self.desc()), P(self.obj_counts.data_ptr()), P(self.obj_faces64.data_ptr()),
+                                            ctypes.c_int32(self.obj_capacity[1]), P(self.obj_flag.data_ptr()), P(self.obj_ws.data_ptr()),
+                                            ctypes.c_size_t(self.obj_ws.numel()), P(stream)), "foho_object_update")
+
+    def obj_slot(self, b):
+        """(first vertex slot, vertex capacity) of image b's object in verts_in / grad_verts_in."""
+        m = self.meta[b]
+        return m["v_off"] + m["Vh"], m.get("Vcap", m["Vo"])
 
     def set_n_renders(self, n):
         if n != self.dims.n_renders:
@@ -345,8 +391,11 @@ class GuidanceBatch:
         order, unique edges, neighbour lists) are rebuilt on the GPU: by foho_topology_tables (k_topo.inc) for closed
         manifold meshes -- what FlexiCubes emits --, by general torch sorts otherwise; one host read-back (validity flag).
         The next step recomputes the cached AABB and clears the rasteriser's planes (FOHO_STAGE_BBOX)."""
+        if self.obj_capacity is not None:
+            raise L.FohoError("update_object: this batch is in capacity mode (use SdfObjective / adopt_objects)")
         if self.B != 1:
-            raise L.FohoError("update_object: topology updates are implemented for one-image batches")
+            raise L.FohoError("update_object: exact-size topology updates are implemented for one-image batches; capacity mode "
+                              "(obj_capacity=...) handles any batch size")
         dev = self.device
         v = torch.as_tensor(verts, dtype=torch.float32, device=dev).detach().reshape(-1, 3).contiguous()
         f = torch.as_tensor(faces, device=dev).detach().to(torch.int64).reshape(-1, 3)
@@ -473,6 +522,13 @@ class GuidanceBatch:
         if (f & 8).any():
             raise L.FohoError("a face crosses the near plane z = znear / 2 (images "
                               f"{np.flatnonzero(f & 8).tolist()}): near-plane clipping is not implemented")
+        if (f & 16).any():
+            raise L.FohoError(f"object capacity exceeded (images {np.flatnonzero(f & 16).tolist()}): enlarge obj_capacity")
+        if (f & 64).any():
+            raise L.FohoError(f"empty iso-surface (images {np.flatnonzero(f & 64).tolist()}): the iteration was skipped")
+        if (f & 32).any():
+            raise L.FohoError(f"object mesh is not a closed 2-manifold (images {np.flatnonzero(f & 32).tolist()}): the on-device "
+                              "edge tables assume it; use the exact-size path (GuidanceBatch.objective)")
         if (f & 4).any():
             msg = "a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced"
             if strict_k:
@@ -543,6 +599,114 @@ class _ObjectiveFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return ctx.gb.grad_obj_verts(0) * g, None, None, None
+
+
+class SdfObjective:
+    """SDF grid -> FlexiCubes mesh -> one guidance iteration -> dL/dSDF, as ONE hipGraph replay (PL:1507-1601 without the
+    VAE decode).  The reference rebuilds the object mesh from the latent in every iteration of phases B and C, so the
+    object's vertex count, face count and connectivity change every time; here the whole chain -- iso-surfacing
+    (foho_flexi_fwd, 4 launches), installing the new object (foho_object_update, 5 launches: image records, topology
+    tables, pair table, AABB), the fused step (6 launches) and the iso-surface backward (2 launches) -- runs over
+    fixed-capacity buffers with the actual counts in device memory, so it is captured once per step recipe and replayed.
+
+    gb must be a capacity-mode GuidanceBatch (obj_capacity=...); xyz = (res+1)^3 grid positions shared by the batch.
+    `obj(sdf, cfg)` with sdf (B, (res+1)^3) or ((res+1)^3,) returns the total loss per image (autograd: backward() puts
+    dL/dSDF into sdf.grad); `status()` reads back (vertex count, face count, flags) of the last call -- one host sync, only
+    when the caller wants to know (empty mesh, capacity overflow, non-manifold output)."""
+
+    def __init__(self, gb, xyz, res):
+        if gb.obj_capacity is None:
+            raise L.FohoError("SdfObjective needs a capacity-mode GuidanceBatch (obj_capacity=(verts, faces))")
+        self.gb, self.res = gb, int(res)
+        dev = gb.device
+        G = self.res + 1
+        self.xyz = torch.as_tensor(xyz, dtype=torch.float32, device=dev).reshape(-1, 3).contiguous()
+        if self.xyz.shape[0] != G ** 3:
+            raise L.FohoError(f"SdfObjective: expected {G ** 3} grid positions")
+        self.sdf = torch.zeros(gb.B, G ** 3, device=dev)
+        self.grad_sdf = torch.zeros(gb.B, G ** 3, device=dev)
+        lib = gb.lib
+        lib.foho_flexi_workspace_bytes.restype = ctypes.c_size_t
+        self.nws = int(lib.foho_flexi_workspace_bytes(self.res))
+        self.flexi_ws = torch.zeros(gb.B, self.nws, dtype=torch.uint8, device=dev)
+        self._graphs = {}
+        self._stream = torch.cuda.Stream(dev)
+
+    def enqueue(self, cfg):
+        """The launch sequence of one iteration on the current stream (eager; the graph captures exactly this)."""
+        gb, lib, P = self.gb, self.gb.lib, ctypes.c_void_p
+        stream = P(torch.cuda.current_stream(gb.device).cuda_stream)
+        vcap, fcap = gb.obj_capacity
+        for b in range(gb.B):
+            lo, _ = gb.obj_slot(b)
+            L.check(lib.foho_flexi_fwd(P(self.xyz.data_ptr()), P(self.sdf[b].data_ptr()), self.res, P(gb.verts_in[lo:].data_ptr()), vcap,
+                                       P(gb.obj_faces64[b].data_ptr()), fcap, None, P(gb.obj_counts[b].data_ptr()),
+                                       P(self.flexi_ws[b].data_ptr()), ctypes.c_size_t(self.nws), stream), "foho_flexi_fwd")
+        gb.adopt_objects()
+        gb.step(cfg)
+        self.grad_sdf.fill_(0.0)        # a fill kernel (memset nodes inside a captured graph are not reliably ordered on this stack)
+        for b in range(gb.B):
+            lo, _ = gb.obj_slot(b)
+            L.check(lib.foho_flexi_bwd(P(self.xyz.data_ptr()), P(self.sdf[b].data_ptr()), self.res, P(gb.grad_verts_in[lo:].data_ptr()),
+                                       vcap, P(self.grad_sdf[b].data_ptr()), None, P(self.flexi_ws[b].data_ptr()),
+                                       ctypes.c_size_t(self.nws), stream), "foho_flexi_bwd")
+
+    def graph(self, cfg):
+        key = (bytes(cfg), self.gb.workspace.data_ptr())     # a re-allocated workspace (set_n_renders) needs a new capture
+        g = self._graphs.get(key)
+        if g is None:
+            gb = self.gb
+            st = self._stream
+            st.wait_stream(torch.cuda.current_stream(gb.device))
+            state = [t.clone() for t in (gb.params, gb.adam_m, gb.adam_v, gb.adam_t, gb.flags)]
+            with torch.cuda.stream(st):
+                self.enqueue(cfg)           # warm-up outside the capture (module load); its optimiser update is undone
+            torch.cuda.current_stream(gb.device).wait_stream(st)
+            torch.cuda.synchronize(gb.device)
+            for t, saved in zip((gb.params, gb.adam_m, gb.adam_v, gb.adam_t, gb.flags), state):
+                t.copy_(saved)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                self.enqueue(cfg)
+            self._graphs[key] = g
+        return g
+
+    def run(self, sdf, cfg, use_graph=True):
+        """Forward + backward of one iteration for the given SDF values; leaves loss in gb.losses, dL/dSDF in grad_sdf."""
+        self.sdf.copy_(sdf.detach().reshape(self.sdf.shape))
+        if use_graph:
+            self.graph(cfg).replay()
+        else:
+            self.enqueue(cfg)
+
+    def __call__(self, sdf, cfg, use_graph=True):
+        return _SdfObjectiveFn.apply(sdf, self, cfg, use_graph)
+
+    def status(self):
+        """[(n_verts, n_faces, flags)] per image of the last run (one host synchronisation)."""
+        c = self.gb.obj_counts.cpu().numpy()
+        f = self.gb.flags.cpu().numpy()
+        return [(int(c[b, 0]), int(c[b, 1]), int(f[b])) for b in range(self.gb.B)]
+
+    def mesh(self, b=0):
+        """(verts (Vo,3), faces (Fo,3) int64 mesh-local) of image b's current object (host sync for the counts)."""
+        nv, nf, _ = self.status()[b]
+        lo, _ = self.gb.obj_slot(b)
+        return self.gb.verts_in[lo:lo + nv].clone(), self.gb.obj_faces64[b, :nf].clone()
+
+
+class _SdfObjectiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, obj, cfg, use_graph):
+        obj.run(sdf, cfg, use_graph)
+        ctx.obj, ctx.shape = obj, sdf.shape
+        out = obj.gb.losses[:, 0].clone()
+        return out[0] if sdf.dim() == 1 else out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = ctx.obj.grad_sdf * g.reshape(-1, 1)
+        return gs.reshape(ctx.shape), None, None, None
 
 
 class GuidanceGroup:

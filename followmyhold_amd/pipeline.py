@@ -212,6 +212,23 @@ class GuidedShapePipeline:
             sdf = latent2sdf(x1, xyz, gsz, self.vae, device, num_chunks)
             return ops.flexicubes(xyz, sdf[0].flatten(), res)
 
+        # Phases B and C re-extract the object from the latent in every iteration (PL:1391-1393, 1507-1509): vertex count,
+        # face count and connectivity change each time.  Fast path: engine.SdfObjective -- iso-surfacing, installing the new
+        # object, the fused step and the backward to the SDF as one hipGraph replay over capacity-sized buffers, the counts
+        # staying on the device.  Iterations it cannot serve (capacity exceeded, a surface that is not a closed manifold)
+        # are redone on the exact-size path (ops.flexicubes + GuidanceBatch.objective), which handles any mesh.
+        fast = {"gb": None, "obj": None, "cap": (0, 0)}
+
+        def fast_objective(cap):
+            if fast["gb"] is None or fast["cap"] != cap:
+                g2 = E.GuidanceBatch([scene], device=device, grid_res=guid_res, n_renders=2, obj_capacity=cap)
+                fast.update(gb=g2, obj=E.SdfObjective(g2, xyz_samples, guid_res), cap=cap)
+            return fast["gb"], fast["obj"]
+
+        def sync_state(src, dst):       # pose parameters and optimiser moments travel with the iteration
+            for name in ("params", "adam_m", "adam_v", "adam_t", "flags"):
+                getattr(dst, name).copy_(getattr(src, name))
+
         def latent_phase(phase, iters, i, t, noise_pred, lr, nan_returns_none):
             """Phases B / C (PL:1362-1453 / 1456-1601): `iters` iterations of decode -> fused step -> AdamW."""
             cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
@@ -219,27 +236,55 @@ class GuidedShapePipeline:
             gb.reset_optimizer()
             noise_pred = noise_pred.clone().detach().requires_grad_(True)
             opt = torch.optim.AdamW([{"params": [noise_pred], "lr": lr}], eps=1e-4)
+            use_fast = os.environ.get("FOHO_EXACT_SIZE_OBJECTIVE") != "1"
+            cap = fast["cap"] if fast["cap"][0] else (8 * guid_res * guid_res, 16 * guid_res * guid_res)
             for k in range(int(iters)):
                 opt.zero_grad()
-                verts, faces, _ = decode_mesh(noise_pred, t, obj_latents, guid_res, xyz_samples, grid_size)
-                if verts.shape[0] == 0:
-                    print("Invalid mesh detected, aborting step!")
-                    stats["skipped_empty"] += 1
-                    continue
-                loss = gb.objective(verts, faces, cfg)
+                x1 = self.scheduler.step_final(noise_pred, t, obj_latents)
+                sdf = latent2sdf(x1, xyz_samples, grid_size, self.vae, device, num_chunks)[0].flatten()
+                loss, cur = None, gb
+                if use_fast:
+                    g2, fobj = fast_objective(cap)
+                    g2.set_n_renders(n_renders)
+                    sync_state(gb, g2)
+                    loss = fobj(sdf, cfg)
+                    nv, nf, fl = fobj.status()[0]          # one read-back per iteration (the reference's NaN test is one, too)
+                    if fl & 64:                            # empty iso-surface (PL:1394-1397, 1511-1513)
+                        print("Invalid mesh detected, aborting step!")
+                        stats["skipped_empty"] += 1
+                        continue
+                    if fl & 16:                            # larger than the capacity: grow it, this iteration goes the exact way
+                        cap = (max(cap[0], 2 * nv), max(cap[1], 2 * nf))
+                        stats["capacity_grown"] = stats.get("capacity_grown", 0) + 1
+                    if fl & 48:
+                        loss = None
+                    else:
+                        cur = g2
+                if loss is None:
+                    verts, faces, _ = ops.flexicubes(xyz_samples, sdf, guid_res)
+                    if verts.shape[0] == 0:
+                        print("Invalid mesh detected, aborting step!")
+                        stats["skipped_empty"] += 1
+                        continue
+                    loss = gb.objective(verts, faces, cfg)
+                    stats["exact_size_iterations"] = stats.get("exact_size_iterations", 0) + 1
                 stats["inner_iterations"] += 1
                 if torch.isnan(loss):
                     print("Total loss is NaN")
+                    if cur is not gb:
+                        sync_state(cur, gb)
                     if nan_returns_none:
                         return None
                     break
                 if k % 10 == 0:
-                    l = gb.loss_dict(0)
+                    l = cur.loss_dict(0)
                     loss_log.append((phase, i, k, l))
                     say(f"Opt step {k}, object loss: {l['edge']}, loss_intersection: {l.get('intersection', 0.0)}, "
                         f"total: {l['total']}")
                 loss.backward()
                 opt.step()
+                if cur is not gb:
+                    sync_state(cur, gb)
             gb.raise_on_flags(strict_k=False)
             param_log.append((phase, i, gb.params[0].detach().clone(), noise_pred.detach().clone()))
             if on_phase_end is not None:

@@ -144,7 +144,8 @@ typedef struct {
     float* grad_params;              /* (B,16)                                                       */
     float* grad_verts_in;            /* (Vtot,3)  dL/d verts_in (object rows are the autograd sink)  */
     int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel,
-                                        bit3 a face straddling z = znear/2 was culled instead of clipped       */
+                                        bit3 a face straddling z = znear/2 was culled instead of clipped,
+                                        bit4 / bit5: capacity mode, see foho_object_update                      */
     void* workspace;
     size_t workspace_bytes;
 } foho_step_desc;
@@ -288,6 +289,28 @@ int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* gra
 size_t foho_topology_workspace_bytes(int32_t V);
 int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8_t* obj_flag, int32_t* inc_off, int32_t* inc_fc,
                          int32_t* nbr_idx, int32_t* flag, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- capacity mode: a new object mesh (new vertex / face counts, new connectivity) every iteration without a host
+ * round trip -- what phases B and C of the reference do 550 times per image (pipelines.py:1391-1393, 1507-1509: decode
+ * the latent, extract the iso-surface, build a fresh Meshes object).  The caller sizes every buffer of the step for a
+ * per-image CAPACITY: dims.Vo_max / dims.Fo_max object vertices / faces per image, images[b].v_off / f_off strided
+ * accordingly, inc_off with Vtot + 1 entries and nbr_off == inc_off (neighbour lists share the incidence offsets), and
+ * lets foho_flexi_fwd write image b's vertices straight into verts_in + 3 * (images[b].v_off + images[b].Vh).
+ * foho_object_update then, reading the ACTUAL counts from device memory (`counts`: B x 3 int32 as foho_flexi_fwd leaves
+ * them), (1) stores Vo / Fo / n_edges = 3 Fo / 2 in the device-resident images[b] -- every kernel of the step takes its
+ * bounds from there --, (2) converts obj_faces (B, faces_cap, 3) int64 mesh-local ids into int32 global ids behind the
+ * hand's faces, (3) rebuilds the topology tables (foho_topology_tables semantics) and the (vertex, face) pair table,
+ * (4) recomputes the AABB of the input meshes (centre of the similarity transform, PL:111).  5 launches, no host sync,
+ * fixed addresses: foho_flexi_fwd -> foho_object_update -> foho_step_run(FOHO_STAGE_STEP) -> foho_flexi_bwd can be
+ * captured in one hipGraph.  flags[b] bit6 (64): the iso-surface is empty (the reference skips such an iteration,
+ * PL:1511-1513), bit4 (16): capacity overflow (the object is left empty for that step), bit5 (32):
+ * the object is not a closed, consistently oriented 2-manifold or a valence exceeds 48 (the edge tables assume it; the
+ * caller must fall back to exact-size tables built by a general sort).  While any of these three bits is set the
+ * step computes losses and gradients but leaves parameters and optimiser state alone; the caller clears the bits once
+ * it has dealt with them.  obj_flag (Vtot bytes): 1 = object vertex slot. */
+size_t foho_object_workspace_bytes(int32_t Vtot, int32_t Ftot);   /* zero-fill it before the first use */
+int foho_object_update(const foho_step_desc* desc, const int32_t* counts, const int64_t* obj_faces, int32_t faces_cap,
+                       const uint8_t* obj_flag, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- mesh post-processing after the pipeline ------------------------------------------
  * `obj_mesh = FaceReducer()(obj_mesh)` (src/foho/guidance/run.py:163): hy3dgen's pymeshlab quadric edge-collapse

@@ -292,3 +292,131 @@ def test_topology_tables_fuzz_on_flexicubes_meshes(seed):
     gb.step(cfg)
     torch.cuda.synchronize()
     assert np.isfinite(gb.loss_dict(0)["total"]) and np.isfinite(gb.grad_obj_verts(0).cpu().numpy()).all()
+
+
+def _chain_scene(seed=0):
+    from helpers import make_scene
+    sc = make_scene("ico2", 64, 64, seed=seed)
+    res = 14
+    x = FR.construct_voxel_grid(res)[0] * 0.24
+    r0 = float(sc["obj_verts"].norm(dim=1).mean())
+    s0 = x.norm(dim=1) - r0 * (1.0 + 0.15 * torch.sin(25 * x[:, 0]) * torch.cos(21 * x[:, 1]))
+    npsc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+    return sc, npsc, x, s0, res
+
+
+@gpu
+def test_capacity_mode_objective_matches_the_oracle_chain_and_the_exact_size_path():
+    """engine.SdfObjective: the whole iteration (SDF -> FlexiCubes -> install the new object on the device -> fused step ->
+    dL/dSDF) as one hipGraph replay over capacity-sized buffers, counts in device memory.  Against the oracle chain
+    (flexi_ref -> step_ref.phase_c_loss -> autograd) and against the exact-size path (ops.flexicubes + gb.objective) for
+    a sequence of SDFs whose meshes differ in vertex count, face count and connectivity; graph replay == eager launches."""
+    from followmyhold_amd import engine as E, ops
+    from oracle import ref_ops as R
+    from oracle import step_ref as S
+    sc, npsc, x, s0, res = _chain_scene()
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb = E.GuidanceBatch([npsc], grid_res=16, obj_capacity=(2048, 4096))
+    obj = E.SdfObjective(gb, x, res)
+    exact = E.GuidanceBatch([npsc], grid_res=16)
+    p = S.make_params()
+    sizes = set()
+    for k, shift in enumerate([0.0, -0.01, 0.012, -0.004]):
+        s = s0 + shift
+        # oracle chain
+        so = s.clone().requires_grad_(True)
+        V, F, _ = FR.flexicubes(x, so, res)
+        total, terms, aux = S.phase_c_loss(dict(sc, obj_faces=F), p, V, R.unique_edges(F), denoise_i=19, grid_res=16)
+        total.backward()
+        # capacity mode, graph replay
+        sg = s.cuda().requires_grad_(True)
+        loss = obj(sg, cfg)
+        loss.backward()
+        torch.cuda.synchronize()
+        nv, nf, flags = obj.status()[0]
+        assert flags == 0 and nv == len(V) and nf == len(F)
+        sizes.add((nv, nf))
+        v_cap, f_cap = obj.mesh(0)
+        assert torch.equal(f_cap.cpu(), F) and torch.equal(v_cap.cpu(), V.detach())
+        assert abs(float(loss) - float(total)) <= 1e-4 * abs(float(total))
+        l = gb.loss_dict(0)
+        assert abs(l["edge"] - float(terms["edge"])) <= 1e-4 * abs(float(terms["edge"])) and int(l["n_intersect"]) == aux["n_int"]
+        g, go = sg.grad.cpu().numpy(), so.grad.numpy()
+        assert np.linalg.norm(g - go) <= 2e-3 * np.linalg.norm(go)
+        # exact-size path: same face ids, same loss terms, same gradient
+        se = s.cuda().requires_grad_(True)
+        ve, fe, _ = ops.flexicubes(x.cuda(), se, res)
+        exact.objective(ve, fe, cfg).backward()
+        torch.cuda.synchronize()
+        P_ = 64 * 64
+        pa = gb.region("p2f", torch.int32, (2, P_)).cpu().numpy()
+        pe = exact.region("p2f", torch.int32, (2, P_)).cpu().numpy()
+        assert np.array_equal(pa, pe)
+        assert np.allclose(gb.losses.cpu().numpy(), exact.losses.cpu().numpy(), rtol=1e-6, atol=1e-9)
+        ge = se.grad.cpu().numpy()
+        assert np.linalg.norm(g - ge) <= 1e-4 * np.linalg.norm(ge)
+        # eager launches of the same sequence
+        s2 = s.cuda().requires_grad_(True)
+        obj(s2, cfg, use_graph=False).backward()
+        torch.cuda.synchronize()
+        assert np.linalg.norm(s2.grad.cpu().numpy() - g) <= 1e-5 * np.linalg.norm(g)
+    assert len(sizes) == 4                                  # four different topologies went through the same graph
+
+
+@gpu
+def test_capacity_mode_batch_of_two_and_updates():
+    """B = 2 in capacity mode (the exact-size path is limited to one image): every image gets the result of its own
+    single-image run, with the optimiser update applied (parameters move, object counts differ per image)."""
+    from followmyhold_amd import engine as E
+    _, sc0, x, s0, res = _chain_scene(0)
+    _, sc1, _, s1, _ = _chain_scene(5)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    sdfs = [s0, s1 + 0.006]
+    singles = []
+    for scn, s in zip([sc0, sc1], sdfs):
+        gb = E.GuidanceBatch([scn], grid_res=16, obj_capacity=(2048, 4096))
+        o = E.SdfObjective(gb, x, res)
+        for _ in range(2):
+            o.run(s.cuda(), cfg)
+        torch.cuda.synchronize()
+        singles.append((gb.losses[0].cpu().numpy(), gb.params[0].cpu().numpy(), o.grad_sdf[0].cpu().numpy(), o.status()[0]))
+    gb = E.GuidanceBatch([sc0, sc1], grid_res=16, obj_capacity=(2048, 4096))
+    o = E.SdfObjective(gb, x, res)
+    for _ in range(2):
+        o.run(torch.stack(sdfs).cuda(), cfg)
+    torch.cuda.synchronize()
+    st = o.status()
+    assert st[0][:2] != st[1][:2]
+    for b in range(2):
+        assert st[b] == singles[b][3] and st[b][2] == 0
+        assert np.allclose(gb.losses[b].cpu().numpy(), singles[b][0], rtol=1e-5, atol=1e-7)
+        assert np.allclose(gb.params[b].cpu().numpy(), singles[b][1], rtol=1e-5, atol=1e-7)
+        gs = o.grad_sdf[b].cpu().numpy()
+        assert np.linalg.norm(gs - singles[b][2]) <= 1e-4 * np.linalg.norm(singles[b][2])
+
+
+@gpu
+def test_capacity_mode_flags_overflow_and_open_surfaces():
+    """The two situations capacity mode cannot serve are reported, not hidden: a mesh larger than the capacity (flag
+    bit 4; the object is left out of that step) and an iso-surface that leaves the grid, i.e. is not closed (bit 5)."""
+    from followmyhold_amd import engine as E
+    _, npsc, x, s0, res = _chain_scene()
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gb = E.GuidanceBatch([npsc], grid_res=16, obj_capacity=(64, 128))
+    o = E.SdfObjective(gb, x, res)
+    o.run(s0.cuda(), cfg)
+    nv, nf, flags = o.status()[0]
+    assert flags & 16 and nv > 64
+    with pytest.raises(E.L.FohoError, match="capacity"):
+        gb.raise_on_flags()
+    gb = E.GuidanceBatch([npsc], grid_res=16, obj_capacity=(4096, 8192))
+    o = E.SdfObjective(gb, x, res)
+    s_open = x[:, 0] - 0.05                                  # a plane: the surface runs out of the grid -> boundary edges
+    o.run(s_open.cuda(), cfg)
+    nv, nf, flags = o.status()[0]
+    assert nf > 0 and flags & 32 and not flags & 16
+    with pytest.raises(E.L.FohoError, match="manifold"):
+        gb.raise_on_flags()
+    gb.flags.zero_()
+    o.run(s0.cuda(), cfg)                                    # the next closed surface is served again
+    assert o.status()[0][2] == 0
