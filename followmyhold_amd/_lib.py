@@ -59,7 +59,7 @@ class FohoStepDesc(ctypes.Structure):
 FACES_HAND, FACES_OBJ, FACES_ALL = 0, 1, 2
 MASK_NONE, MASK_HAND, MASK_OBJ, MASK_HOI = 0, 1, 2, 3
 STAGE_VERTEX, STAGE_RASTER, STAGE_LOSS, STAGE_BACKWARD, STAGE_INSIDE, STAGE_FINAL, STAGE_BBOX = 1, 2, 4, 8, 16, 32, 64
-STAGE_STEP, STAGE_ALL = 63, 127
+STAGE_STEP, STAGE_ALL, STAGE_TARGETS = 63, 127, 256
 N_LOSS = 24
 LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_obj", "verts_obj", "edge", "normal0",
               "disp0", "sil0", "normal1", "disp1", "sil1", "n_intersect", "w_int", "mean_d2"]

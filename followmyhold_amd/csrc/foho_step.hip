@@ -150,6 +150,7 @@ struct WS {
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
     size_t g_ndc, g_nrm, g_world, g_direct;
     size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc;
+    size_t tile_static, image_static;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -169,6 +170,9 @@ static WS make_ws(const foho_dims& d) {
         return r;
     };
     const int G1 = d.grid_res + 1;
+    // --- static with the targets (FOHO_STAGE_TARGETS); first, so that their place does not move with the mesh sizes ---
+    w.tile_static = take(B * (size_t)w.nbtiles * 12 * 4);  // loss contributions of the target maps per tile (k_loss.inc)
+    w.image_static = take(B * 12 * 8);                     // ... and per image (double)
     // --- zeroed every step (atomic accumulators) ---
     w.zero_begin = o;
     w.frac_count = take(R * B * 4);
@@ -306,6 +310,8 @@ struct Ctx {
     unsigned* final_ticket;
     unsigned long long* knn_inv;
     double* loss_acc;
+    float* tile_static;
+    double* image_static;
     int btiles_x;
 };
 

@@ -309,6 +309,7 @@ class GuidanceBatch:
         self._desc = None
         # the AABB of verts_in lives in the workspace (FOHO_STAGE_BBOX); capacity mode recomputes it in adopt_objects()
         self._bbox_dirty = getattr(self, "obj_capacity", None) is None
+        self._targets_dirty = True   # ... and so do the static loss sums of the target maps (FOHO_STAGE_TARGETS)
 
     def adopt_objects(self, stream=None):
         """Capacity mode: install the object meshes whose vertices sit in the object slots of verts_in, whose mesh-local
@@ -430,6 +431,7 @@ class GuidanceBatch:
         need = int(self.lib.foho_step_workspace_bytes(ctypes.byref(d)))
         if need > self.workspace.numel():
             self.workspace = torch.zeros(int(need * 1.25), dtype=torch.uint8, device=dev)   # head-room: sizes drift slowly
+            self._targets_dirty = True
         self._desc = None
         self._bbox_dirty = True     # the workspace layout moved with the sizes: AABB + clean scatter planes again
 
@@ -503,6 +505,9 @@ class GuidanceBatch:
         if self._bbox_dirty and (stages & L.STAGE_VERTEX):
             stages |= L.STAGE_BBOX
             self._bbox_dirty = False
+        if self._targets_dirty and (stages & L.STAGE_LOSS):
+            stages |= L.STAGE_TARGETS
+            self._targets_dirty = False
         L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(stages), ctypes.c_void_p(stream)),
                 "foho_step_run")
 
@@ -578,6 +583,8 @@ class GuidanceBatch:
         lib = self.lib
         if self._bbox_dirty:
             self.refresh_bbox()
+        if self._targets_dirty:
+            self.step(cfg, stages=0)     # FOHO_STAGE_TARGETS only
         lib.foho_step_run_profiled.restype = ctypes.c_int
         lib.foho_kernel_name.restype = ctypes.c_char_p
         ms = (ctypes.c_float * L.N_KERNELS)()

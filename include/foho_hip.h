@@ -166,7 +166,11 @@ enum {
                                         the topology: needed once per workspace and again whenever the caller
                                         rewrites verts_in, faces or the incidence tables                         */
     FOHO_STAGE_STEP = 63,            /* one optimisation step with a cached AABB                               */
-    FOHO_STAGE_ALL = 127
+    FOHO_STAGE_ALL = 127,
+    FOHO_STAGE_TARGETS = 256         /* per-tile / per-image sums of the TARGET maps (tgt_disp, mask) in the workspace: the
+                                        loss pass only visits tiles with a hit and takes the rest from these.  Needed once
+                                        per workspace before the first FOHO_STAGE_LOSS, and again when the caller rewrites
+                                        tgt_normal / tgt_disp / mask                                               */
 };
 
 /* named workspace regions, for parity tests that inspect intermediates */
