@@ -86,9 +86,30 @@ extern "C" void foho_debug_clear(void) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
 }
 extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 1024 * 8); }
+// KSPAN(k): device-side span of a launch -- every workgroup stores its own start / end stamp (plain stores, own slots);
+// foho_debug_spans() copies the table: [kernel][workgroup][2], KS_WG workgroups per kernel
+constexpr int KS_K = 6, KS_WG = 8192;
+__device__ unsigned long long g_span[KS_K * KS_WG * 2];
+struct KSpan {
+    unsigned long long* p;
+    __device__ __forceinline__ explicit KSpan(int k) {
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        p = &g_span[((size_t)k * KS_WG + (lin < KS_WG ? lin : KS_WG - 1)) * 2];
+        if (threadIdx.x == 0) p[0] = wall_clock64();
+    }
+    __device__ __forceinline__ ~KSpan() {
+        if (threadIdx.x == 0) p[1] = wall_clock64();
+    }
+};
+extern "C" void foho_debug_spans(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(g_span)); }
+extern "C" void foho_debug_spans_clear(void) { (void)hipMemset((void*)nullptr, 0, 0); void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(g_span)); (void)hipMemset(d, 0, sizeof(g_span)); }
+#define KSPAN(k) KSpan kspan_(k)
 #else
 #define DBG(i) \
     do {       \
+    } while (0)
+#define KSPAN(k) \
+    do {         \
     } while (0)
 #endif
 
@@ -109,7 +130,8 @@ constexpr int SIM_ROWS_MAX = VERT_BLOCKS_MAX * (256 / VB);  // partial rows per 
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
 constexpr int SIM_ACC = 40;            // floats per image and parity in the deferred-update accumulators (36 used)
 constexpr int STATE_NEXT = 64;         // floats per image in the deferred-update staging area
-constexpr int PIX_BWD_TILE_BLOCKS = 256;  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
+constexpr int PIX_BWD_TILE_BLOCKS = 256;
+constexpr int BWD_SPLIT = 4;             // a dense 32x8 tile is handed to k_pix_bwd as up to 4 bands of pixel rows  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
 constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
@@ -144,7 +166,7 @@ struct RStats {
 struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
-    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
+    size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, bwd_list, bwd_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, rstats, rslot, loss_part, stats2;
@@ -177,6 +199,7 @@ static WS make_ws(const foho_dims& d) {
     w.zero_begin = o;
     w.frac_count = take(R * B * 4);
     w.hit_count = take(R * B * 4);  // tiles with at least one hit pixel, per (render, image)
+    w.bwd_count = take(R * B * 4);  // entries of the backward pass's work list (a dense tile is split into up to 4 entries)
     w.rstats = take(R * B * sizeof(RStats));
     w.rslot = take(R * B * NSLOT * sizeof(RSlot));
     w.g_world = take(V3);
@@ -215,7 +238,8 @@ static WS make_ws(const foho_dims& d) {
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
     w.prod = take(R * B * P * 4);
-    w.hit_list = take(R * B * (size_t)w.nbtiles * 4);  // ids of those tiles (k_resolve appends, k_pix_bwd walks the list)
+    w.hit_list = take(R * B * (size_t)w.nbtiles * 4);  // ids of those tiles (k_resolve appends, k_loss walks the list)
+    w.bwd_list = take(R * B * (size_t)w.nbtiles * BWD_SPLIT * 4);  // tile | part << 16 | parts << 20 (k_resolve appends, k_pix_bwd walks it)
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
@@ -288,6 +312,8 @@ struct Ctx {
     float *zbuf, *sdist, *prod, *pcol;
     int* hit_list;
     unsigned* hit_count;
+    int* bwd_list;
+    unsigned* bwd_count;
     uint8_t *tile_touched, *tile_clean;
     int4* pair_v;
     int* pending;
