@@ -175,12 +175,14 @@ def test_ragged_batch_matches_single_image_runs():
     singles = []
     for s in scs:
         gb = E.GuidanceBatch([s], grid_res=16)
-        for _ in range(3):
+        for _ in range(2):      # two iterations: the second one runs on updated parameters (longer runs let atomic-sum noise reach
+                                # the discontinuities of the silhouette BCE, see test_fullsize_gpu._clamp_flips)
             gb.step(cfg)
         torch.cuda.synchronize()
         singles.append((gb.losses[0].cpu().numpy(), gb.params[0].cpu().numpy(), gb.region("p2f", torch.int32).cpu().numpy()))
     gb = E.GuidanceBatch(scs, grid_res=16)
-    for _ in range(3):
+    for _ in range(2):      # two iterations: the second one runs on updated parameters (longer runs let atomic-sum noise reach
+                                # the discontinuities of the silhouette BCE, see test_fullsize_gpu._clamp_flips)
         gb.step(cfg)
     torch.cuda.synchronize()
     gb.raise_on_flags()
@@ -418,6 +420,10 @@ def test_deferred_update_graph_replays_equal_plain_stepping(n, monkeypatch):
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
     for q in range(16):
         cfg.lr[q] *= 0.05          # short Adam steps: atomic-sum noise cannot grow into visible differences over 2 n iterations
+    # ... and no silhouette term: its BCE is discontinuous where 1 - alpha rounds to 0 (a jump of 84 in one pixel's loss and of
+    # 6e4 x in its gradient, tests/test_fullsize_gpu.py::_clamp_flips), so 1e-7 of atomic-sum noise in the parameters can move a
+    # whole trajectory -- this test is about the plumbing of the deferred update, not about that term
+    cfg.render[1].w_sil = 0.0
     ref = E.GuidanceBatch(scenes, grid_res=16)
     for _ in range(2 * n):
         ref.step(cfg)
