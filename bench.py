@@ -101,8 +101,8 @@ def pick_spg(steps, cap=0):
     return min(spg, cap) if cap > 0 else spg
 
 
-def make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=True, joint=False):
-    group = E.GuidanceGroup(scenes, n_streams, device=dev)
+def make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=True, joint=False, **kw):
+    group = E.GuidanceGroup(scenes, n_streams, device=dev, **kw)
     if graph:
         group.capture(cfg, joint=joint, steps_per_graph=spg)
     ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batched / topology_changing sub-records")
     ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--gbuf-f16", action="store_true", help="depth / colour planes of the G-buffer in fp16 (configs[4])")
     args = ap.parse_args()
 
     import numpy as np
@@ -182,7 +183,8 @@ def main():
     # iterations per hipGraph: the reference's inner loop is 50 iterations per denoising step, and nothing in the step
     # needs the host, so a slice of that loop is ONE graph replay (no host work between iterations)
     spg = 1 if (args.no_graph or args.joint_graph) else pick_spg(args.steps, args.steps_per_graph)
-    group, run_steps = make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=not args.no_graph, joint=args.joint_graph)
+    group, run_steps = make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=not args.no_graph, joint=args.joint_graph,
+                                   gbuf_f16=args.gbuf_f16)
     gb = group.batches[0]
 
     run_steps(50)            # setup: let clocks / caches settle before the counted warm-up
@@ -215,7 +217,8 @@ def main():
     out = {
         "metric": "guidance-steps/sec (512x512, 778+20k verts)", "value": value, "unit": "guidance-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.gbuf_f16 else "f32 (G-buffer f16)",
+        "data": "synthetic",
         "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
                                f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
@@ -272,6 +275,7 @@ def main():
 
         if world == 1 and not args.no_extras:
             out["batched"] = batched_record(E, torch, synthetic, render_fn, args, dev, cfg)
+            out["batched_f16_gbuffer"] = batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)
             out["topology_changing"] = topology_record(E, torch, scenes[0], dev)
         if world == 1 and not args.no_cpu_baseline:
             base, first = cpu_baseline(scenes[0], args.cpu_steps)
@@ -284,12 +288,13 @@ def main():
         dist.destroy_process_group()
 
 
-def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, steps=200):
+def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, steps=200, gbuf_f16=False):
     """configs[2]'s per-GPU regime (64 frames image-sharded over 8 GPUs = 8 frames per GPU): 4 streams x 2 frames,
-    one hipGraph of 50 iterations per stream."""
+    one hipGraph of 50 iterations per stream.  gbuf_f16: configs[4]'s numeric regime (8-image batch, fp16 G-buffer planes,
+    fp32 accumulation)."""
     H = W = args.size
     scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=100 + j) for j in range(n_img)]
-    group, run_steps = make_runner(E, torch, scenes, 4, dev, cfg, 50)
+    group, run_steps = make_runner(E, torch, scenes, 4, dev, cfg, 50, gbuf_f16=gbuf_f16)
     run_steps(100)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -301,7 +306,7 @@ def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, step
     m = group.batches[0].meta[0]
     bstep = algorithmic_bytes(H, W, m["Vh"], m["Vo"], m["Fh"], m["Fo"])
     v = n_img * steps / dt
-    return {"images_per_gpu": n_img, "streams": 4, "steps": steps, "value": v, "unit": "guidance-steps/s",
+    return {"images_per_gpu": n_img, "streams": 4, "steps": steps, "gbuf_f16": bool(gbuf_f16), "value": v, "unit": "guidance-steps/s",
             "ms_per_batch_step": dt * 1e3 / steps, "step_roofline_frac": bstep * v / 1e9 / HBM_PEAK_GBS}
 
 

@@ -8,9 +8,12 @@ stays on the host is file IO, the initial transform and the surface sampling.
 
 Differences that are deliberate:
   * trimesh / pyvista are not available on the MI355X image: meshes are loaded by followmyhold_amd.meshio
-    (.ply / .obj), `plot=True` and `on_surface=True` raise NotImplementedError.
-  * `trimesh.sample.sample_surface_even` is unseeded in the reference (ICP:79, ICP:85); here it is restated with
-    a seedable generator (`seed` keyword, default 0) so runs are reproducible.
+    (.ply / .obj); `plot=True` raises NotImplementedError.  `on_surface=True` IS implemented (closest point on the
+    target triangles, `foho_icp_run_surface`).
+  * `trimesh.sample.sample_surface_even` is unseeded in the reference (ICP:79, ICP:85), so its results differ from run
+    to run; here it is restated with a seedable generator and the runs are reproducible: `icp(..., seed=)`, the
+    keyword-only `seed` of `align_meshes_impl` (coarse stage: seed, fine stage: seed + 1), the CLI's `--seed` and
+    $FOHO_ICP_SEED (default 0; a negative value draws a fresh seed from the OS like the reference does).
 """
 import time
 from typing import Optional
@@ -194,9 +197,15 @@ def icp(source_mesh: Mesh, target_mesh: Mesh, n_iter, count_source=5_000, count_
 
 def align_meshes_impl(source_mesh_path, target_mesh_path, transform_path, transformed_mesh_path, fixed_scale, outliers,
                       test_rotations, test_reflections, on_surface, iterations_coarse, count_source_coarse,
-                      count_target_coarse, iterations_fine, count_source_fine, count_target_fine, min_scale, max_scale, plot):
+                      count_target_coarse, iterations_fine, count_source_fine, count_target_fine, min_scale, max_scale, plot,
+                      *, seed: Optional[int] = None):
     """ICP:178-217: init transform, coarse ICP, fine ICP; writes the 4x4 transform (np.save appends '.npy') and/or the
-    transformed source mesh."""
+    transformed source mesh.  The 18 positional parameters are the reference's; `seed` (keyword only, default
+    $FOHO_ICP_SEED or 0, negative = unseeded) fixes the surface sampling."""
+    import os
+    if seed is None:
+        seed = int(os.environ.get("FOHO_ICP_SEED", "0"))
+    seed_c, seed_f = (None, None) if seed < 0 else (seed, seed + 1)
     t0 = time.time()
     source_mesh, target_mesh = load(source_mesh_path), load(target_mesh_path)
     init_transform = compute_init_transform(source_mesh, target_mesh, fixed_scale)
@@ -204,11 +213,11 @@ def align_meshes_impl(source_mesh_path, target_mesh_path, transform_path, transf
     transform_coarse, _ = icp(source_mesh, target_mesh, n_iter=iterations_coarse, count_source=count_source_coarse,
                               count_target=count_target_coarse, test_reflections=test_reflections,
                               test_rotations=test_rotations, fixed_scale=fixed_scale, outliers=outliers,
-                              on_surface=on_surface, min_scale=min_scale, max_scale=max_scale, plot=plot)
+                              on_surface=on_surface, min_scale=min_scale, max_scale=max_scale, plot=plot, seed=seed_c)
     source_mesh.apply_transform(transform_coarse)
     transform_fine, _ = icp(source_mesh, target_mesh, n_iter=iterations_fine, count_source=count_source_fine,
                             count_target=count_target_fine, outliers=outliers, on_surface=on_surface, min_scale=min_scale,
-                            max_scale=max_scale, plot=plot, seed=1)
+                            max_scale=max_scale, plot=plot, seed=seed_f)
     source_mesh.apply_transform(transform_fine)
     final_transform = transform_fine @ transform_coarse @ init_transform
     if transform_path is not None:
@@ -244,11 +253,13 @@ def main(argv=None):
     ap.add_argument("-mis", "--min_scale", type=float, default=0.7)
     ap.add_argument("-mas", "--max_scale", type=float, default=3.0)
     ap.add_argument("-p", "--plot", action="store_true")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the surface sampling (not in the reference, whose sampling "
+                    "is unseeded; default $FOHO_ICP_SEED or 0, negative = unseeded)")
     a = ap.parse_args(argv)
     align_meshes_impl(a.source_mesh_path, a.target_mesh_path, a.transform_path, a.transformed_mesh_path, a.fixed_scale,
                       a.outliers, a.test_rotations, a.test_reflections, a.on_surface, a.iterations_coarse,
                       a.count_source_coarse, a.count_target_coarse, a.iterations_fine, a.count_source_fine,
-                      a.count_target_fine, a.min_scale, a.max_scale, a.plot)
+                      a.count_target_fine, a.min_scale, a.max_scale, a.plot, **({} if a.seed is None else {"seed": a.seed}))
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ class FohoImage(ctypes.Structure):
 class FohoDims(ctypes.Structure):
     _fields_ = [("B", c_i), ("H", c_i), ("W", c_i), ("Vtot", c_i), ("Ftot", c_i), ("Vmax", c_i), ("Fmax", c_i),
                 ("Vh_max", c_i), ("Vo_max", c_i), ("grid_res", c_i), ("frac_cap", c_i), ("n_renders", c_i),
-                ("Fh_max", c_i), ("Fo_max", c_i)]
+                ("Fh_max", c_i), ("Fo_max", c_i), ("gbuf_f16", c_i)]
 
 
 class FohoRenderCfg(ctypes.Structure):

@@ -25,6 +25,7 @@
 // between steps) and a G-buffer (face id i32 for every pixel; z, signed dist, silhouette product, colour for
 // hit pixels only).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -346,6 +347,36 @@ __device__ __forceinline__ foho_render_cfg pick_render(const foho_render_cfg (&r
     foho_render_cfg o = rr[0];
     if (r != 0) o = rr[1];
     return o;
+}
+
+// ---- G-buffer planes of the hit pixels: depth and face colour, fp32 or (dims.gbuf_f16, BASELINE configs[4]) fp16 ----
+// Selection (face ids, the z keys) and every sum stay fp32; with gbuf_f16 the stored depth and colour are rounded to half
+// precision ONCE, in k_resolve, before the render's extrema are taken, so that the loss and backward passes -- which
+// convert back to fp32 -- see exactly the values the extrema were computed from (their `== max` tie tests stay exact).
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half(x)); }
+__device__ __forceinline__ void gbuf_store(const Ctx& c, size_t pi, float z, const float* col) {
+    if (c.d.gbuf_f16) {
+        __half* zh = reinterpret_cast<__half*>(c.zbuf);
+        __half* ch = reinterpret_cast<__half*>(c.pcol);
+        zh[pi] = __float2half(z);
+        if (col)
+            for (int k = 0; k < 3; k++) ch[3 * pi + k] = __float2half(col[k]);
+    } else {
+        c.zbuf[pi] = z;
+        if (col)
+            for (int k = 0; k < 3; k++) c.pcol[3 * pi + k] = col[k];
+    }
+}
+__device__ __forceinline__ void gbuf_load(const Ctx& c, size_t pi, float& z, float* col) {
+    if (c.d.gbuf_f16) {
+        const __half* zh = reinterpret_cast<const __half*>(c.zbuf);
+        const __half* ch = reinterpret_cast<const __half*>(c.pcol);
+        z = __half2float(zh[pi]);
+        for (int k = 0; k < 3; k++) col[k] = __half2float(ch[3 * pi + k]);
+    } else {
+        z = c.zbuf[pi];
+        for (int k = 0; k < 3; k++) col[k] = c.pcol[3 * pi + k];
+    }
 }
 
 __device__ __forceinline__ void face_range(const foho_image& im, int face_set, int& f0, int& f1) {

@@ -170,14 +170,18 @@ class GuidanceBatch:
     moge_normal (H,W,3), moge_disp (H,W), hand_mask (H,W) bool, obj_mask (H,W) bool, fov (deg), H, W.
     """
 
-    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2, topology="auto", obj_capacity=None):
+    def __init__(self, scenes, device="cuda", grid_res=64, frac_cap=1 << 18, n_renders=2, topology="auto", obj_capacity=None,
+                 gbuf_f16=False):
         """topology: "auto" builds the tables on the device (foho_topology_tables; closed manifold object meshes) and falls
         back to the host builders when the validity flag says so; "host" always uses the numpy builders; "render" builds
         the incidence lists only (target-map renders need no edge tables).
 
         obj_capacity=(verts, faces): CAPACITY MODE (foho_object_update): every image gets that many object vertex / face
         slots, the actual object of an iteration -- its counts live on the device only -- is installed by
-        `SdfObjective` without a host round trip; the scenes' own obj_verts / obj_faces are ignored."""
+        `SdfObjective` without a host round trip; the scenes' own obj_verts / obj_faces are ignored.
+
+        gbuf_f16: store the depth and colour planes of the G-buffer in half precision (BASELINE configs[4]); face ids, edge
+        distances, silhouette products and every accumulation stay fp32."""
         self.lib = L.lib()
         self.device = torch.device(device)
         self.B = B = len(scenes)
@@ -296,6 +300,7 @@ class GuidanceBatch:
         d.Fh_max = max(m["Fh"] for m in self.meta)
         d.Fo_max = max(m.get("Fcap", m["Fo"]) for m in self.meta)
         d.grid_res, d.frac_cap, d.n_renders = grid_res, frac_cap, n_renders
+        d.gbuf_f16 = int(bool(gbuf_f16))     # BASELINE configs[4]: depth / colour planes of the G-buffer in fp16, sums in fp32
         self.dims = d
         self._alloc_workspace()
         if self.obj_capacity is not None:
@@ -807,6 +812,37 @@ class GuidanceGroup:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+
+
+def normal_map(gb, face_set, r=0, b=0, sigma=1e-8):
+    """(H, W, 3) normal map of render r of image b as render_normal_and_disparity returns it (PL:272-289), read back from
+    the G-buffer the last step left (face ids, edge distances, vertex normals) -- debug dumps only."""
+    P = gb.H * gb.W
+    R = gb.dims.n_renders
+    m = gb.meta[b]
+    p2f = gb.region("p2f", torch.int32, (R, gb.B, P))[r, b].long()
+    sd = gb.region("sdist", torch.float32, (R, gb.B, P))[r, b]
+    vn = gb.region("vn", torch.float32, (-1, 3))
+    hit = p2f >= 0
+    f0 = m["f_off"] + (m["Fh"] if face_set == L.FACES_OBJ else 0)
+    f = gb.faces.long()[(p2f.clamp(min=0) + f0).clamp(max=gb.faces.shape[0] - 1)]
+    col = vn[f].sum(1)
+    p = torch.sigmoid(-torch.where(hit, sd, torch.zeros_like(sd)) / sigma)
+    rgb = torch.where(hit[:, None], (p[:, None] * col + 1e-10) / (p[:, None] + 1e-10), torch.ones_like(col))
+    nn = (rgb - rgb.min()) / (rgb.max() - rgb.min() + 1e-6)
+    return torch.where(hit[:, None], nn, torch.zeros_like(nn)).reshape(gb.H, gb.W, 3).cpu().numpy()
+
+
+def save_grid(img1, img2, path):
+    """plot_in_grid of the reference (PL:189-201) without matplotlib: the two (H, W, 3) maps side by side, values clipped to
+    [0, 1] like imshow does, at native resolution with an 8-pixel white gutter (no axes, no resampling)."""
+    from PIL import Image
+    a, b = (np.clip(np.asarray(x, np.float32), 0.0, 1.0) for x in (img1, img2))
+    H = max(a.shape[0], b.shape[0])
+    out = np.ones((H, a.shape[1] + 8 + b.shape[1], 3), np.float32)
+    out[:a.shape[0], :a.shape[1]] = a
+    out[:b.shape[0], a.shape[1] + 8:] = b
+    Image.fromarray((out * 255.0 + 0.5).astype(np.uint8)).save(path)
 
 
 def hip_render_fn(device="cuda"):

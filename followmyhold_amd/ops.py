@@ -242,6 +242,7 @@ class _FlexiFn(torch.autograd.Function):
         ctx.save_for_backward(xx, ss)
         ctx.res, ctx.ws, ctx.nv = res, ws, nv
         ctx.need_x = x.requires_grad
+        ctx.s_meta, ctx.x_meta = (s.shape, s.dtype), (x.shape, x.dtype)
         f_out, l_out = faces[:nf], ldev[:nv]
         ctx.mark_non_differentiable(f_out, l_out)
         return verts[:nv], f_out, l_out
@@ -256,6 +257,10 @@ class _FlexiFn(torch.autograd.Function):
         L.check(lib.foho_flexi_bwd(P(xx.data_ptr()), P(ss.data_ptr()), ctx.res, P(g.data_ptr()), ctx.nv, P(gs.data_ptr()),
                                    P(gx.data_ptr()) if gx is not None else None, P(ctx.ws.data_ptr()),
                                    ctypes.c_size_t(ctx.ws.numel()), _stream(xx)), "foho_flexi_bwd")
+        # gradients in the shape and dtype the caller's tensors have (a (G,G,G) or half-precision SDF is a legal input)
+        gs = gs.view(ctx.s_meta[0]).to(ctx.s_meta[1])
+        if gx is not None:
+            gx = gx.view(ctx.x_meta[0]).to(ctx.x_meta[1])
         return gx, gs, None, None, None
 
 

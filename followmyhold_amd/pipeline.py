@@ -277,6 +277,9 @@ class GuidedShapePipeline:
                         return None
                     break
                 if k % 10 == 0:
+                    if debug_root and phase == "B":     # PL:1417-1419
+                        E.save_grid(E.normal_map(cur, E.L.FACES_OBJ), scene["moge_normal"] * np.asarray(scene["obj_mask"], np.float32)[..., None],
+                                    os.path.join(save_dir, f"rendered_obj_normal_t{i}_opt{k}.png"))
                     l = cur.loss_dict(0)
                     loss_log.append((phase, i, k, l))
                     say(f"Opt step {k}, object loss: {l['edge']}, loss_intersection: {l.get('intersection', 0.0)}, "
@@ -310,6 +313,8 @@ class GuidedShapePipeline:
                         gb.reset_optimizer()
                         n = int(cfg0.optimization_steps_hand)
                         spg = max([d for d in range(1, 51) if n % d == 0]) if n > 0 else 1
+                        if debug_root and n % 10 == 0:
+                            spg = 10        # the reference plots the rendered hand normals every 10 iterations (PL:1331-1333)
                         graph = gb.capture(cfg, steps_per_graph=spg)
                         # capture() ran one iteration from the current parameters and put the optimiser state back: what it
                         # left in gb.losses are the k = 0 losses the reference prints (PL:1351-1355)
@@ -317,7 +322,12 @@ class GuidedShapePipeline:
                         loss_log.append(("A", i, 0, l0))
                         say(f"Opt step 0, loss_2d_kps: {l0['kps']}, loss_normal_hand: {l0['normal0']}, loss_disp_hand: {l0['disp0']}")
                         gb.reset_optimizer()
-                        for _ in range(n // spg):
+                        cfg_eval, _ = E.phase_cfg("A", cfg0, denoise_i=i, do_update=False)
+                        for rep in range(n // spg):
+                            if debug_root and spg == 10:    # the render iteration k = 10 rep starts from
+                                gb.step(cfg_eval)
+                                E.save_grid(E.normal_map(gb, E.L.FACES_HAND), scene["moge_normal"],
+                                            os.path.join(save_dir, f"rendered_normal_hand_t{i}_opt{10 * rep}.png"))
                             graph.replay()
                         stats["inner_iterations"] += n
                         torch.cuda.synchronize(device)
@@ -365,6 +375,14 @@ class GuidedShapePipeline:
                 tex_h = torch.zeros_like(hand_now)
                 tex_h[:, 1] = 1.0
                 hand_out = Meshes(verts=[hand_now], faces=[hand_faces], textures=TexturesVertex(verts_features=[tex_h]))
+            if debug_root:      # PL:1664-1667: the scene of this denoising step against the MoGe normals
+                if i >= handopt_start_step:
+                    dv = torch.cat([hand_now, obj_world], 0)
+                    df = torch.cat([hand_faces, faces + hand_now.shape[0]], 0)
+                else:
+                    dv, df = obj_world, faces
+                dn, _, _ = E.hip_render_fn(device)(dv.detach().cpu().numpy(), df.cpu().numpy(), gb.H, gb.W, scene["fov"])
+                E.save_grid(dn, scene["moge_normal"], os.path.join(save_dir, f"rendered_normal_t{i}.png"))
             if debug_root and i in (14, num_inference_steps - 1):
                 from . import meshio
                 tag = "final" if i == num_inference_steps - 1 else f"guidance_step_{i}"

@@ -78,6 +78,8 @@ typedef struct {
     int32_t frac_cap;        /* capacity of the fractional-coverage fragment list per render     */
     int32_t n_renders;       /* 1 (phase A/B) or 2 (phase C)                                     */
     int32_t Fh_max, Fo_max;  /* largest per-image hand / object face count (0 = unknown: Fmax is used) */
+    int32_t gbuf_f16;        /* 1: depth and colour planes of the G-buffer in fp16 (BASELINE configs[4]: "fp16 rasterizer +
+                                fp32 loss accumulate"); face selection, edge distances and all sums stay fp32        */
 } foho_dims;
 
 /* ---- one render = one mesh through renderer + sil_renderer --------------------------------- */

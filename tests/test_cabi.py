@@ -82,10 +82,10 @@ def test_struct_layouts_match_the_header():
     """ctypes mirrors must have the C sizes (4-byte fields, 8-byte pointers, natural alignment)."""
     from followmyhold_amd import _lib as L
     assert ctypes.sizeof(L.FohoImage) == 8 * 4 + 2 * 4 + 9 * 4 + 3 * 4 + 2 * 4 + 12 * 4
-    assert ctypes.sizeof(L.FohoDims) == 14 * 4
+    assert ctypes.sizeof(L.FohoDims) == 15 * 4
     assert ctypes.sizeof(L.FohoRenderCfg) == 7 * 4
     assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4
-    assert ctypes.sizeof(L.FohoStepDesc) == 56 + 21 * 8 + 8
+    assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

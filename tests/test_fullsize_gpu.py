@@ -314,6 +314,56 @@ def test_config1_fifty_steps_track_the_oracle():
 
 
 @gpu
+def test_config4_fp16_gbuffer_with_fp32_accumulation():
+    """configs[4]'s numeric regime ("fp16 rasterizer + fp32 loss accumulate", 8-image batch): depth and colour planes of the
+    G-buffer in half precision (GuidanceBatch(gbuf_f16=True) -> foho_dims.gbuf_f16), selection / edge distances / sums in
+    fp32.  Against the fp32 oracle on the configs[1] scene: face ids bit-exact (selection never sees fp16), the stored depth
+    = the oracle's depth rounded to half, loss terms within 2e-3 (half has 11 significant bits: 5e-4 per value), gradients
+    within 2e-2; and every frame of an 8-frame fp16 batch equals its own single-frame fp16 run."""
+    from followmyhold_amd import engine as E
+    _threads()
+    scs = [_scene("20k", seed=s) for s in range(8)]
+    sc = scs[0]
+    p = _perturbed()
+    st = S.JointStepper(_t(sc), p, denoise_i=19, grid_res=64)
+    total, terms, aux, grads = st.step(update=False)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+    gh = E.GuidanceBatch([sc], gbuf_f16=True)
+    gh.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    gh.step(cfg)
+    torch.cuda.synchronize()
+    gh.raise_on_flags()
+    p2f = gh.region("p2f", torch.int32, (2, P)).cpu().numpy()
+    for r, ren in enumerate([aux["hand"]["render"], aux["render"]]):
+        ref = ren["sel"]["pix_to_face"].reshape(-1)
+        hit = ref >= 0
+        assert np.array_equal(p2f[r], ref)
+        zh = gh.region("zbuf", torch.float16).reshape(-1)[: 2 * P].reshape(2, P)[r].cpu().numpy()    # first half of the fp32 plane
+        assert np.array_equal(zh[hit], ren["sel"]["zbuf"].reshape(-1)[hit].astype(np.float16))
+        sd = gh.region("sdist", torch.float32, (2, P))[r].cpu().numpy()
+        assert np.array_equal(sd[hit], ren["sel"]["dists"].reshape(-1)[hit])                            # edge distances stay fp32
+    l = gh.loss_dict(0)
+    for a, b in [("normal1", "normal_hoi"), ("disp1", "disp_hoi"), ("sil1", "sil_hoi"), ("normal0", "normal_hand"), ("disp0", "disp_hand"),
+                 ("contact", "contact"), ("edge", "edge")]:
+        assert abs(l[a] - float(terms[b])) <= 2e-3 * max(abs(float(terms[b])), 1e-6), (a, l[a], float(terms[b]))
+    assert abs(l["total"] - float(total)) <= 2e-3 * abs(float(total)) and l["total"] != float(total)
+    assert l["sil1"] == pytest.approx(float(terms["sil_hoi"]), rel=1e-6)            # no fp16 value enters the silhouette term
+    _check_grads(E, gh, grads, tol=2e-2)
+    # batch of 8 in fp16 == singles in fp16
+    cfgu, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    gb = E.GuidanceBatch(scs, gbuf_f16=True)
+    gb.step(cfgu)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    for b in (0, 3, 7):
+        g1 = E.GuidanceBatch([scs[b]], gbuf_f16=True)
+        g1.step(cfgu)
+        torch.cuda.synchronize()
+        assert np.allclose(g1.losses[0].cpu().numpy(), gb.losses[b].cpu().numpy(), rtol=1e-6, atol=1e-9)
+        assert np.allclose(g1.params[0].cpu().numpy(), gb.params[b].cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@gpu
 def test_near_plane_flag_in_the_fused_step():
     """A face across z = znear / 2 is culled and reported (flag bit 3): the object pushed onto the camera."""
     from followmyhold_amd import engine as E

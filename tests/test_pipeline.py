@@ -180,6 +180,14 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
     dbg = [os.path.join(r, f) for r, _, fs in os.walk(str(tmp_path / "debug")) for f in fs]
     assert any(f.endswith("params.json") for f in dbg) and any(f.endswith("final_obj_mesh.ply") for f in dbg)
     assert "Joint optimization step 4" in open([f for f in dbg if f.endswith("losses.txt")][0]).read()
+    # the grids of rendered against target normals (plot_in_grid, PL:189-201, 1331-1333, 1417-1419, 1664-1667), as PNG files:
+    # phase A every 10 iterations (10 iterations here -> opt0), phase B at k = 0, one per denoising step
+    names = sorted(os.path.basename(f) for f in dbg if f.endswith(".png"))
+    assert names == ["rendered_normal_hand_t1_opt0.png", "rendered_normal_t0.png", "rendered_normal_t1.png", "rendered_normal_t2.png",
+                     "rendered_normal_t3.png", "rendered_normal_t4.png", "rendered_obj_normal_t2_opt0.png"], names
+    g = np.asarray(Image.open([f for f in dbg if f.endswith("rendered_normal_t4.png")][0]))
+    Hs = sc["H"]
+    assert g.shape == (Hs, 2 * sc["W"] + 8, 3) and (g[:, :sc["W"]] > 0).any() and (g[:, sc["W"] + 8:] > 0).any()
     # the gradient reaches the latent: with the latent's learning rates at zero the decoded object differs
     monkeypatch.delenv("FOHO_DEBUG_DIR")
     obj0, _ = run(_short_config(noise_lr=0.0))
