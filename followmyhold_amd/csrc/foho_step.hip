@@ -120,6 +120,7 @@ extern "C" void foho_debug_spans_clear(void) { (void)hipMemset((void*)nullptr, 0
 constexpr int BTX = 32, BTY = 8;      // pixel tile of k_resolve / k_pix_bwd (one pixel per lane; 32 px = one 128-B line of a 4-B plane)
 constexpr int RF = 64;                // faces per workgroup of the scatter rasteriser (= one wave for the setup scan)
 constexpr int RQ_CAP = 2048;          // LDS queue of (face slot, pixel) candidates per enumerate round
+constexpr int FRAC_SEG = 256;          // fractional-coverage fragments a raster workgroup keeps in its own list segment per render
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
 constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
@@ -170,7 +171,8 @@ struct WS {
     size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, bwd_list, bwd_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
     size_t zkey, fcnt, psum, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
-    size_t frac, frac_count, rstats, rslot, loss_part, stats2;
+    size_t frac, frac_count, frac_seg, seg_count, rstats, rslot, loss_part, stats2;
+    int nseg;
     size_t g_ndc, g_nrm, g_world, g_direct;
     size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc;
     size_t tile_static, image_static;
@@ -179,6 +181,23 @@ struct WS {
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// faces per workgroup of the scatter rasteriser: power of two in [8, RF], about F / 256
+static inline int raster_faces_per_block(int F, int B = 1) {
+    // few faces = big faces: fewer per workgroup.  With many images in the batch the machine is full anyway and
+    // fatter workgroups (fewer rounds of workgroups) win.
+    int r = 8;
+    while (r < RF && (size_t)r * 256 < (size_t)F * B) r <<= 1;
+    return r;
+}
+// raster workgroups per image (hand blocks, then object blocks): also the number of fragment-list segments per render
+static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& nRh, int& nRo) {
+    const int Fh_max = d.Fh_max > 0 ? d.Fh_max : d.Fmax, Fo_max = d.Fo_max > 0 ? d.Fo_max : d.Fmax;
+    rf_h = raster_faces_per_block(Fh_max, d.B);
+    rf_o = raster_faces_per_block(Fo_max, d.B);
+    nRh = cdiv(Fh_max, rf_h);
+    nRo = cdiv(Fo_max, rf_o);
+}
 
 static WS make_ws(const foho_dims& d) {
     WS w;
@@ -199,6 +218,12 @@ static WS make_ws(const foho_dims& d) {
     // --- zeroed every step (atomic accumulators) ---
     w.zero_begin = o;
     w.frac_count = take(R * B * 4);
+    {
+        int rf_h, rf_o, nRh, nRo;
+        raster_blocks(d, rf_h, rf_o, nRh, nRo);
+        w.nseg = nRh + nRo;
+    }
+    w.seg_count = take(R * B * (size_t)w.nseg * 4);  // entries in every raster workgroup's segment of the fragment list
     w.hit_count = take(R * B * 4);  // tiles with at least one hit pixel, per (render, image)
     w.bwd_count = take(R * B * 4);  // entries of the backward pass's work list (a dense tile is split into up to 4 entries)
     w.rstats = take(R * B * sizeof(RStats));
@@ -242,7 +267,8 @@ static WS make_ws(const foho_dims& d) {
     w.hit_list = take(R * B * (size_t)w.nbtiles * 4);  // ids of those tiles (k_resolve appends, k_loss walks the list)
     w.bwd_list = take(R * B * (size_t)w.nbtiles * BWD_SPLIT * 4);  // tile | part << 16 | parts << 20 (k_resolve appends, k_pix_bwd walks it)
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
-    w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));
+    w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));  // overflow of the segments (rare)
+    w.frac_seg = take(R * B * (size_t)w.nseg * FRAC_SEG * sizeof(FracEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
     w.stats2 = take(R * B * NSTAT * 4);
     w.g_direct = take(V3);
@@ -284,6 +310,7 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
         case FOHO_WS_STATS: off = w.stats2; n = R * B * NSTAT * 4; break;
         case FOHO_WS_PARITY: off = w.parity; n = B * 2 * (size_t)G1 * G1 * 16; break;
         case FOHO_WS_FRAG_COUNT: off = w.fcnt; n = R * B * P * 4; break;
+        case FOHO_WS_SEG_COUNT: off = w.seg_count; n = R * B * (size_t)w.nseg * 4; break;
         default: return -1;
     }
     if (nbytes) *nbytes = (int64_t)n;
@@ -326,6 +353,9 @@ struct Ctx {
     unsigned long long* plog;
     FracEntry* frac;
     unsigned* frac_count;
+    FracEntry* frac_seg;
+    unsigned* seg_count;
+    int nseg;
     RStats* rstats;
     RSlot* rslot;
     float *loss_part, *stats2;

@@ -257,13 +257,20 @@ def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None
     n_steps = int(cfg0.num_inference_steps)
     a_step, b_step = int(cfg0.handopt_start_step), int(cfg0.guidance_start_step)
 
+    graphs = {}     # the nine joint loops only differ in the intersection gate (denoising steps >= 17): two captures, not nine
+
     def loop(phase, iters, denoise_i):
         cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=denoise_i, do_update=True)
         gb.set_n_renders(n_renders)
         gb.reset_optimizer()
         iters_ = int(iters)
         spg = max([d for d in range(1, 51) if iters_ % d == 0]) if iters_ > 0 else 1   # iterations per hipGraph replay
-        graph = gb.capture(cfg, steps_per_graph=spg) if capture else None
+        graph = None
+        if capture:
+            key = (bytes(cfg), spg, gb.workspace.data_ptr())
+            if key not in graphs:
+                graphs[key] = gb.capture(cfg, steps_per_graph=spg)
+            graph = graphs[key]
         gb.reset_optimizer()
         for _ in range(iters_ // spg if graph is not None else iters_):
             graph.replay() if graph is not None else gb.step(cfg)

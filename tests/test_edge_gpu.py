@@ -184,7 +184,8 @@ def test_full_size_properties(obj_kind):
     gbatch = E.GuidanceBatch([other, sc])
     gbatch.step(cfg)
     torch.cuda.synchronize()
-    assert np.array_equal(gbatch.losses[1].cpu().numpy(), ga.losses[0].cpu().numpy())
+    # (to float rounding: the loss pass groups its partial sums by workgroup, and a batch uses fewer workgroups per image)
+    assert np.allclose(gbatch.losses[1].cpu().numpy(), ga.losses[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
 
 
 @gpu

@@ -319,8 +319,9 @@ def test_graph_replay_equals_eager_launches():
         graph.replay()
     torch.cuda.synchronize()
     gb_.raise_on_flags()
-    fc = gb_.region("frac_count", torch.int32).cpu().numpy()
-    assert fc[0] == 0 and 0 < fc[1] < gb_.dims.frac_cap     # only the hand+object render carries the silhouette
+    fc = gb_.region("frac_count", torch.int32).cpu().numpy()          # overflow list of the fragment segments: unused here
+    sg = gb_.region("seg_count", torch.int32).reshape(2, -1).cpu().numpy()
+    assert (fc == 0).all() and sg[0].sum() == 0 and 0 < sg[1].sum() < 20000 and sg.max() <= 256   # only the hand+object render carries the silhouette
     assert int(gb_.adam_t[0]) == 43 and np.isfinite(gb_.loss_dict(0)["total"])
 
 
