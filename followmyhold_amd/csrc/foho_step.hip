@@ -193,7 +193,9 @@ static inline int raster_faces_per_block(int F, int B = 1) {
 // raster workgroups per image (hand blocks, then object blocks): also the number of fragment-list segments per render
 static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& nRh, int& nRo) {
     const int Fh_max = d.Fh_max > 0 ? d.Fh_max : d.Fmax, Fo_max = d.Fo_max > 0 ? d.Fo_max : d.Fmax;
-    rf_h = raster_faces_per_block(Fh_max, d.B);
+    // hand faces are the big ones (tens of pixels each, the palm's up to hundreds): half of that per workgroup (a quarter overfills the chip at one image: a second round of workgroups), so that
+    // the workgroup with the largest faces does not set the length of the launch
+    rf_h = std::max(2, raster_faces_per_block(Fh_max, d.B) / 2);
     rf_o = raster_faces_per_block(Fo_max, d.B);
     nRh = cdiv(Fh_max, rf_h);
     nRo = cdiv(Fo_max, rf_o);

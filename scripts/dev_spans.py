@@ -39,6 +39,8 @@ for mode in ("eager", "graph1"):
                         sl = slice(o, o + cnt); o += cnt
                         lf = (e_[sl] - s_[sl]) / 100.0
                         print("            role %-12s life median %.1f max %.1f us, last end +%.1f us" % (nm, np.median(lf), lf.max(), (e_[sl].max() - s_[m].min()) / 100.0))
+                        if nm == "inside":
+                            print("              by block:", " ".join("%.0f" % v for v in lf[::8]), "| start offsets:", " ".join("%.1f" % ((v - s_[m].min()) / 100.0) for v in s_[sl][::40]))
                 life = np.where(m, e_ - s_, 0); top = np.argsort(-life)[:6]
                 print("            longest:", ", ".join("wg %d: %.1f us (start +%.1f)" % (i, life[i] / 100.0, (s_[i] - s_[m].min()) / 100.0) for i in top),
                       "| last to end:", ", ".join("wg %d" % i for i in np.argsort(-np.where(m, e_, 0))[:4]))
