@@ -124,6 +124,7 @@ constexpr int FRAC_SEG = 256;          // fractional-coverage fragments a raster
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
 constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
+constexpr int LOSS_SLOTS = 16;        // copies of a render's 12 loss accumulators (same-address f64 atomics serialise: 3 us of tail with one copy)
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per workgroup (18 used)
 constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd
@@ -236,7 +237,7 @@ static WS make_ws(const foho_dims& d) {
     w.parity = take(B * 2 * (size_t)G1 * G1 * 16);
     w.int_count = take(B * 4);
     w.final_ticket = take(B * 4);
-    w.loss_acc = take(R * B * NPART * 8);  // 12 loss sums per render (double atomics of k_loss, read by k_pix_bwd)
+    w.loss_acc = take(R * B * LOSS_SLOTS * NPART * 8);  // 12 loss sums per render x LOSS_SLOTS (double atomics of k_loss, read by k_pix_bwd)
     w.knn_inv = take(B * (size_t)std::max(d.Vh_max, 1) * 8);  // ~(d2 bits << 32 | index) of the nearest object vertex, atomicMax
     w.zero_end = o;
     // --- scatter planes of the rasteriser: all-zero outside [k_stage2, k_resolve]; k_resolve puts back to zero what
