@@ -14,7 +14,8 @@ names = ["xform", "stage2", "resolve", "loss", "pix_bwd", "vert_bwd"]
 KS_K, KS_WG = 6, 8192
 out = (ctypes.c_ulonglong * (KS_K * KS_WG * 2))()
 g1 = gb.capture(cfgu)
-for mode in ("eager", "graph1"):
+g3 = gb.capture(cfgu, steps_per_graph=3)       # deferred update: the stamps that survive are those of the LAST iteration
+for mode in ("eager", "graph1", "graph3-deferred"):
     rows = []
     for rep in range(6):
         gb.reset_optimizer(); gb.params.copy_(torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device="cuda"))
@@ -22,7 +23,7 @@ for mode in ("eager", "graph1"):
         torch.cuda.synchronize()
         gb.lib.foho_debug_spans_clear()
         torch.cuda.synchronize()
-        gb.step(cfgu) if mode == "eager" else g1.replay()
+        gb.step(cfgu) if mode == "eager" else (g1.replay() if mode == "graph1" else g3.replay())
         torch.cuda.synchronize()
         gb.lib.foho_debug_spans(out)
         a = np.frombuffer(out, dtype=np.uint64).reshape(KS_K, KS_WG, 2).astype(np.int64)
