@@ -238,6 +238,8 @@ class GuidedShapePipeline:
             opt = torch.optim.AdamW([{"params": [noise_pred], "lr": lr}], eps=1e-4)
             use_fast = os.environ.get("FOHO_EXACT_SIZE_OBJECTIVE") != "1"
             cap = fast["cap"] if fast["cap"][0] else (8 * guid_res * guid_res, 16 * guid_res * guid_res)
+            if not fast["cap"][0] and os.environ.get("FOHO_OBJ_CAPACITY"):      # "verts,faces": start value (tests: force the growth path)
+                cap = tuple(int(x) for x in os.environ["FOHO_OBJ_CAPACITY"].split(","))
             for k in range(int(iters)):
                 opt.zero_grad()
                 x1 = self.scheduler.step_final(noise_pred, t, obj_latents)

@@ -62,6 +62,35 @@ def test_mesh_off_screen_and_behind_the_camera():
 
 
 @gpu
+def test_object_beyond_the_background_depth_takes_the_full_loss_pass():
+    """render_normal_and_disparity puts the background at depth 10 (PL:283-284).  A hit pixel farther away than that makes the
+    background's normalised disparity non-zero, so the loss pass cannot take the uncovered pixels from its static target sums
+    and walks every tile instead (k_loss.inc): object scaled 60x and pushed to z = 14 m, against the oracle."""
+    from followmyhold_amd import engine as E
+    sc = make_scene("ico2", 64, 64, seed=2)
+    p = S.make_params(scale_obj=torch.tensor([60.0]), trans_obj=torch.tensor([0.0, 0.0, -13.5]))
+    st = S.PhaseStepper("B", sc, p)
+    total, terms, aux, grads = st.step(update=False)
+    z = aux["render"]["sel"]["zbuf"]
+    assert (aux["render"]["sel"]["pix_to_face"] >= 0).sum() > 200 and z[z > 0].max() > 10.5      # visible and beyond the background
+    gb = E.GuidanceBatch([_np_scene(sc)], grid_res=16, n_renders=1)
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
+    cfg, _ = E.phase_cfg("B", do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    gb.raise_on_flags()
+    assert np.array_equal(gb.region("p2f", torch.int32).cpu().numpy(), aux["render"]["sel"]["pix_to_face"].reshape(-1))
+    l = gb.loss_dict(0)
+    for a, b in [("normal0", "normal_obj"), ("disp0", "disp_obj"), ("sil0", "sil_obj")]:
+        assert abs(l[a] - float(terms[b])) <= 1e-4 * max(abs(float(terms[b])), 1e-6), (a, l[a], float(terms[b]))
+    assert abs(l["total"] - float(total)) <= 1e-4 * abs(float(total))
+    g = gb.grad_params[0].cpu().numpy()
+    for k in ("scale_obj", "trans_obj", "rot_obj"):
+        ref = grads[k].numpy()
+        assert np.linalg.norm(g[E.PARAM_SLICES[k]] - ref) <= 5e-4 * np.linalg.norm(ref), (k, g[E.PARAM_SLICES[k]], ref)
+
+
+@gpu
 def test_hand_only_scene_without_object():
     """Vo = 0 (empty object mesh): phase A runs, the object roles have nothing to do."""
     from followmyhold_amd import engine as E

@@ -188,8 +188,19 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
     g = np.asarray(Image.open([f for f in dbg if f.endswith("rendered_normal_t4.png")][0]))
     Hs = sc["H"]
     assert g.shape == (Hs, 2 * sc["W"] + 8, 3) and (g[:, :sc["W"]] > 0).any() and (g[:, sc["W"] + 8:] > 0).any()
-    # the gradient reaches the latent: with the latent's learning rates at zero the decoded object differs
+    # capacity mode's escape hatch: with an object capacity that is far too small the first latent iteration is redone on the
+    # exact-size path, the capacity grows, and the run completes (the two runs are not comparable vertex by vertex: phase A's
+    # learning rate of 0.5 makes the trajectory chaotic)
     monkeypatch.delenv("FOHO_DEBUG_DIR")
+    monkeypatch.setenv("FOHO_OBJ_CAPACITY", "64,128")
+    obj_c, hand_c = run(_short_config())
+    monkeypatch.delenv("FOHO_OBJ_CAPACITY")
+    assert pipe.stats.get("capacity_grown", 0) >= 1 and pipe.stats.get("exact_size_iterations", 0) >= 1
+    assert pipe.stats["inner_iterations"] == 10 + 3 + 2 * 2
+    oc = obj_c.verts_packed()
+    assert oc.shape[0] > 1000 and torch.isfinite(oc).all() and torch.isfinite(hand_c.verts_packed()).all()
+    assert np.abs(oc.mean(0).cpu().numpy() - centre).max() < 0.12
+    # the gradient reaches the latent: with the latent's learning rates at zero the decoded object differs
     obj0, _ = run(_short_config(noise_lr=0.0))
     v0 = obj0.verts_packed()
     assert v0.shape != ov.shape or not torch.allclose(v0, ov, atol=1e-6)
