@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfoho_hip.so")
+SO_PATH = os.environ.get("FOHO_HIP_SO") or os.path.join(_HERE, "libfoho_hip.so")   # $FOHO_HIP_SO: another build of the same library (development)
 _lib = None
 
 c_f = ctypes.c_float

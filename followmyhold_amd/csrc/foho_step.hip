@@ -135,7 +135,7 @@ constexpr int SIM_ACC = 40;            // floats per image and parity in the def
 constexpr int STATE_NEXT = 64;         // floats per image in the deferred-update staging area
 constexpr int PIX_BWD_TILE_BLOCKS = 256;
 constexpr int BWD_SPLIT = 4;             // a dense 32x8 tile is handed to k_pix_bwd as up to 4 bands of pixel rows  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
-constexpr int BWD_SLOTS = 1024;       // LDS hash slots (distinct vertices per 256-px tile <= 768)
+constexpr int BWD_SLOTS = 512;        // LDS hash slots: a work-list entry holds at most 128 hit pixels (band split), i.e. <= 384 distinct vertices
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
     unsigned long long kmin_inv[3];  // ~(ordered value << 32 | index), atomicMax  -> min value, lowest index
