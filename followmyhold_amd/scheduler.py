@@ -59,7 +59,7 @@ class FlowMatchEulerDiscreteScheduler:
         """Inference schedule.  The guidance pipeline passes sigmas = linspace(0, 1, 20) (pipelines.py:1187-1193)."""
         dynamic = self.config.use_dynamic_shifting
         if dynamic and mu is None:
-            raise ValueError(" you have a pass a value for `mu` when `use_dynamic_shifting` is set to be `True`")
+            raise ValueError("set_timesteps: `mu` is required because this scheduler was configured with use_dynamic_shifting=True")
         n_train = self.config.num_train_timesteps
         if sigmas is None:
             self.num_inference_steps = num_inference_steps
@@ -89,10 +89,8 @@ class FlowMatchEulerDiscreteScheduler:
     @staticmethod
     def _reject_int_timestep(timestep):
         if isinstance(timestep, int) or isinstance(timestep, (torch.IntTensor, torch.LongTensor)):
-            raise ValueError(
-                "Passing integer indices (e.g. from `enumerate(timesteps)`) as timesteps to"
-                " `EulerDiscreteScheduler.step()` is not supported. Make sure to pass"
-                " one of the `scheduler.timesteps` as a timestep.")
+            raise ValueError("step(): `timestep` must be one of scheduler.timesteps (a float tensor), not an integer index such as "
+                             "the counter of enumerate(timesteps)")
 
     def step(self, model_output, timestep, sample, return_dict: bool = True, **_):
         """x_next = x + (sigma_{k+1} - sigma_k) v ; pred_x1 = x + (1 - sigma_k) v ; advances the index."""
@@ -128,7 +126,7 @@ class FlowMatchEulerDiscreteScheduler:
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
     """pipelines.py:363-419."""
     if timesteps is not None and sigmas is not None:
-        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
+        raise ValueError("retrieve_timesteps: pass either `timesteps` or `sigmas`, not both")
     if timesteps is not None:
         scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
         timesteps = scheduler.timesteps
