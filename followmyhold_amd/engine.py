@@ -584,9 +584,10 @@ class GuidanceBatch:
                 "foho_step_finalize")
 
     def step_profiled(self, cfg, deferred=False):
-        """One iteration with a hipEvent after every kernel; returns {kernel name: milliseconds}.  deferred=True times the
-        iteration the way it runs inside a multi-iteration hipGraph (foho_step_cfg.deferred_update: the final stage of an
-        iteration rides in the next k_xform): two such iterations are run, the second one is reported, a finalize closes."""
+        """Per-kernel durations {kernel name: milliseconds} of one iteration (hipEvents after every launch).  The library
+        runs an un-timed iteration first and times the one behind it, so TWO iterations are executed.  deferred=True times
+        the iteration the way it runs inside a multi-iteration hipGraph (foho_step_cfg.deferred_update: the final stage of
+        an iteration rides in the next k_xform); a finalize closes the pair."""
         lib = self.lib
         if self._bbox_dirty:
             self.refresh_bbox()
@@ -596,20 +597,16 @@ class GuidanceBatch:
         lib.foho_kernel_name.restype = ctypes.c_char_p
         ms = (ctypes.c_float * L.N_KERNELS)()
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        cfgs = [cfg]
+        c2 = cfg
         if deferred:
-            cfgs = []
-            for k in range(2):
-                c2 = L.FohoStepCfg.from_buffer_copy(bytes(cfg))
-                c2.deferred_update = 1 + (k & 1)
-                cfgs.append(c2)
-        for c2 in cfgs:
-            L.check(lib.foho_step_run_profiled(ctypes.byref(self.desc()), ctypes.byref(c2), ctypes.c_void_p(stream), ms),
-                    "foho_step_run_profiled")
+            c2 = L.FohoStepCfg.from_buffer_copy(bytes(cfg))
+            c2.deferred_update = 2
+        L.check(lib.foho_step_run_profiled(ctypes.byref(self.desc()), ctypes.byref(c2), ctypes.c_void_p(stream), ms),
+                "foho_step_run_profiled")
         names = [lib.foho_kernel_name(i).decode() for i in range(L.N_KERNELS)]
         out = {n: float(ms[i]) for i, n in enumerate(names) if n}
         if deferred:
-            self.finalize(cfgs[-1])
+            self.finalize(c2)
         return out
 
 

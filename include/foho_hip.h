@@ -189,8 +189,9 @@ int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stag
 /* Applies the update a deferred_update step left pending (no-op per image when nothing is pending): one small launch;
  * cfg->deferred_update must carry the number of the LAST step run. */
 int foho_step_finalize(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream);
-/* Same as foho_step_run(FOHO_STAGE_STEP) but brackets every launch with hipEvents on `stream`, synchronises
- * the stream and returns the duration of each launch in milliseconds (measurement aid for bench.py);
+/* Runs foho_step_run(FOHO_STAGE_STEP) TWICE: an un-timed iteration (with the other parity when cfg->deferred_update is
+ * set), then the same iteration again with every launch bracketed by hipEvents on `stream`; synchronises the stream and
+ * returns the duration of each launch of the second iteration in milliseconds (measurement aid for bench.py);
  * foho_kernel_name(i) names the i-th launch of the calling thread's last profiled run ("" past the end). */
 #define FOHO_N_KERNELS 10
 int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
