@@ -28,6 +28,8 @@ for rep in range(4):
         d(10, 11), d(11, 12), d(12, 13), d(10, 14), d(14, 15), d(15, 16), d(16, 17)))
     print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
         "eager" if rep < 2 else "graph", d(6, 20), d(24, 10), d(0, 17)))
+    print("resolve centre tile (render 1): flags %.2f key %.2f face verts %.2f eval %.2f (sil planes) %.2f colour gather %.2f stores+shade %.2f barrier %.2f reduce+atomics %.2f | total %.2f" % (
+        d(70, 71), d(71, 72), d(72, 73), d(73, 74), d(74, 75), d(75, 76), d(76, 77), d(77, 78), d(78, 79), d(70, 79)))
     for nm, o in (("hand", 50), ("obj", 60)):
         print("raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f (T=%d candidates)" % (
             nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), a[o + 8]))
