@@ -262,7 +262,7 @@ static WS make_ws(const foho_dims& d) {
     w.vn = take(V3);
     w.face_ndc = take((size_t)d.Ftot * 9 * 4);
     w.state_next = take(B * (size_t)STATE_NEXT * 4);   // deferred update: params 16 | adam m 16 | adam v 16 | t | flags, written by k_xform
-    w.pair_v = take((size_t)d.Ftot * 3 * 16);  // per (vertex, incident face) pair, CSR order: the face's 3 vertex ids + the corner
+    w.pair_v = take((size_t)d.Ftot * 3 * 8);  // per (vertex, incident face) pair, CSR order: the face's 3 vertex ids + the corner (pack_pair)
     w.p2f = take(R * B * P * 4);
     w.zbuf = take(R * B * P * 4);
     w.sdist = take(R * B * P * 4);
@@ -320,6 +320,19 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
     return (int64_t)off;
 }
 
+// One (vertex, incident face) pair in 8 bytes: v0 in 22 bits, v1 - v0 and v2 - v0 biased by 2^19 in 20 bits each (a face's
+// vertices belong to one image: |difference| < 262144), the corner in the top 2 bits.  Needs Vtot <= 2^22 (checked on the host).
+__device__ __forceinline__ unsigned long long pack_pair(int v0, int v1, int v2, int corner) {
+    return (unsigned long long)(unsigned)v0 | ((unsigned long long)(unsigned)(v1 - v0 + (1 << 19)) << 22) |
+           ((unsigned long long)(unsigned)(v2 - v0 + (1 << 19)) << 42) | ((unsigned long long)(corner & 3) << 62);
+}
+__device__ __forceinline__ void unpack_pair(unsigned long long p, int v[3], int& corner) {
+    v[0] = (int)(p & 0x3FFFFFu);
+    v[1] = v[0] + (int)((p >> 22) & 0xFFFFFu) - (1 << 19);
+    v[2] = v[0] + (int)((p >> 42) & 0xFFFFFu) - (1 << 19);
+    corner = (int)(p >> 62);
+}
+
 // kernel-side view of the step (device pointers, by value)
 struct Ctx {
     foho_dims d;
@@ -346,7 +359,7 @@ struct Ctx {
     int* bwd_list;
     unsigned* bwd_count;
     uint8_t *tile_touched, *tile_clean;
-    int4* pair_v;
+    unsigned long long* pair_v;
     int* pending;
     float* state_next;
     float* sim_acc;
