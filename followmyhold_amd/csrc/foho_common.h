@@ -211,17 +211,36 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
 }
 
 // ---------------------------------------------------------------- rasteriser primitives
-// pixel index -> NDC of the pixel centre (pytorch3d PixToNonSquareNdc)
-__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
+// pixel index -> NDC of the pixel centre (pytorch3d PixToNonSquareNdc).  The per-axis constants are the
+// same for every pixel of a launch: they are worked out once on the host (same IEEE binary32 operations) and travel in
+// the kernel arguments, so a pixel costs a convert, two multiplies and two adds -- inside per-lane loops the compiler
+// would otherwise redo the two uniform divisions on the vector unit every time (float division has no scalar form).
+struct PixAxis {
+    float range, offset, s1, inv_s1, inv_range;
+    int S1;
+    int pow2, range_pow2;  // S1 / range are powers of two: dividing by them = multiplying by the exact reciprocal
+};
+__host__ __device__ __forceinline__ PixAxis pix_axis(int S1, int S2) {
+    PixAxis a;
     float range = 2.0f;
     if (S1 > S2) range = ((float)S1 * range) / (float)S2;
-    const float offset = range / 2.0f;
-    const float num = range * (float)i + offset;
-    // dividing by a power of two is exact, so multiplying by its (exact) reciprocal gives the same bits without the
-    // ~10-instruction correctly rounded division; 512x512 images take this path (wave-uniform branch)
-    const float q = ((S1 & (S1 - 1)) == 0) ? num * (1.0f / (float)S1) : num / (float)S1;
-    return -offset + q;
+    a.range = range;
+    a.offset = range / 2.0f;
+    a.s1 = (float)S1;
+    a.inv_s1 = 1.0f / (float)S1;
+    a.inv_range = 1.0f / range;
+    a.S1 = S1;
+    a.pow2 = (S1 & (S1 - 1)) == 0;
+    int e = 0;
+    a.range_pow2 = frexpf(range, &e) == 0.5f;
+    return a;
 }
+__device__ __forceinline__ float pix_to_ndc(int i, const PixAxis& a) {
+    const float num = a.range * (float)i + a.offset;
+    const float q = a.pow2 ? num * a.inv_s1 : num / a.s1;
+    return -a.offset + q;
+}
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) { return pix_to_ndc(i, pix_axis(S1, S2)); }
 
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);

@@ -82,6 +82,11 @@ __device__ unsigned long long g_dbg[1024];
     do {                                                        \
         if (threadIdx.x == 0) g_dbg[i] = wall_clock64();        \
     } while (0)
+#define DBGW(i)                                  \
+    do {                                         \
+        __builtin_amdgcn_s_waitcnt(0);           \
+        DBG(i);                                  \
+    } while (0)
 extern "C" void foho_debug_clear(void) {
     static unsigned long long z[1024];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
@@ -108,6 +113,9 @@ extern "C" void foho_debug_spans_clear(void) { (void)hipMemset((void*)nullptr, 0
 #else
 #define DBG(i) \
     do {       \
+    } while (0)
+#define DBGW(i) \
+    do {        \
     } while (0)
 #define KSPAN(k) \
     do {         \
@@ -336,6 +344,7 @@ __device__ __forceinline__ void unpack_pair(unsigned long long p, int v[3], int&
 // kernel-side view of the step (device pointers, by value)
 struct Ctx {
     foho_dims d;
+    PixAxis ax, ay;  // pixel column / row -> NDC (pix_to_ndc)
     const foho_image* img;
     const float* verts_in;
     const int32_t* faces;

@@ -1,9 +1,17 @@
-# bench value of library variants followmyhold_amd/libfoho_var*.so at 1 / 8 / 32 images (development aid)
+# bench value + per-kernel times of library variants (FOHO_HIP_SO hook) at 1 / 8 images on one stream (development aid)
+# usage: bash scripts/dev_variants.sh followmyhold_amd/libfoho_hip.so [more.so ...]
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for so in followmyhold_amd/libfoho_var*.so; do
-  for n in 1 8 32; do
-    s=2000; [ $n -gt 1 ] && s=200
+for so in "$@"; do
+  for n in 1 8; do
+    s=2000; [ $n -gt 1 ] && s=300
+    for rep in 1 2; do
     echo -n "$so n=$n: "
-    FOHO_HIP_SO=$PWD/$so timeout 200 python bench.py --no-cpu-baseline --no-extras --images-per-gpu $n --steps $s 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), {k[2:]: round(v*1e3,1) for k,v in d['kernel_ms'].items()})"
+    FOHO_HIP_SO=$PWD/$so timeout 120 python bench.py --no-cpu-baseline --no-extras --images-per-gpu $n --streams 1 --steps $s 2>&1 | tail -1 | python -c "
+import json,sys
+t=sys.stdin.read()
+try:
+    d=json.loads(t); print(round(d['value']), {k[2:]: round(v*1e3,1) for k,v in d['kernel_ms'].items()})
+except Exception as e: print('ERR', t[-300:])"
+    done
   done
 done
