@@ -32,6 +32,6 @@ for rep in range(4):
         d(70, 71), d(71, 72), d(72, 73), d(73, 74), d(74, 75), d(75, 76), d(76, 77), d(77, 78), d(78, 79), d(70, 79)))
     for nm, o in (("hand", 50), ("obj", 60)):
         print("raster %s blk setup: ids %.2f ndc %.2f math+stores issued %.2f scan %.2f" % (nm, d(o, o + 6), d(o + 6, o + 7), d(o + 7, o + 9), d(o + 9, o + 1)))
-        print("raster %s blk setup detail: stores issued %.2f cull+flags %.2f pix range %.2f (again %.2f) tile marks %.2f" % (nm, d(o + 7, o + 30), d(o + 30, o + 31), d(o + 31, o + 32), d(o + 32, o + 33), d(o + 33, o + 9)))
+        print("raster %s blk setup detail: stores issued %.2f cull+flags %.2f pix range %.2f tile marks %.2f" % (nm, d(o + 7, o + 30), d(o + 30, o + 31), d(o + 31, o + 32), d(o + 32, o + 9)))
         print("raster %s blk: setup %.2f barrier %.2f enumerate %.2f barrier %.2f evaluate %.2f (T=%d candidates)" % (
             nm, d(o, o + 1), d(o + 1, o + 2), d(o + 2, o + 3), d(o + 3, o + 4), d(o + 4, o + 5), a[o + 8]))
