@@ -275,9 +275,15 @@ def main():
             out["step_traffic_frac"] = step_traffic * value / world / 1e9 / HBM_PEAK_GBS
 
         if world == 1 and not args.no_extras:
-            out["batched"] = batched_record(E, torch, synthetic, render_fn, args, dev, cfg)
-            out["batched_f16_gbuffer"] = batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)
-            out["topology_changing"] = topology_record(E, torch, scenes[0], dev)
+            # side records: a failure in one of them (a raised step flag, say) is reported in its place and must not cost
+            # the headline line above
+            for key, fn in (("batched", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg)),
+                            ("batched_f16_gbuffer", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)),
+                            ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev))):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             base, first = cpu_baseline(scenes[0], args.cpu_steps)
             out["cpu_baseline"] = base
