@@ -135,7 +135,7 @@ constexpr int NPART = 12;             // partial sums per loss block
 constexpr int LOSS_SLOTS = 16;        // copies of a render's 12 loss accumulators (same-address f64 atomics serialise: 3 us of tail with one copy)
 constexpr int VERT_BLOCKS_MAX = 1024; // blocks of vertex-role partials per image
 constexpr int SIM_NP = 20;            // similarity-backward partial sums per workgroup (18 used)
-constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd
+constexpr int VB = 64;                // vertices per workgroup of k_vert_bwd at one image (128 in batches: vert_block)
 constexpr int VP_CAP = 1024;          // (vertex, incident face) pairs staged in LDS per round of k_vert_bwd
 constexpr int SIM_ROWS_MAX = VERT_BLOCKS_MAX * (256 / VB);  // partial rows per (image, mesh)
 constexpr int NSTAT = 32;             // finalised per-render stats (floats)
@@ -192,6 +192,7 @@ struct WS {
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // faces per workgroup of the scatter rasteriser: power of two in [8, RF], about F / 256
+static inline int vert_block(const foho_dims& d) { return d.B > 1 ? 2 * VB : VB; }  // vertices per k_vert_bwd workgroup
 static inline int raster_faces_per_block(int F, int B = 1) {
     // few faces = big faces: fewer per workgroup.  With many images in the batch the machine is full anyway and
     // fatter workgroups (fewer rounds of workgroups) win.
