@@ -231,14 +231,15 @@ def main():
     if rank == 0:
         sizes = (H, W, m0["Vh"], m0["Vo"], m0["Fh"], m0["Fo"])
         # ---- roofline of the dominant kernel: hipEvents around every launch, averaged over the timed step count
-        acc = {}
-        nprof = 20
+        acc, samples = {}, {}
+        nprof = 100
         run_steps(25)            # profile in the middle of a 50-iteration window
         torch.cuda.synchronize(dev)
         cfg_frozen, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
         for _ in range(nprof):      # timed the way the iterations run inside the multi-iteration graphs (deferred final stage)
             for k, v in gb.step_profiled(cfg_frozen, deferred=spg > 1).items():
                 acc[k] = acc.get(k, 0.0) + v / nprof
+                samples.setdefault(k, []).append(v)
         # hit statistics of the profiled scene (the G-buffer is hit-only): hit pixels and pixels of 32x8 tiles with a hit
         P = H * W
         p2f = gb.region("p2f", torch.int32, (2, gb.B, H, W))[:, 0]
@@ -246,7 +247,10 @@ def main():
         for r in range(2):
             t = (p2f[r] >= 0)[: H // 8 * 8, : W // 32 * 32].reshape(H // 8, 8, W // 32, 32).any(3).any(1)
             hits["tile_px"].append(int(t.sum()) * 256)
-        dom = max(acc, key=lambda k: acc[k])
+        # the dominant kernel is picked by the MEDIAN (one disturbed launch in the sample must not change which kernel the
+        # record is about); the roofline figures use the mean, as the contract asks
+        med = {k: float(np.median(v)) for k, v in samples.items()}
+        dom = max(med, key=lambda k: med[k])
         kb = kernel_bytes(dom, *sizes, hits=hits)
         bstep = algorithmic_bytes(*sizes)
         if kb is None:
@@ -259,6 +263,7 @@ def main():
                            "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)", "kernel_ms": acc[dom],
                            "algorithmic_bytes_per_launch": kb * ipb}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
+        out["kernel_ms_median"] = {k: round(v, 5) for k, v in med.items()}
         out["hit_pixels"] = hits
         out["kernels"] = {}
         for k, v in acc.items():           # every launch of the step against the HBM roofline (algorithmic bytes / duration)
