@@ -28,6 +28,7 @@ for rep in range(4):
         d(10, 11), d(11, 12), d(12, 13), d(10, 14), d(14, 15), d(15, 16), d(16, 17)))
     print("vbwd  mid blk body: offsets %.2f pair records + gathers %.2f pair arithmetic %.2f barrier %.2f per-vertex sums %.2f per-vertex rest %.2f" % (
         d(10, 18), d(18, 19), d(19, 45), d(45, 46), d(46, 47), d(47, 11)))
+    print("vbwd  hand blk 0 per-vertex: projection %.2f contact %.2f keypoints %.2f" % (d(40, 41), d(41, 42), d(42, 43)))
     print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
         "eager" if rep < 2 else "graph", d(6, 20), d(24, 10), d(0, 17)))
     print("resolve centre tile (render 1): flags %.2f key %.2f face verts %.2f eval %.2f (sil planes) %.2f colour gather %.2f stores+shade %.2f barrier %.2f reduce+atomics %.2f | total %.2f" % (
