@@ -29,6 +29,8 @@ for rep in range(4):
     print("vbwd  mid blk body: offsets %.2f pair records + gathers %.2f pair arithmetic %.2f barrier %.2f per-vertex sums %.2f per-vertex rest %.2f" % (
         d(10, 18), d(18, 19), d(19, 45), d(45, 46), d(46, 47), d(47, 11)))
     print("vbwd  hand blk 0 per-vertex: projection %.2f contact %.2f keypoints %.2f" % (d(40, 41), d(41, 42), d(42, 43)))
+    print("xform blk 0 deferred prologue: prefetch + pending %.2f sums ready %.2f gradients / centre path || loss assembly %.2f barrier %.2f Adam + stores %.2f rest %.2f | total %.2f" % (
+        d(95, 90), d(90, 91), d(91, 92), d(92, 93), d(93, 94), d(94, 96), d(95, 96)))
     print("gaps (%s): loss end -> pixbwd mid tile start %.2f | pixbwd mid tile end -> vbwd mid start %.2f | loss blk0 start -> vbwd last end %.2f" % (
         "eager" if rep < 2 else "graph", d(6, 20), d(24, 10), d(0, 17)))
     print("resolve centre tile (render 1): flags %.2f key %.2f face verts %.2f eval %.2f (sil planes) %.2f colour gather %.2f stores+shade %.2f barrier %.2f reduce+atomics %.2f | total %.2f" % (

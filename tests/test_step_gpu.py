@@ -446,8 +446,10 @@ def test_deferred_update_graph_replays_equal_plain_stepping(n, monkeypatch):
             a, b_ = a.cpu().numpy(), b_.cpu().numpy()
             assert np.allclose(a, b_, atol=tol) if tol else np.allclose(a, b_, rtol=2e-3), (mode, a, b_)
         # gradients of the last iteration, incl. the six arg-min / arg-max vertices the final stage completes
-        assert rel_err(gb.grad_params.cpu().numpy(), ref.grad_params.cpu().numpy()) < 2e-2
-        assert rel_err(gb.grad_verts_in.cpu().numpy(), ref.grad_verts_in.cpu().numpy()) < 2e-2
+        # (free-running trajectories of 2 n iterations: the atomic-sum noise of the earlier iterations shows up here at the
+        # per-cent level -- 2.03 % was seen once in ~20 runs; a plumbing error moves these by O(1))
+        assert rel_err(gb.grad_params.cpu().numpy(), ref.grad_params.cpu().numpy()) < 5e-2
+        assert rel_err(gb.grad_verts_in.cpu().numpy(), ref.grad_verts_in.cpu().numpy()) < 5e-2
     # nothing is left pending: a plain eager step on the deferred batch continues the same trajectory
     gd = outs["deferred"]
     gd.step(cfg)
