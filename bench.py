@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
 PMC_CSV = os.path.join("profiles", "r02_rocprofv3_pmc_fetch_write_b1.csv")
 PMC_CSV_FALLBACK = os.path.join("profiles", "r01_rocprofv3_pmc_fetch_write_b1.csv")
+KSTATS_CSV = os.path.join("profiles", "r02_rocprofv3_kernel_stats_bench_b1.csv")
 
 
 def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
@@ -91,6 +92,20 @@ def pmc_table():
                if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
         return out, rel
     return {}, None
+
+
+def dominant_from_kernel_stats(names):
+    """Longest step kernel by mean duration in profiles/r02_rocprofv3_kernel_stats_bench_b1.csv (None without the file)."""
+    import csv
+    path = os.path.join(ROOT, KSTATS_CSV)
+    if not os.path.exists(path):
+        return None
+    best, best_ns = None, 0.0
+    for row in csv.DictReader(open(path)):
+        k = row["Name"].replace("void ", "").split("(")[0].split("<")[0]
+        if k in names and float(row["AverageNs"]) > best_ns:
+            best, best_ns = k, float(row["AverageNs"])
+    return best
 
 
 def pick_spg(steps, cap=0):
@@ -251,6 +266,12 @@ def main():
         # record is about); the roofline figures use the mean, as the contract asks
         med = {k: float(np.median(v)) for k, v in samples.items()}
         dom = max(med, key=lambda k: med[k])
+        # ... and at one image by the committed rocprofv3 kernel trace of this same command when it is there: the event-timed
+        # k_pix_bwd reads ~18 instead of ~13.5 us in roughly one process out of six (address dependent; graph replays and the
+        # kernel trace do not show it), which would flip the record between two kernels from run to run
+        prof_dom = dominant_from_kernel_stats(set(acc)) if ipg == 1 else None
+        if prof_dom is not None:
+            dom = prof_dom
         kb = kernel_bytes(dom, *sizes, hits=hits)
         bstep = algorithmic_bytes(*sizes)
         if kb is None:
