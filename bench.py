@@ -33,9 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW")
-PMC_CSV = os.path.join("profiles", "r02_rocprofv3_pmc_fetch_write_b1.csv")
-PMC_CSV_FALLBACK = os.path.join("profiles", "r01_rocprofv3_pmc_fetch_write_b1.csv")
-KSTATS_CSV = os.path.join("profiles", "r02_rocprofv3_kernel_stats_bench_b1.csv")
+MIN_TIMED_S = 0.25     # the timed region of --steps iterations is repeated until this much has been measured
+# committed rocprofv3 summaries, by workload (object kind, image size, images per GPU): PMC traffic and kernel trace are only
+# attached to a record of the SAME workload (images per LAUNCH: the b8 files are one 8-image batch on one stream) --
+# another object / size / batch gets null, never a borrowed number
+PMC_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_pmc_fetch_write_b1.csv"),
+                              os.path.join("profiles", "r02_rocprofv3_pmc_fetch_write_b1.csv")],
+            ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_pmc_fetch_write_b8.csv")]}
+KSTATS_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_kernel_stats_bench_b1.csv"),
+                                 os.path.join("profiles", "r02_rocprofv3_kernel_stats_bench_b1.csv")],
+               ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_kernel_stats_bench_b8_1stream.csv")]}
 
 
 def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
@@ -76,11 +83,11 @@ def kernel_bytes(name, H, W, Vh, Vo, Fh, Fo, hits=None, grid_res=64):
     return table.get(name)
 
 
-def pmc_table():
-    """{kernel: HBM bytes per launch} from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE /
+def pmc_table(workload):
+    """({kernel: HBM bytes per launch}, file) from the committed rocprofv3 PMC passes of THIS workload (FETCH_SIZE /
     WRITE_SIZE are in KiB and FETCH_SIZE reads half of a wide coalesced stream on gfx950 -- MI355X_MICROARCH.md
-    "HBM" -- hence 2 x FETCH + WRITE)."""
-    for rel in (PMC_CSV, PMC_CSV_FALLBACK):
+    "HBM" -- hence 2 x FETCH + WRITE); ({}, None) when no summary of this workload is committed."""
+    for rel in PMC_CSVS.get(workload, []):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -94,18 +101,21 @@ def pmc_table():
     return {}, None
 
 
-def dominant_from_kernel_stats(names):
-    """Longest step kernel by mean duration in profiles/r02_rocprofv3_kernel_stats_bench_b1.csv (None without the file)."""
+def dominant_from_kernel_stats(names, workload):
+    """(longest step kernel by mean duration, file) in the committed rocprofv3 kernel trace of this workload, (None, None)
+    without one.  Reported BESIDE the live choice (`dominant_by_trace`), it never replaces it."""
     import csv
-    path = os.path.join(ROOT, KSTATS_CSV)
-    if not os.path.exists(path):
-        return None
-    best, best_ns = None, 0.0
-    for row in csv.DictReader(open(path)):
-        k = row["Name"].replace("void ", "").split("(")[0].split("<")[0]
-        if k in names and float(row["AverageNs"]) > best_ns:
-            best, best_ns = k, float(row["AverageNs"])
-    return best
+    for rel in KSTATS_CSVS.get(workload, []):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        best, best_ns = None, 0.0
+        for row in csv.DictReader(open(path)):
+            k = row["Name"].replace("void ", "").split("(")[0].split("<")[0]
+            if k in names and float(row["AverageNs"]) > best_ns:
+                best, best_ns = k, float(row["AverageNs"])
+        return best, rel
+    return None, None
 
 
 def pick_spg(steps, cap=0):
@@ -156,6 +166,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batched / topology_changing sub-records")
     ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region (0 = as many as it takes to measure "
+                    f"{MIN_TIMED_S} s; the median repeat is reported)")
     ap.add_argument("--gbuf-f16", action="store_true", help="depth / colour planes of the G-buffer in fp16 (configs[4])")
     args = ap.parse_args()
 
@@ -208,23 +220,39 @@ def main():
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_region():
+        """EXACTLY args.steps iterations between barrier + synchronize on both sides; max over ranks."""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        tm = torch.tensor([dt_], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item())
+
+    # A short --steps (the driver's 20) is a ~1 ms region -- two graph replays, at the mercy of one scheduling hiccup.  The
+    # region is therefore repeated until MIN_TIMED_S has been measured and the MEDIAN repeat is reported; every repeat is
+    # the contract's region (K steps, barriers, max over ranks), `steps` stays K.  The repeat count follows from the first
+    # repeat's all-reduced time, so every rank arrives at the same number.
+    times = [timed_region()]
+    n_rep = int(min(200, max(1, -(-MIN_TIMED_S // max(times[0], 1e-6))))) if args.repeats <= 0 else args.repeats
+    while len(times) < n_rep:
+        times.append(timed_region())
+    dt = float(np.median(times))
     # end-of-batch metrics all-reduce (the only collective of the path; SURVEY.md 8(e))
-    metrics = sum(sharding.local_metrics(g, n_steps=args.steps, wall_ms=dt * 1e3 if i == 0 else 0.0)
+    metrics = sum(sharding.local_metrics(g, n_steps=args.steps * len(times), wall_ms=sum(times) * 1e3 if i == 0 else 0.0)
                   for i, g in enumerate(group.batches))
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if backend != "nccl":
+            metrics = metrics.cpu()
         metrics = sharding.all_reduce_metrics(metrics, dist)
-    dt = float(tmax.item())
     for g in group.batches:
         g.raise_on_flags()
 
@@ -233,6 +261,7 @@ def main():
     out = {
         "metric": "guidance-steps/sec (512x512, 778+20k verts)", "value": value, "unit": "guidance-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+        "repeats": len(times), "ms_per_step_min_max": [min(times) * 1e3 / args.steps, max(times) * 1e3 / args.steps],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.gbuf_f16 else "f32 (G-buffer f16)",
         "data": "synthetic",
         "config": {"workload": f"configs[1]: single {H}x{W} synthetic frame per GPU, {m0['Vh']}-vert hand + "
@@ -240,7 +269,8 @@ def main():
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
                    "hip_graph": not args.no_graph, "steps_per_graph": spg, "streams": len(group.batches),
                    "restart_every": 50},
-        "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[-2]),
+        "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[sharding.IDX["n_nan"]]),
+        "metrics": {k: float(v) for k, v in zip(sharding.METRIC_NAMES, metrics.tolist())},
     }
 
     if rank == 0:
@@ -262,27 +292,27 @@ def main():
         for r in range(2):
             t = (p2f[r] >= 0)[: H // 8 * 8, : W // 32 * 32].reshape(H // 8, 8, W // 32, 32).any(3).any(1)
             hits["tile_px"].append(int(t.sum()) * 256)
-        # the dominant kernel is picked by the MEDIAN (one disturbed launch in the sample must not change which kernel the
-        # record is about); the roofline figures use the mean, as the contract asks
+        # the dominant kernel is picked LIVE, by the MEDIAN of the profiled launches (one disturbed launch in the sample must
+        # not change which kernel the record is about); the roofline figures use the mean, as the contract asks.  What the
+        # committed rocprofv3 kernel trace of the same workload says is reported beside it (`dominant_by_trace`): event
+        # timing adds ~3 us per launch and reads k_pix_bwd high in about one process out of six, so the two can differ -- the
+        # record says so instead of hiding it.
         med = {k: float(np.median(v)) for k, v in samples.items()}
         dom = max(med, key=lambda k: med[k])
-        # ... and at one image by the committed rocprofv3 kernel trace of this same command when it is there: the event-timed
-        # k_pix_bwd reads ~18 instead of ~13.5 us in roughly one process out of six (address dependent; graph replays and the
-        # kernel trace do not show it), which would flip the record between two kernels from run to run
-        prof_dom = dominant_from_kernel_stats(set(acc)) if ipg == 1 else None
-        if prof_dom is not None:
-            dom = prof_dom
+        workload = (args.obj, args.size, gb.B)       # object, image size, images per LAUNCH (the profiled batch)
+        prof_dom, prof_src = dominant_from_kernel_stats(set(acc), workload)
         kb = kernel_bytes(dom, *sizes, hits=hits)
         bstep = algorithmic_bytes(*sizes)
         if kb is None:
             kb = bstep
         ipb = gb.B               # images in the profiled batch (the first stream's)
         achieved = kb * ipb / (acc[dom] * 1e-3) / 1e9
-        pmc, pmc_src = pmc_table()
+        pmc, pmc_src = pmc_table(workload)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom) if ipg == 1 else None,
-                           "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)", "kernel_ms": acc[dom],
-                           "algorithmic_bytes_per_launch": kb * ipb}
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom),
+                           "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)" if pmc_src else None,
+                           "kernel_ms": acc[dom], "kernel_ms_median": med[dom], "algorithmic_bytes_per_launch": kb * ipb,
+                           "dominant_by_trace": prof_dom, "trace_source": prof_src}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
         out["kernel_ms_median"] = {k: round(v, 5) for k, v in med.items()}
         out["hit_pixels"] = hits
@@ -292,10 +322,10 @@ def main():
             gbs = kbk * ipb / (v * 1e-3) / 1e9
             out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipb / 1e6, 3), "GBs": round(gbs, 1),
                                  "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                 "traffic_MB": round(pmc[k] / 1e6, 3) if (k in pmc and ipg == 1) else None}
+                                 "traffic_MB": round(pmc[k] / 1e6, 3) if k in pmc else None}
         out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
         out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
-        if ipg == 1 and pmc:
+        if pmc:
             step_traffic = sum(pmc.get(k, 0.0) for k in acc)
             out["step_traffic_MB"] = round(step_traffic / 1e6, 3)
             out["step_traffic_frac"] = step_traffic * value / world / 1e9 / HBM_PEAK_GBS
@@ -305,7 +335,9 @@ def main():
             # the headline line above
             for key, fn in (("batched", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("batched_f16_gbuffer", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)),
-                            ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev))):
+                            ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev)),
+                            ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
+                            ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev))):
                 try:
                     out[key] = fn()
                 except Exception as e:  # noqa: BLE001
@@ -339,8 +371,63 @@ def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, step
     m = group.batches[0].meta[0]
     bstep = algorithmic_bytes(H, W, m["Vh"], m["Vo"], m["Fh"], m["Fo"])
     v = n_img * steps / dt
-    return {"images_per_gpu": n_img, "streams": 4, "steps": steps, "gbuf_f16": bool(gbuf_f16), "value": v, "unit": "guidance-steps/s",
-            "ms_per_batch_step": dt * 1e3 / steps, "step_roofline_frac": bstep * v / 1e9 / HBM_PEAK_GBS}
+    rec = {"images_per_gpu": n_img, "streams": 4, "steps": steps, "gbuf_f16": bool(gbuf_f16), "value": v, "unit": "guidance-steps/s",
+           "ms_per_batch_step": dt * 1e3 / steps, "step_roofline_frac": bstep * v / 1e9 / HBM_PEAK_GBS}
+    # bytes actually moved per image and step in the batch regime: rocprofv3 PMC passes over ONE 8-image batch on one stream
+    pmc, src = pmc_table((args.obj, args.size, 8))
+    if pmc and not gbuf_f16:
+        per_image = sum(pmc.values()) / 8.0
+        rec.update(step_traffic_MB_per_image=round(per_image / 1e6, 3), step_traffic_frac=per_image * v / 1e9 / HBM_PEAK_GBS,
+                   traffic_source=src)
+    return rec
+
+
+def obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg, steps=1000):
+    """The literal reading of the metric's "778 + 20k VERTS": the 20 160-vertex / 40 320-face torus (configs[3]'s object) with
+    one hand, one image, 50-iteration graphs -- the headline line follows north_star / configs[1]'s "~20k-FACE" object."""
+    H = W = args.size
+    scene = synthetic.build_scene(render_fn, obj_kind="40k", H=H, W=W, seed=0)
+    group, run_steps = make_runner(E, torch, [scene], 1, dev, cfg, 50)
+    run_steps(100)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run_steps(steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    group.batches[0].raise_on_flags()
+    m = group.batches[0].meta[0]
+    bstep = algorithmic_bytes(H, W, m["Vh"], m["Vo"], m["Fh"], m["Fo"])
+    v = steps / dt
+    return {"workload": f"single {H}x{W} frame, {m['Vh']}-vert hand + {m['Vo']}-vert/{m['Fo']}-face object", "steps": steps,
+            "value": v, "unit": "guidance-steps/s", "ms_per_step": dt * 1e3 / steps, "step_roofline_frac": bstep * v / 1e9 / HBM_PEAK_GBS}
+
+
+def job_record(E, torch, synthetic, render_fn, args, dev):
+    """The per-image JOB behind the product entry point (`python -m foho.guidance.run` with FOHO_MESH_LEVEL_GUIDANCE=1 ->
+    inputs.MeshGuidanceRunner): the reference's whole schedule -- 200 hand + 100 object + 9 x 50 joint iterations = 750 per
+    image (CFG:11-13, PL:1293-1610) -- for images already in host memory, including the upload of every image set, the
+    installation of its objects on the device and the export read-back; graphs are captured by a first, untimed image set
+    (once per process).  Images per second and GPU at 1 and at 8 images in flight."""
+    from followmyhold_amd import inputs
+    H = W = args.size
+    cfg0 = E.OptimizationConfig()
+    n_iter = sum(it for _, it, _ in inputs.job_schedule(cfg0))
+    rec = {"iterations_per_image": n_iter, "schedule": "200 A + 100 B + 9 x 50 C", "unit": "images/s"}
+    scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=200 + j) for j in range(8)]
+    for in_flight, n_img in ((1, 4), (8, 16)):
+        runner = inputs.MeshGuidanceRunner(cfg0, device=dev, in_flight=in_flight)
+        res = runner.run(scenes[:in_flight])              # captures (untimed: once per process)
+        torch.cuda.synchronize(dev)
+        todo = [scenes[j % 8] for j in range(n_img)]
+        t0 = time.perf_counter()
+        res = runner.run(todo)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ok = sum(1 for r in res if r["ok"])
+        rec[f"in_flight_{in_flight}"] = {"images": n_img, "ok": ok, "images_per_s": n_img / dt, "ms_per_image": dt * 1e3 / n_img,
+                                         "guidance_steps_per_s": n_img * n_iter / dt, "streams": runner.n_streams,
+                                         "graph_captures": runner.stats["captures"], "groups_built": runner.stats["groups_built"]}
+    return rec
 
 
 def topology_record(E, torch, scene, dev, steps=200):

@@ -11,6 +11,11 @@ all-reduce(SUM) of the metrics vector (followmyhold_amd.sharding.METRIC_NAMES; R
 print the batch totals.  There is no collective on the data path.  FOHO_DIST_BACKEND=gloo runs the same code with a
 CPU-side reduce (several ranks on one GPU / no GPU: tests).
 
+With FOHO_MESH_LEVEL_GUIDANCE=1 (fixed object meshes, no diffusion networks) the rank's images do not go one by one: `run()`
+hands them to followmyhold_amd.inputs.MeshGuidanceRunner, FOHO_IMAGES_IN_FLIGHT (default 8) at a time -- several images per
+kernel launch on several HIP streams, graphs captured once per process -- with the reference's per-image skip rules and
+error isolation kept (an image that fails is reported and the others go on).
+
 `run_hunyuan_w_guid` runs followmyhold_amd.pipeline.GuidedShapePipeline -- the patched Hunyuan pipeline's __call__ with
 the guidance arithmetic on HIP -- over the Hunyuan3D-2 DiT + ShapeVAE (PyTorch networks outside the hot path, SURVEY.md
 8(a) A20), which are looked up at call time; without hy3dgen a clear error is raised unless FOHO_STANDIN_NETWORKS=1
@@ -244,12 +249,124 @@ def _mesh_level_guidance(fovx, hamer_for_guid_path, aligned_mano_mesh_path, crop
              T_h2m_path=T_h2m_path, aligned_mano_mesh_path=aligned_mano_mesh_path,
              hunyuan_hoi_mesh_path=hunyuan_hoi_mesh_path, hamer_for_guid_path=hamer_for_guid_path)
     scene = inputs.load_scene_from_files(p, inputs.load_j_regressor(), E.hip_render_fn(device))
-    scene["fov"] = float(fovx)
+    if fovx is not None:
+        scene["fov"] = float(fovx)
     gb = inputs.run_mesh_guidance([scene], config, device=device)
-    n_iter = int(config.optimization_steps_hand) + int(config.optimization_steps_scale) + \
-        int(config.optimization_steps_joint) * max(0, int(config.num_inference_steps) - int(config.guidance_start_step) - 1)
-    _tally(sharding.local_metrics(gb, n_steps=n_iter, wall_ms=0.0).cpu().numpy())
+    _tally(sharding.local_metrics(gb, n_steps=_n_iterations(config), wall_ms=0.0).cpu().numpy())
     return inputs.export_meshes(gb, 0, save_path_obj, save_path_hand)
+
+
+def _n_iterations(config) -> int:
+    return int(config.optimization_steps_hand) + int(config.optimization_steps_scale) + \
+        int(config.optimization_steps_joint) * max(0, int(config.num_inference_steps) - int(config.guidance_start_step) - 1)
+
+
+def _mesh_level_batched() -> bool:
+    """True when run() should take the rank's images through MeshGuidanceRunner: mesh-level guidance was asked for and the
+    networks are not there (with them, every image is a full pipeline call and stays one at a time like RUN:208-259)."""
+    if os.environ.get("FOHO_MESH_LEVEL_GUIDANCE") != "1" or os.environ.get("FOHO_STANDIN_NETWORKS") == "1":
+        return False
+    if int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "8")) < 1:
+        return False
+    try:
+        import hy3dgen.shapegen  # noqa: F401
+        return False
+    except ImportError:
+        return True
+
+
+def _screen(cropped_obj_img, dirs):
+    """RUN:210-236 for one list entry: paths, skip rules, fov.  Returns (paths, fovx) or None when the image is skipped."""
+    p = derive_paths(cropped_obj_img, **dirs)
+    index = p["index"]
+    if os.path.exists(p["save_path_obj"]) and os.path.exists(p["save_path_hand"]):
+        print(f"{index} already exists, skipping")
+        return None
+    with open(p["moge_fov_path"], "r", encoding="utf-8") as f:
+        fovx = float(json.load(f)["fov_x"])
+    if _read_mask(p["cropped_hand_mask_path"]).max() == 0 or _read_mask(p["cropped_obj_mask_path"]).max() == 0:
+        print(f"Skipping {index} due to empty mask")
+        return None
+    return p, fovx
+
+
+def _run_batched(assigned_imgs, dirs, config, device) -> None:
+    """The per-image body of RUN:208-259 for the mesh-level path, FOHO_IMAGES_IN_FLIGHT images at a time.  Failures stay
+    per image: a file that does not load, an image the runner hands back (object not a closed manifold -> the exact-size
+    single-image driver), a NaN in phase B (the reference's pipeline returns None there, PL:1442-1444, which surfaces as
+    "Error in processing")."""
+    from followmyhold_amd import engine as E
+    from followmyhold_amd import inputs
+    in_flight = int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "8"))
+    runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
+    jr, render_fn = None, None
+    n_iter = _n_iterations(config)
+    pending = []                     # (list entry, paths, scene)
+
+    def fail(name, e):
+        print(f"Error in processing {name} : {e}")
+        _tally_named(n_failed=1)
+
+    def finish(name, p, res):
+        if not res["ok"] and res.get("reason") == "fallback":      # any mesh goes through the exact-size driver
+            res = None
+            obj_mesh, hand_mesh = _mesh_level_guidance(
+                None, p["hamer_for_guid_path"], p["aligned_mano_mesh_path"], p["cropped_obj_mask_path"], p["cropped_hand_mask_path"],
+                p["moge_mesh_path"], p["T_h2m_path"], p["hunyuan_hoi_mesh_path"], p["save_path_obj"], p["save_path_hand"], config, device)
+        else:
+            if not res["ok"]:
+                raise RuntimeError(res["reason"])
+            if res["nan_in_phase_b"]:
+                raise TypeError("cannot unpack non-iterable NoneType object")     # what RUN:141 raises on PL:1442-1444's `return None`
+            obj_mesh, hand_mesh = inputs.export_result(res, p["save_path_obj"], p["save_path_hand"])
+            _tally(sharding.image_metrics(res["losses_row"], res["flags"], n_iter))
+        if len(obj_mesh[0]) == 0:
+            print(f"Empty mesh for {p['cropped_obj_img_path']}")
+            print(f"Error in reconstruction for {p['index']}")
+            return
+        print(f"Reconstructed object {p['index']}")
+
+    def flush():
+        if not pending:
+            return
+        names, paths, scenes = zip(*pending)
+        pending.clear()
+        try:
+            results = runner.run(list(scenes))
+        except Exception as e:  # noqa: BLE001 -- the image set as a whole failed: every image gets its own try, one at a time
+            print(f"Image set of {len(names)} failed as a whole ({e}); retrying its images one by one")
+            results = [dict(ok=False, reason="fallback") for _ in names]
+        for name, p, res in zip(names, paths, results):
+            try:
+                finish(name, p, res)
+            except Exception as e:  # noqa: BLE001 -- RUN:257-259
+                fail(name, e)
+
+    for cropped_obj_img in assigned_imgs:
+        try:
+            scr = _screen(cropped_obj_img, dirs)
+            if scr is None:
+                continue
+            p, fovx = scr
+            print(f"Processing {p['index']}")
+            if jr is None:
+                jr, render_fn = inputs.load_j_regressor(), E.hip_render_fn(device)
+            scene = inputs.load_scene_from_files(p, jr, render_fn)
+            scene["fov"] = float(fovx)
+            pending.append((cropped_obj_img, p, scene))
+        except Exception as e:  # noqa: BLE001 -- RUN:257-259
+            fail(cropped_obj_img, e)
+            continue
+        if len(pending) >= in_flight:
+            flush()
+    flush()
+
+
+def _tally_named(**kw) -> None:
+    v = np.zeros(len(sharding.METRIC_NAMES), np.float64)
+    for k, x in kw.items():
+        v[sharding.IDX[k]] = x
+    _tally(v)
 
 
 def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir: str, hunyuan_hoi_mesh_dir: str,
@@ -259,23 +376,44 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
     _METRICS = np.zeros(len(sharding.METRIC_NAMES), np.float64)
     _setup_sys_path(project_root)
     rank, world, device, dist, created = _dist_setup()
-    config = OptimizationConfig()
-    os.makedirs(guidance_out_dir, exist_ok=True)
-    assigned_imgs = _load_task_list(task_list_file, cropped_obj_img_dir)   # this rank's share when WORLD_SIZE > 1
+    # Every rank must reach the end-of-batch all-reduce, whatever happens to its own share of the list: the body below
+    # runs under try/finally, a rank that failed outside the per-image handlers contributes its tally (n_failed > 0) and
+    # re-raises after the collective instead of leaving the others waiting for the RCCL timeout.
     t_start = time.perf_counter()
+    error = None
+    try:
+        config = OptimizationConfig()
+        os.makedirs(guidance_out_dir, exist_ok=True)
+        assigned_imgs = _load_task_list(task_list_file, cropped_obj_img_dir)   # this rank's share when WORLD_SIZE > 1
+        dirs = dict(cropped_obj_img_dir=cropped_obj_img_dir, mask_dir=mask_dir, moge_out_dir=moge_out_dir,
+                    hunyuan_hoi_mesh_dir=hunyuan_hoi_mesh_dir, hamer_out_dir=hamer_out_dir, h2m_rt_dir=h2m_rt_dir,
+                    aligned_mano_dir=aligned_mano_dir, guidance_out_dir=guidance_out_dir)
+        if _mesh_level_batched():
+            _run_batched(assigned_imgs, dirs, config, device)
+        else:
+            _run_one_by_one(assigned_imgs, dirs, config)
+        print("Finished processing all images")
+    except BaseException as e:  # noqa: BLE001 -- reported after the collective
+        error = e
+        _tally_named(n_failed=1)
+    _tally_named(sum_wall_ms=(time.perf_counter() - t_start) * 1e3)
+    try:
+        out = _reduce_and_report(rank, world, device, dist, created)
+    finally:
+        if error is not None:
+            raise error
+    return out
+
+
+def _run_one_by_one(assigned_imgs, dirs, config) -> None:
+    """RUN:208-259: one image at a time through run_hunyuan_w_guid (the full pipeline with the networks in the loop)."""
     for cropped_obj_img in assigned_imgs:
         try:
-            p = derive_paths(cropped_obj_img, cropped_obj_img_dir, mask_dir, moge_out_dir, hunyuan_hoi_mesh_dir,
-                             hamer_out_dir, h2m_rt_dir, aligned_mano_dir, guidance_out_dir)
+            scr = _screen(cropped_obj_img, dirs)
+            if scr is None:
+                continue
+            p, fovx = scr
             index = p["index"]
-            if os.path.exists(p["save_path_obj"]) and os.path.exists(p["save_path_hand"]):
-                print(f"{index} already exists, skipping")
-                continue
-            with open(p["moge_fov_path"], "r", encoding="utf-8") as f:
-                fovx = float(json.load(f)["fov_x"])
-            if _read_mask(p["cropped_hand_mask_path"]).max() == 0 or _read_mask(p["cropped_obj_mask_path"]).max() == 0:
-                print(f"Skipping {index} due to empty mask")
-                continue
             print(f"Processing {index}")
             obj_mesh, hand_mesh = run_hunyuan_w_guid(
                 cropped_obj_img_path=p["cropped_obj_img_path"], fovx=fovx, hamer_for_guid_path=p["hamer_for_guid_path"],
@@ -287,12 +425,10 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                 print(f"Error in reconstruction for {index}")
                 continue
             print(f"Reconstructed object {index}")
-        except Exception as e:  # RUN:257-259
+        except Exception as e:  # noqa: BLE001 -- RUN:257-259
             print(f"Error in processing {cropped_obj_img} : {e}")
+            _tally_named(n_failed=1)
             continue
-    _tally([0.0] * 12 + [(time.perf_counter() - t_start) * 1e3, 0.0, 0.0])
-    print("Finished processing all images")
-    return _reduce_and_report(rank, world, device, dist, created)
 
 
 def build_parser() -> argparse.ArgumentParser:

@@ -44,7 +44,7 @@ class FohoStepCfg(ctypes.Structure):
                 ("use_intersection", c_i), ("w_int_near", c_f), ("w_int_far", c_f), ("int_gate", c_f),
                 ("int_gate_step_ok", c_i), ("sigma", c_f), ("gamma", c_f), ("blur_radius", c_f),
                 ("lr", c_f * 16), ("beta1", c_f), ("beta2", c_f), ("eps", c_f), ("weight_decay", c_f),
-                ("do_update", c_i), ("world_space_input", c_i), ("deferred_update", c_i)]
+                ("do_update", c_i), ("world_space_input", c_i), ("deferred_update", c_i), ("n_active_renders", c_i)]
 
 
 class FohoStepDesc(ctypes.Structure):

@@ -143,7 +143,7 @@ constexpr int SIM_ACC = 40;            // floats per image and parity in the def
 constexpr int STATE_NEXT = 64;         // floats per image in the deferred-update staging area
 constexpr int PIX_BWD_TILE_BLOCKS = 256;
 constexpr int BWD_SPLIT = 4;             // a dense 32x8 tile is handed to k_pix_bwd as up to 4 bands of pixel rows  // k_pix_bwd workgroups per (render, image) walking the hit-tile list
-constexpr int BWD_SLOTS = 512;        // LDS hash slots: a work-list entry holds at most 128 hit pixels (band split), i.e. <= 384 distinct vertices
+constexpr int BWD_SLOTS = 512;        // LDS hash slots: a work-list entry holds at most 160 hit pixels (k_resolve's band split), i.e. <= 480 distinct vertices
 
 struct MeshInfo {  // per (image, mesh): AABB of the INPUT vertices, recomputed by FOHO_STAGE_BBOX only
     unsigned long long kmin_inv[3];  // ~(ordered value << 32 | index), atomicMax  -> min value, lowest index
@@ -330,10 +330,12 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
 }
 
 // One (vertex, incident face) pair in 8 bytes: v0 in 22 bits, v1 - v0 and v2 - v0 biased by 2^19 in 20 bits each (a face's
-// vertices belong to one image: |difference| < 262144), the corner in the top 2 bits.  Needs Vtot <= 2^22 (checked on the host).
+// vertices belong to one image, and an image holds fewer than 2^19 vertices: |difference| < 524288), the corner in the top
+// 2 bits.  Needs Vtot <= 2^22 and Vmax < 2^19 (both checked on the host: pair_limits_ok); the fields are masked, so an id
+// outside those limits can never spill into the neighbouring field.
 __device__ __forceinline__ unsigned long long pack_pair(int v0, int v1, int v2, int corner) {
-    return (unsigned long long)(unsigned)v0 | ((unsigned long long)(unsigned)(v1 - v0 + (1 << 19)) << 22) |
-           ((unsigned long long)(unsigned)(v2 - v0 + (1 << 19)) << 42) | ((unsigned long long)(corner & 3) << 62);
+    return (unsigned long long)((unsigned)v0 & 0x3FFFFFu) | ((unsigned long long)((unsigned)(v1 - v0 + (1 << 19)) & 0xFFFFFu) << 22) |
+           ((unsigned long long)((unsigned)(v2 - v0 + (1 << 19)) & 0xFFFFFu) << 42) | ((unsigned long long)(corner & 3) << 62);
 }
 __device__ __forceinline__ void unpack_pair(unsigned long long p, int v[3], int& corner) {
     v[0] = (int)(p & 0x3FFFFFu);

@@ -159,6 +159,9 @@ def phase_cfg(phase, config=None, denoise_i=19, do_update=True, sigma=1e-8, gamm
         raise ValueError(f"Unknown phase {phase}. Expected 'A' (hand only), 'B' (object only) or 'C' (joint).")
     for i, v in enumerate(lr):
         c.lr[i] = v
+    # phases A and B run ONE render on whatever the workspace is laid out for (no re-allocation between the phases of a
+    # job), and roles without a weight in this recipe are not launched (foho_step_cfg.n_active_renders)
+    c.n_active_renders = n_renders
     return c, n_renders
 
 
@@ -334,7 +337,10 @@ class GuidanceBatch:
         return m["v_off"] + m["Vh"], m.get("Vcap", m["Vo"])
 
     def set_n_renders(self, n):
-        if n != self.dims.n_renders:
+        """Make sure the workspace holds `n` renders.  It only ever grows: a step whose cfg activates fewer renders
+        (foho_step_cfg.n_active_renders, set by phase_cfg) runs on the larger layout as it is, so the phases of a job share
+        one workspace -- AABB, pair table, clean scatter planes and static target sums included."""
+        if n > self.dims.n_renders:
             self.dims.n_renders = n
             self._alloc_workspace()
 
@@ -358,6 +364,93 @@ class GuidanceBatch:
         assert off >= 0
         v = self.workspace[off:off + n.value].view(dtype)
         return v.reshape(shape) if shape is not None else v
+
+    def prepare(self, stream=None):
+        """Run the per-input stages the step relies on (AABB / pair table / clean planes: FOHO_STAGE_BBOX; static sums of the
+        target maps: FOHO_STAGE_TARGETS) now, eagerly, if they are due -- a captured hipGraph only holds the step itself."""
+        stages = 0
+        if self._bbox_dirty:
+            stages |= L.STAGE_BBOX
+            self._bbox_dirty = False
+        if self._targets_dirty:
+            stages |= L.STAGE_TARGETS
+            self._targets_dirty = False
+        if stages:
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+            cfg, _ = phase_cfg("C", do_update=False)
+            L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(stages), ctypes.c_void_p(stream)),
+                    "foho_step_run(prepare)")
+
+    def fits(self, scenes):
+        """True when `scenes` can be loaded into this (capacity-mode) batch in place."""
+        if self.obj_capacity is None or len(scenes) != self.B:
+            return False
+        vcap, fcap = self.obj_capacity
+        for s, m in zip(scenes, self.meta):
+            if (int(s["H"]), int(s["W"])) != (self.H, self.W) or len(s["hand_verts"]) != m["Vh"] or len(s["hand_faces"]) != m["Fh"]:
+                return False
+            if len(s["obj_verts"]) > vcap or len(s["obj_faces"]) > fcap or np.asarray(s["J_regressor"]).shape[1] != self.J.shape[1]:
+                return False
+        return True
+
+    def load_scenes(self, scenes):
+        """CAPACITY MODE: put B new images into this batch IN PLACE -- same buffers, same addresses, so every hipGraph captured
+        on it stays valid and a per-image job pays for its captures once per process, not once per image (the reference
+        rebuilds renderer, pipeline and optimisers per image, RUN:140).  Geometry, camera, targets and key points are
+        overwritten, the objects (any vertex / face count within the capacity) are installed on the device
+        (foho_object_update: image records, topology tables, pair table, AABB), pose parameters return to the identity
+        (PL:1207-1215) and the optimiser is reset.  Asynchronous on the current stream after the host-to-device copies.
+        `load_flags` keeps what the installation reported (bit 4 capacity, bit 5 not a closed manifold, bit 6 empty)."""
+        if not self.fits(scenes):
+            raise L.FohoError("load_scenes: needs a capacity-mode batch and scenes of the same image size / hand topology "
+                              "whose objects fit the capacity")
+        dev = self.device
+        vcap, fcap = self.obj_capacity
+        verts = np.zeros((self.Vtot, 3), np.float32)
+        hfaces = []
+        faces64 = np.zeros((self.B, fcap, 3), np.int64)
+        counts = np.zeros((self.B, 3), np.int32)
+        for b, (s, m, im) in enumerate(zip(scenes, self.meta, self._images_host)):
+            ov, of = np.asarray(s["obj_verts"], np.float32).reshape(-1, 3), np.asarray(s["obj_faces"], np.int64).reshape(-1, 3)
+            nv, nf = len(ov), len(of)
+            lo = m["v_off"]
+            verts[lo:lo + m["Vh"]] = np.asarray(s["hand_verts"], np.float32)
+            verts[lo + m["Vh"]:lo + m["Vh"] + nv] = ov
+            hfaces.append(np.asarray(s["hand_faces"], np.int64) + lo)
+            faces64[b, :nf] = of
+            counts[b, :2] = (nv, nf)
+            m.update(Vo=nv, Fo=nf, n_edges=3 * nf // 2)
+            im.k00, im.k11 = fov_focal(float(s["fov"]))
+            R = np.asarray(s.get("cam_R", np.diag([-1.0, 1.0, -1.0])), np.float32).reshape(-1)
+            T = np.asarray(s.get("cam_T", np.zeros(3)), np.float32)
+            M = np.asarray(s["T_h2m"], np.float32)[:3, :4].reshape(-1)
+            for k in range(9):
+                im.cam_R[k] = float(R[k])
+            for k in range(3):
+                im.cam_T[k] = float(T[k])
+            for k in range(12):
+                im.T_h2m[k] = float(M[k])
+            im.Vo = im.Fo = im.n_edges = 0        # the device-side records get the actual counts from foho_object_update
+        up = lambda dst, a: dst.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(dst.dtype), non_blocking=False)
+        up(self.verts_in, verts)
+        for m, hf in zip(self.meta, hfaces):
+            up(self.faces[m["f_off"]:m["f_off"] + m["Fh"]], hf)
+        up(self.obj_faces64, faces64)
+        up(self.obj_counts, counts)
+        up(self.images, np.frombuffer(b"".join(bytes(im) for im in self._images_host), np.uint8))
+        up(self.tgt_normal, np.stack([s["moge_normal"] for s in scenes]))
+        up(self.tgt_disp, np.stack([s["moge_disp"] for s in scenes]))
+        up(self.mask, np.stack([(np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1))
+                                for s in scenes]))
+        up(self.kps_2d, np.stack([s["kps_2d"] for s in scenes]))
+        up(self.params, np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1)))
+        self.reset_optimizer()
+        self.adopt_objects()
+        self.load_flags = self.flags.clone()
+        self.flags.zero_()
+        self._targets_dirty = True
+        self.prepare()
 
     # ------------------------------------------------------------------ state
     def reset_optimizer(self):
@@ -589,10 +682,7 @@ class GuidanceBatch:
         the iteration the way it runs inside a multi-iteration hipGraph (foho_step_cfg.deferred_update: the final stage of
         an iteration rides in the next k_xform); a finalize closes the pair."""
         lib = self.lib
-        if self._bbox_dirty:
-            self.refresh_bbox()
-        if self._targets_dirty:
-            self.step(cfg, stages=0)     # FOHO_STAGE_TARGETS only
+        self.prepare()
         lib.foho_step_run_profiled.restype = ctypes.c_int
         lib.foho_kernel_name.restype = ctypes.c_char_p
         ms = (ctypes.c_float * L.N_KERNELS)()
@@ -822,6 +912,26 @@ class GuidanceGroup:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+
+    def _chunks(self, scenes):
+        out, i = [], 0
+        for gb in self.batches:
+            out.append(scenes[i:i + gb.B])
+            i += gb.B
+        return out if i == len(scenes) else None
+
+    def fits(self, scenes):
+        ch = self._chunks(scenes)
+        return ch is not None and all(gb.fits(c) for gb, c in zip(self.batches, ch))
+
+    def load_scenes(self, scenes):
+        """Capacity-mode groups: new images into the existing batches, in place (GuidanceBatch.load_scenes), each on its own
+        stream; captured graphs stay valid."""
+        if not self.fits(scenes):
+            raise L.FohoError("GuidanceGroup.load_scenes: the scenes do not fit this group (count, image size, hand topology, capacity)")
+        for gb, st, c in zip(self.batches, self.streams, self._chunks(scenes)):
+            with torch.cuda.stream(st):
+                gb.load_scenes(c)
 
 
 def normal_map(gb, face_set, r=0, b=0, sigma=1e-8):

@@ -244,48 +244,199 @@ def save_scene_files(scene, moge_verts, moge_faces, dirs, index, hand_verts_huny
 
 
 # ------------------------------------------------------------------------------------------------ driver
-def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None):
-    """Phases A (hand), B (object), C (joint) of PL:1293-1610 for a batch of scenes on fixed object meshes.
+def job_schedule(config):
+    """The reference's iteration schedule of one image (PL:1293-1610) as [(phase, iterations, denoising step)]: phase A at
+    `handopt_start_step`, phase B at `guidance_start_step`, phase C at every later denoising step."""
+    a_step, b_step, n_steps = int(config.handopt_start_step), int(config.guidance_start_step), int(config.num_inference_steps)
+    sched = [("A", int(config.optimization_steps_hand), a_step), ("B", int(config.optimization_steps_scale), b_step)]
+    sched += [("C", int(config.optimization_steps_joint), i) for i in range(b_step + 1, n_steps)]
+    return sched
 
-    Iteration counts and the guidance window come from the reference's OptimizationConfig: phase A at denoising
-    step `handopt_start_step`, phase B at `guidance_start_step`, phase C at every later step, each with a fresh
+
+def _steps_per_graph(iters):
+    # iterations per hipGraph replay: a capture costs the device ~30 us of idle time per iteration recorded, a replay
+    # boundary ~10 us -- 10 iterations per graph beat 50 (44.9 against 47.5 ms per job)
+    return max([d for d in range(1, 11) if iters % d == 0]) if iters > 0 else 1
+
+
+def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None):
+    """Phases A (hand), B (object), C (joint) of PL:1293-1610 for ONE exact-size batch of scenes on fixed object meshes
+    (any mesh: open, non-manifold -- the topology tables come from the host builders when the device ones refuse).  The
+    product driver goes through `MeshGuidanceRunner` (images in flight on several streams, graphs captured once per
+    process) and falls back to this function for images the runner cannot take.
+
+    Iteration counts and the guidance window come from the reference's OptimizationConfig, each loop with a fresh
     optimiser (PL:1318, 1384, 1478).  Returns the GuidanceBatch (parameters, losses, world-space vertices)."""
     import torch
     from . import engine as E
     cfg0 = config if config is not None else E.OptimizationConfig()
     gb = E.GuidanceBatch(scenes, device=device, n_renders=2)
-    n_steps = int(cfg0.num_inference_steps)
-    a_step, b_step = int(cfg0.handopt_start_step), int(cfg0.guidance_start_step)
-
+    gb.prepare()
     graphs = {}     # the nine joint loops only differ in the intersection gate (denoising steps >= 17): two captures, not nine
-
-    def loop(phase, iters, denoise_i):
-        cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=denoise_i, do_update=True)
-        gb.set_n_renders(n_renders)
-        gb.reset_optimizer()
-        iters_ = int(iters)
-        # iterations per hipGraph replay: a capture costs the device ~30 us of idle time per iteration recorded and happens four
-        # times per job, a replay boundary ~10 us -- 10 iterations per graph beat 50 (44.9 against 47.5 ms per job)
-        spg = max([d for d in range(1, 11) if iters_ % d == 0]) if iters_ > 0 else 1
+    for phase, iters, denoise_i in job_schedule(cfg0):
+        cfg, _ = E.phase_cfg(phase, cfg0, denoise_i=denoise_i, do_update=True)   # one workspace for all phases (n_active_renders)
+        spg = _steps_per_graph(iters)
         graph = None
         if capture:
-            key = (bytes(cfg), spg, gb.workspace.data_ptr())
+            key = (bytes(cfg), spg)
             if key not in graphs:
                 graphs[key] = gb.capture(cfg, steps_per_graph=spg)
             graph = graphs[key]
         gb.reset_optimizer()
-        for _ in range(iters_ // spg if graph is not None else iters_):
+        for _ in range(iters // spg if graph is not None else iters):
             graph.replay() if graph is not None else gb.step(cfg)
         torch.cuda.synchronize(gb.device)
         gb.raise_on_flags(strict_k=False)
         if log is not None:
             log(phase, denoise_i, [gb.loss_dict(b)["total"] for b in range(gb.B)])
-
-    loop("A", cfg0.optimization_steps_hand, a_step)
-    loop("B", cfg0.optimization_steps_scale, b_step)
-    for i in range(b_step + 1, n_steps):
-        loop("C", cfg0.optimization_steps_joint, i)
     return gb
+
+
+class MeshGuidanceRunner:
+    """The mesh-level guidance job for MANY images per GPU ("within a GPU, batch the rank's images through
+    each kernel launch"; the reference walks its list one image at a time with batch size 1, RUN:208-259, CFG:9).
+
+    `in_flight` images are optimised at once: `n_streams` independent capacity-mode GuidanceBatch slots (engine.
+    GuidanceGroup), each with its own HIP stream and its own hipGraphs.  A new set of images is loaded INTO the slots
+    (GuidanceBatch.load_scenes: same buffers, objects installed on the device), so the graphs of the schedule -- phase A,
+    phase B, phase C with and without the intersection gate -- are captured once per process, not once per image, and no
+    workspace is re-allocated between phases (foho_step_cfg.n_active_renders).  No host synchronisation inside an image
+    set: NaN break, optimiser state and flags live on the device; flags of every loop are OR-ed into `flags_seen`.
+
+    run(scenes) -> one result per scene: dict(ok, flags, losses (dict of the last step), params (16,), hand (verts, faces),
+    obj (verts, faces), nan_in_phase_b).  Scenes the slots cannot take (other image size / hand topology) and images whose
+    object is not a closed manifold (device-side edge tables refuse: flag bit 5) are reported with ok=False,
+    reason="fallback": the caller runs them through `run_mesh_guidance`."""
+
+    def __init__(self, config=None, device="cuda", in_flight=8, n_streams=None, grid_res=64):
+        from . import engine as E
+        self.E = E
+        self.config = config if config is not None else E.OptimizationConfig()
+        self.device = device
+        self.in_flight = max(1, int(in_flight))
+        # two images per stream, at most four streams: the setting bench.py's `batched` record measures (DESIGN.md section 6)
+        self.n_streams = int(n_streams) if n_streams else max(1, min(4, (self.in_flight + 1) // 2))
+        self.grid_res = grid_res
+        self.group = None
+        self.graphs = {}
+        self.stats = dict(captures=0, groups_built=0, image_sets=0)
+
+    # -------------------------------------------------------------------------------------------- slots
+    @staticmethod
+    def _capacity(scenes):
+        rnd = lambda x, q: ((int(x) + q - 1) // q) * q
+        return (rnd(max(len(s["obj_verts"]) for s in scenes) * 1.125 + 1, 1024), rnd(max(len(s["obj_faces"]) for s in scenes) * 1.125 + 2, 2048))
+
+    def _group_for(self, scenes):
+        """A group whose slots take `scenes` (exactly in_flight of them); rebuilt -- graphs and all -- when they do not fit."""
+        if self.group is not None and self.group.fits(scenes):
+            return self.group
+        cap = self._capacity(scenes)
+        if self.group is not None:      # keep the larger of the old and the new capacity: sizes drift, they do not alternate
+            old = self.group.batches[0].obj_capacity
+            cap = (max(cap[0], old[0]), max(cap[1], old[1]))
+        self.group = self.E.GuidanceGroup(scenes, self.n_streams, device=self.device, grid_res=self.grid_res, n_renders=2,
+                                          obj_capacity=cap)
+        self.graphs = {}
+        self.stats["groups_built"] += 1
+        return self.group
+
+    def _graphs_for(self, group, cfg, spg):
+        key = (bytes(cfg), spg)
+        g = self.graphs.get(key)
+        if g is None:
+            import torch
+            g = []
+            for gb, st in zip(group.batches, group.streams):
+                with torch.cuda.stream(st):
+                    g.append(gb.capture(cfg, steps_per_graph=spg))
+            self.graphs[key] = g
+            self.stats["captures"] += 1
+        return g
+
+    # -------------------------------------------------------------------------------------------- one image set
+    def _run_set(self, scenes, log):
+        import torch
+        E = self.E
+        group = self._group_for(scenes)
+        group.load_scenes(scenes)
+        seen, nan_b = [], []
+        for gb, st in zip(group.batches, group.streams):       # per-slot tensors live on the slot's stream
+            with torch.cuda.stream(st):
+                seen.append(gb.load_flags.clone())
+                nan_b.append(torch.zeros_like(gb.flags))
+        for phase, iters, denoise_i in job_schedule(self.config):
+            cfg, _ = E.phase_cfg(phase, self.config, denoise_i=denoise_i, do_update=True)
+            spg = _steps_per_graph(iters)
+            graphs = self._graphs_for(group, cfg, spg)
+            for gb, st in zip(group.batches, group.streams):
+                with torch.cuda.stream(st):
+                    gb.reset_optimizer()
+            for _ in range(iters // spg):       # streams interleaved: every slot's replay k is queued before any replay k + 1
+                for g, st in zip(graphs, group.streams):
+                    with torch.cuda.stream(st):
+                        g.replay()
+            for k, (gb, st) in enumerate(zip(group.batches, group.streams)):
+                with torch.cuda.stream(st):
+                    seen[k] |= gb.flags
+                    if phase == "B":
+                        nan_b[k].copy_(gb.flags & 1)
+            if log is not None:
+                group.synchronize()
+                log(phase, denoise_i, [gb.loss_dict(b)["total"] for gb in group.batches for b in range(gb.B)])
+        group.synchronize()
+        self.stats["image_sets"] += 1
+        out = []
+        for k, gb in enumerate(group.batches):
+            fl = seen[k].cpu().numpy()
+            nb = nan_b[k].cpu().numpy()
+            losses = gb.losses.detach().cpu().numpy()
+            params = gb.params.detach().cpu().numpy()
+            world = gb.region("world", torch.float32, (-1, 3)).detach().cpu().numpy()
+            faces = gb.faces.detach().cpu().numpy().astype(np.int64)
+            for b in range(gb.B):
+                m = gb.meta[b]
+                hv = world[m["v_off"]:m["v_off"] + m["Vh"]].copy()
+                ov = world[m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]].copy()
+                hf = faces[m["f_off"]:m["f_off"] + m["Fh"]] - m["v_off"]
+                of = faces[m["f_off"] + m["Fh"]:m["f_off"] + m["Fh"] + m["Fo"]] - m["v_off"] - m["Vh"]
+                f = int(fl[b])
+                res = dict(ok=True, flags=f, losses=dict(zip(E.L.LOSS_NAMES, losses[b].tolist())), losses_row=losses[b].copy(),
+                           params=params[b].copy(), hand=(hv, hf), obj=(ov, of), nan_in_phase_b=bool(nb[b]))
+                if f & (16 | 32):       # capacity (cannot happen: sized from the scenes) / not a closed manifold
+                    res.update(ok=False, reason="fallback")
+                elif f & 2:
+                    res.update(ok=False, reason="fractional-coverage fragment list overflowed")
+                elif f & 64:
+                    res.update(ok=False, reason="empty object mesh")
+                out.append(res)
+        return out
+
+    def run(self, scenes, log=None):
+        """Results in the order of `scenes`.  Image sets are filled up to `in_flight` by repeating the set's first image (its
+        copies are computed and dropped): the slots -- and with them the captured graphs -- keep one shape."""
+        results = [None] * len(scenes)
+        key = lambda s: (int(s["H"]), int(s["W"]), len(s["hand_verts"]), len(s["hand_faces"]))
+        order = sorted(range(len(scenes)), key=lambda i: key(scenes[i]))        # stable: same-shape images stay in list order
+        i = 0
+        while i < len(order):
+            j = i
+            while j < len(order) and j - i < self.in_flight and key(scenes[order[j]]) == key(scenes[order[i]]):
+                j += 1
+            ids = order[i:j]
+            batch = [scenes[k] for k in ids]
+            batch += [batch[0]] * (self.in_flight - len(batch))
+            for k, r in zip(ids, self._run_set(batch, log)):
+                results[k] = r
+            i = j
+        return results
+
+
+def export_result(res, save_path_obj, save_path_hand):
+    """{idx}_obj.ply / {idx}_hand.ply (run.py:221-222) from a MeshGuidanceRunner result."""
+    meshio.save_ply(save_path_obj, *res["obj"])
+    meshio.save_ply(save_path_hand, *res["hand"])
+    return res["obj"], res["hand"]
 
 
 def export_meshes(gb, b, save_path_obj, save_path_hand):

@@ -72,19 +72,26 @@ class FlowMatchEulerDiscreteScheduler:
         self._step_index = self._begin_index = None
 
     def index_for_timestep(self, timestep, schedule_timesteps=None):
-        if schedule_timesteps is None:
-            schedule_timesteps = self.timesteps
-        indices = (schedule_timesteps == timestep).nonzero()
-        pos = 1 if len(indices) > 1 else 0
-        return indices[pos].item()
+        """Position of `timestep` in the schedule.  A value that occurs more than once resolves to its SECOND occurrence
+        (so that a run started in the middle of a schedule does not skip a sigma, SCH:213-226); a value that does not
+        occur raises IndexError like the reference's indexing does."""
+        table = self.timesteps if schedule_timesteps is None else schedule_timesteps
+        hits = torch.nonzero(table == timestep).flatten().tolist()
+        return hits[1] if len(hits) > 1 else hits[0]
 
-    def _init_step_index(self, timestep):
-        if self.begin_index is None:
-            if isinstance(timestep, torch.Tensor):
-                timestep = timestep.to(self.timesteps.device)
-            self._step_index = self.index_for_timestep(timestep)
-        else:
+    def _locate(self, timestep):
+        """First use after set_timesteps(): the index comes from set_begin_index() when the caller fixed it, otherwise
+        from the timestep's place in the schedule."""
+        if self._step_index is not None:
+            return
+        if self._begin_index is not None:
             self._step_index = self._begin_index
+            return
+        if torch.is_tensor(timestep):
+            timestep = timestep.to(self.timesteps.device)
+        self._step_index = self.index_for_timestep(timestep)
+
+    _init_step_index = _locate   # name used by callers written against the reference's scheduler
 
     @staticmethod
     def _reject_int_timestep(timestep):
@@ -92,35 +99,28 @@ class FlowMatchEulerDiscreteScheduler:
             raise ValueError("step(): `timestep` must be one of scheduler.timesteps (a float tensor), not an integer index such as "
                              "the counter of enumerate(timesteps)")
 
+    def _euler(self, model_output, sample, *targets):
+        """x + (target - sigma_k) * v for every target sigma, evaluated in float32 and returned in v's dtype."""
+        x = sample.to(torch.float32)
+        here = self.sigmas[self._step_index]
+        return [(x + (there - here) * model_output).to(model_output.dtype) for there in targets]
+
     def step(self, model_output, timestep, sample, return_dict: bool = True, **_):
-        """x_next = x + (sigma_{k+1} - sigma_k) v ; pred_x1 = x + (1 - sigma_k) v ; advances the index."""
+        """One Euler step towards sigma_{k+1} plus the clean-sample prediction (target sigma 1); advances the index."""
         self._reject_int_timestep(timestep)
-        if self.step_index is None:
-            self._init_step_index(timestep)
-        sample = sample.to(torch.float32)
-        sigma = self.sigmas[self.step_index]
-        sigma_next = self.sigmas[self.step_index + 1]
-        prev_sample = sample + (sigma_next - sigma) * model_output
-        pred_x1 = sample + (1 - sigma) * model_output
-        prev_sample = prev_sample.to(model_output.dtype)
-        pred_x1 = pred_x1.to(model_output.dtype)
+        self._locate(timestep)
+        prev_sample, pred_x1 = self._euler(model_output, sample, self.sigmas[self._step_index + 1], 1)
         self._step_index += 1
-        if not return_dict:
-            return (prev_sample, pred_x1)
-        return FlowMatchEulerDiscreteSchedulerOutput(prev_sample=prev_sample, pred_x1=pred_x1)
+        if return_dict:
+            return FlowMatchEulerDiscreteSchedulerOutput(prev_sample=prev_sample, pred_x1=pred_x1)
+        return (prev_sample, pred_x1)
 
     def step_final(self, model_output, timestep, sample, return_dict: bool = True, **_):
-        """pred_x1 only; the index is NOT advanced (the inner optimisation loops call this repeatedly)."""
+        """Clean-sample prediction only; the index stays where it is (the inner optimisation loops call this repeatedly)."""
         self._reject_int_timestep(timestep)
-        if self.step_index is None:
-            self._init_step_index(timestep)
-        sample = sample.to(torch.float32)
-        sigma = self.sigmas[self.step_index]
-        pred_x1 = sample + (1 - sigma) * model_output
-        pred_x1 = pred_x1.to(model_output.dtype)
-        if not return_dict:
-            return (pred_x1,)
-        return pred_x1
+        self._locate(timestep)
+        (pred_x1,) = self._euler(model_output, sample, 1)
+        return pred_x1 if return_dict else (pred_x1,)
 
 
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):

@@ -14,7 +14,8 @@ import torch
 
 METRIC_NAMES = ["n_images", "n_steps", "sum_total_loss", "sum_intersection", "sum_contact", "sum_kps", "sum_edge",
                 "sum_normal_hand", "sum_disp_hand", "sum_normal_hoi", "sum_disp_hoi", "sum_sil_hoi", "sum_wall_ms",
-                "n_nan", "n_flagged"]
+                "n_nan", "n_flagged", "n_failed"]
+IDX = {n: i for i, n in enumerate(METRIC_NAMES)}
 
 
 def shard_images(items: List[str], rank: int, world_size: int) -> List[str]:
@@ -40,16 +41,27 @@ def load_task_list(task_list_file: Optional[str], cropped_obj_img_dir: str, rank
     return shard_images(items, rank, world_size) if world_size > 1 else list(items)
 
 
+_TERM_COLS = [0, 1, 2, 3, 7, 8, 9, 11, 12, 13]   # total, intersection, contact, kps, edge, normal0, disp0, normal1, disp1, sil1
+
+
+def image_metrics(losses_row, flags: int, n_steps: int):
+    """One image's contribution to the metrics vector (list of floats, METRIC_NAMES order) from its row of
+    GuidanceBatch.losses and its flag word; wall time and failures are tallied by the driver."""
+    import math
+    l = [float(x) for x in losses_row]
+    v = [1.0, float(n_steps)] + [0.0 if math.isnan(l[c]) else l[c] for c in _TERM_COLS]
+    return v + [0.0, float(bool(flags & 1)), float(bool(flags & 6)), 0.0]
+
+
 def local_metrics(gb, n_steps: int, wall_ms: float) -> torch.Tensor:
     """This rank's contribution: sums over its images of the last step's loss terms (device -> fp64 vector)."""
     l = gb.losses.detach().double()
     fl = gb.flags.detach()
-    names = {"total": 0, "intersection": 1, "contact": 2, "kps": 3, "edge": 7, "normal0": 8, "disp0": 9, "normal1": 11,
-             "disp1": 12, "sil1": 13}
     v = [float(gb.B), float(n_steps) * gb.B]
-    for k in ["total", "intersection", "contact", "kps", "edge", "normal0", "disp0", "normal1", "disp1", "sil1"]:
-        v.append(float(torch.nan_to_num(l[:, names[k]]).sum().item()))
-    v += [wall_ms, float((fl & 1).ne(0).sum().item()), float((fl & 6).ne(0).sum().item())]
+    for c in _TERM_COLS:
+        v.append(float(torch.nan_to_num(l[:, c]).sum().item()))
+    # n_failed (images whose processing raised) is tallied by the driver, not here
+    v += [wall_ms, float((fl & 1).ne(0).sum().item()), float((fl & 6).ne(0).sum().item()), 0.0]
     return torch.tensor(v, dtype=torch.float64, device=gb.losses.device)
 
 

@@ -117,6 +117,13 @@ typedef struct {
                                         for back-to-back steps inside one hipGraph, where it removes the serial tail of
                                         the last-workgroup stage.  params / adam / losses / flags of the last step only
                                         become visible after foho_step_finalize()                                    */
+    int32_t n_active_renders;        /* 0 = all dims.n_renders.  1 with a workspace laid out for 2 renders: phases A and B
+                                        (one render each, PL:1328-1329, 1414-1415) run on the workspace phase C uses, so a
+                                        per-image job never re-allocates or re-initialises it between phases.  Roles whose
+                                        output has no weight in this cfg are not launched at all: a mesh no active render
+                                        draws gets no raster / vertex-normal workgroups, w_contact == 0 without the
+                                        intersection gate -> no nearest-neighbour role (contact / mean_d2 report 0),
+                                        w_edge == w_verts_obj == 0 -> no edge role, w_kps == 0 -> no keypoint role        */
 } foho_step_cfg;
 
 /* ---- buffers of one batched step -------------------------------------------------------------- */

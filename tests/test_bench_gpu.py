@@ -1,0 +1,62 @@
+"""bench.py as the driver launches it: the N=1 line's contract fields and the N>1 path (one rank per GPU; here two ranks
+share the box's one GPU and the collectives go through gloo -- FOHO_BENCH_BACKEND -- instead of RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+gpu = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def _env(**kw):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **kw)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@gpu
+def test_bench_line_n1_and_two_ranks_gloo():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` and the same workload as
+    `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`: one JSON line each, whole-job value, weak scaling
+    (every rank brings its own frame), timings max-reduced over the ranks, metrics vector summed over them."""
+    flags = ["--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + flags, env=_env(), cwd=ROOT, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    o1 = _line(r1.stdout)
+    assert o1["n_gpus"] == 1 and o1["steps"] == 20 and o1["warmup"] == 5 and o1["scaling"] == "weak"
+    assert o1["config"]["global_images"] == 1 and o1["higher_is_better"] is True and o1["vs_baseline"] is None
+    assert o1["repeats"] >= 2 and o1["repeats"] * 20 * o1["ms_per_step"] * 1e-3 > 0.1     # short regions are repeated
+    assert abs(o1["value"] - 1e3 / o1["ms_per_step"]) <= 1e-6 * o1["value"]
+    rf = o1["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel"] in o1["kernels"]
+    assert rf["kernel"] == max(o1["kernel_ms_median"], key=o1["kernel_ms_median"].get)     # chosen live
+    assert o1["metrics"]["n_images"] == 1 and o1["nan_images"] == 0
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", "bench.py", "--gpus", "2"] + flags
+    r2 = subprocess.run(cmd, env=_env(FOHO_BENCH_BACKEND="gloo"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                        text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-4000:]
+    o2 = _line(r2.stdout)
+    assert o2["n_gpus"] == 2 and o2["config"]["global_images"] == 2 and o2["config"]["images_per_gpu"] == 1
+    assert o2["steps"] == 20 and o2["scaling"] == "weak" and o2["metric"] == o1["metric"] and o2["unit"] == o1["unit"]
+    assert abs(o2["value"] - 2 * 1e3 / o2["ms_per_step"]) <= 1e-6 * o2["value"]            # whole-job aggregate
+    # two ranks time-share one GPU here: anything between one and four single-rank throughputs is plausible, outside that
+    # the aggregation (x world, max over ranks) is wrong
+    assert o1["value"] <= 2.0 * o2["value"] and o2["value"] <= 4.0 * o1["value"], (o1["value"], o2["value"])
+    m1, m2 = o1["metrics"], o2["metrics"]
+    assert m2["n_images"] == 2 and m2["n_steps"] == 2 * 20 * o2["repeats"] and m2["n_nan"] == 0
+    # rank 1 optimises another frame (seed = rank): the summed loss is not twice rank 0's, but of its order
+    assert 0.2 * m1["sum_total_loss"] < m2["sum_total_loss"] - m1["sum_total_loss"] < 5.0 * m1["sum_total_loss"]
+    assert "roofline" in o2 and "cpu_baseline" not in o2

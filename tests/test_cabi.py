@@ -84,7 +84,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.FohoImage) == 8 * 4 + 2 * 4 + 9 * 4 + 3 * 4 + 2 * 4 + 12 * 4
     assert ctypes.sizeof(L.FohoDims) == 15 * 4
     assert ctypes.sizeof(L.FohoRenderCfg) == 7 * 4
-    assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4
+    assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4 + 4
     assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8
 
 

@@ -200,3 +200,109 @@ def test_guidance_driver_under_torchrun_two_ranks(tmp_path):
     tot = json.loads(line[0].split("Batch metrics:", 1)[1])
     assert tot["world_size"] == 2 and tot["n_images"] == 2 and tot["n_steps"] == 2 * 750
     assert np.isfinite(tot["sum_total_loss"]) and tot["sum_total_loss"] > 0 and tot["n_nan"] == 0
+
+
+def _write_tree(tmp_path, n, size=64, kinds=("ico2", "ico3")):
+    """n scene folders with objects of different sizes; returns (dirs, scenes by index, J regressor path)."""
+    from followmyhold_amd import engine as E
+    d = _dirs(tmp_path)
+    scenes = {}
+    for k in range(n):
+        idx = f"{3 + 4 * k:04d}"
+        sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind=kinds[k % len(kinds)], H=size, W=size, seed=40 + k)
+        mv, mf = _gt_mesh(sc)
+        inputs.save_scene_files(sc, mv, mf, {k2: v for k2, v in d.items() if k2 != "guidance_out_dir"}, idx)
+        scenes[idx] = sc
+    jr = str(tmp_path / "J.npy")
+    np.save(jr, next(iter(scenes.values()))["J_regressor"])
+    return d, scenes, jr
+
+
+@gpu
+def test_batched_driver_equals_one_image_at_a_time(tmp_path, monkeypatch, capsys):
+    """SURVEY.md 8(e) "within a GPU, batch the rank's images": `foho.guidance.run.run` takes nine scene folders (two object
+    sizes) through MeshGuidanceRunner four at a time -- two full image sets and a padded one, the second and third loaded
+    INTO the slots of the first -- and every image's meshes equal what the same driver produces one image at a time and
+    what the exact-size single-image driver (`inputs.run_mesh_guidance`) produces.  One empty mask and one missing file
+    exercise the per-image skip / error isolation of RUN:224-236, 257-259 inside an image set."""
+    from foho import configs
+    from followmyhold_amd import engine as E
+    d, scenes, jr = _write_tree(tmp_path, 9)
+    monkeypatch.setenv("FOHO_J_REGRESSOR", jr)
+    monkeypatch.setenv("FOHO_MESH_LEVEL_GUIDANCE", "1")
+    short = configs.OptimizationConfig()
+    short.optimization_steps_hand, short.optimization_steps_scale, short.optimization_steps_joint = 2, 2, 1
+    monkeypatch.setattr(G, "OptimizationConfig", lambda: short)
+    idxs = sorted(scenes)
+    # two more list entries that must not disturb the others: an empty hand mask (skipped) and a missing key-point file (error)
+    for extra, seed in (("0100", 70), ("0101", 71)):
+        sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="ico2", H=64, W=64, seed=seed)
+        mv, mf = _gt_mesh(sc)
+        inputs.save_scene_files(sc, mv, mf, {k2: v for k2, v in d.items() if k2 != "guidance_out_dir"}, extra)
+    inputs.save_mask(os.path.join(d["mask_dir"], "0100_cropped_hand_mask.png"), np.zeros((64, 64), bool))
+    os.remove(os.path.join(d["hamer_out_dir"], "0101_kps_for_guidance.npy"))
+
+    def drive(in_flight, out):
+        monkeypatch.setenv("FOHO_IMAGES_IN_FLIGHT", str(in_flight))
+        dd = dict(d, guidance_out_dir=str(tmp_path / out))
+        tot = G.run(project_root=str(tmp_path), task_list_file=None, **dd)
+        txt = capsys.readouterr().out
+        res = {}
+        for idx in idxs:
+            res[idx] = (meshio.load_ply(os.path.join(dd["guidance_out_dir"], f"{idx}_obj.ply")),
+                        meshio.load_ply(os.path.join(dd["guidance_out_dir"], f"{idx}_hand.ply")))
+        return tot, txt, res
+
+    tot4, txt4, r4 = drive(4, "out4")
+    tot1, txt1, r1 = drive(1, "out1")
+    for tot, txt in ((tot4, txt4), (tot1, txt1)):
+        assert tot["n_images"] == 9 and tot["n_steps"] == 9 * (2 + 2 + 9) and tot["n_failed"] == 1 and tot["n_nan"] == 0
+        assert "Skipping 0100 due to empty mask" in txt and "Error in processing 0101_cropped_hoi_1.png" in txt
+        assert txt.count("Reconstructed object") == 9
+        assert not os.path.exists(os.path.join(str(tmp_path), "out4", "0100_obj.ply"))
+    assert abs(tot4["sum_total_loss"] - tot1["sum_total_loss"]) <= 1e-3 * abs(tot1["sum_total_loss"])
+    for idx in idxs:
+        sc = scenes[idx]
+        for (v4, f4), (v1, f1) in zip(r4[idx], r1[idx]):
+            assert np.array_equal(f4, f1) and v4.shape == v1.shape
+            assert np.abs(v4 - v1).max() < 2e-4, idx
+        assert np.array_equal(r4[idx][0][1], sc["obj_faces"]) and np.array_equal(r4[idx][1][1], sc["hand_faces"])
+    # ... and against the exact-size driver (host / device topology builders, its own graphs) for three of the images
+    for idx in (idxs[0], idxs[4], idxs[8]):
+        p = G.derive_paths(f"{idx}_cropped_hoi_1.png", **d)
+        back = inputs.load_scene_from_files(p, scenes[idx]["J_regressor"], E.hip_render_fn("cuda"))
+        gb = inputs.run_mesh_guidance([back], short)
+        (ov, _), (hv, _) = inputs.export_meshes(gb, 0, str(tmp_path / "e_obj.ply"), str(tmp_path / "e_hand.ply"))
+        assert np.abs(ov - r4[idx][0][0]).max() < 2e-4 and np.abs(hv - r4[idx][1][0]).max() < 2e-4, idx
+    # different images really are different (the comparison above is not vacuous)
+    assert np.abs(r4[idxs[0]][1][0] - r4[idxs[2]][1][0]).max() > 1e-2
+
+
+@gpu
+def test_runner_reuses_slots_and_graphs_across_image_sets():
+    """MeshGuidanceRunner: the second and third image set run on the slots and hipGraphs of the first (no new group, no new
+    capture), also when their objects have other vertex / face counts; a larger object than the capacity rebuilds the
+    group once; an open object mesh is handed back for the exact-size driver."""
+    from followmyhold_amd import engine as E
+    short = E.OptimizationConfig()
+    short.optimization_steps_hand, short.optimization_steps_scale, short.optimization_steps_joint = 4, 2, 2
+    rf = E.hip_render_fn("cuda")
+    mk = lambda kind, seed: synthetic.build_scene(rf, obj_kind=kind, H=64, W=64, seed=seed)
+    runner = inputs.MeshGuidanceRunner(short, in_flight=2, grid_res=16)
+    a = runner.run([mk("ico3", 1), mk("ico2", 2)])
+    caps, groups = runner.stats["captures"], runner.stats["groups_built"]
+    assert groups == 1 and caps == 4               # phase A, phase B, phase C without / with the intersection gate
+    b = runner.run([mk("ico2", 3), mk("ico3", 4), mk("ico2", 5)])       # two sets, the second one padded
+    assert runner.stats["captures"] == caps and runner.stats["groups_built"] == 1 and runner.stats["image_sets"] == 3
+    assert all(r["ok"] and np.isfinite(r["hand"][0]).all() and np.isfinite(r["obj"][0]).all() for r in a + b)
+    assert [len(r["obj"][0]) for r in b] == [162, 642, 162]
+    # a repeat of the first set on the re-used slots gives the first set's answer
+    a2 = runner.run([mk("ico3", 1), mk("ico2", 2)])
+    for r, r2 in zip(a, a2):
+        assert np.abs(r["hand"][0] - r2["hand"][0]).max() < 2e-4 and np.abs(r["obj"][0] - r2["obj"][0]).max() < 2e-4
+    big = runner.run([mk("ico4", 6)])
+    assert big[0]["ok"] and runner.stats["groups_built"] == 2 and len(big[0]["obj"][0]) == 2562
+    sc = mk("ico2", 7)
+    sc["obj_faces"] = sc["obj_faces"][:-2]         # a hole: not a closed manifold
+    opened = runner.run([sc])
+    assert not opened[0]["ok"] and opened[0]["reason"] == "fallback"
