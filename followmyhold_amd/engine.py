@@ -382,6 +382,17 @@ class GuidanceBatch:
             L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(stages), ctypes.c_void_p(stream)),
                     "foho_step_run(prepare)")
 
+    def refresh_world(self, stream=None):
+        """Recompute the world-space vertices (workspace region "world") from the CURRENT parameters.  A step transforms the
+        vertices first and updates the parameters last, so after a loop the region is one optimiser update behind; the
+        reference builds its output meshes from the final parameters (PL:1614-1618, 1653-1657).  One vertex-stage call."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.prepare(stream)
+        cfg, _ = phase_cfg("C", do_update=False)
+        L.check(self.lib.foho_step_run(ctypes.byref(self.desc()), ctypes.byref(cfg), int(L.STAGE_VERTEX), ctypes.c_void_p(stream)),
+                "foho_step_run(VERTEX)")
+
     def fits(self, scenes):
         """True when `scenes` can be loaded into this (capacity-mode) batch in place."""
         if self.obj_capacity is None or len(scenes) != self.B:

@@ -289,6 +289,8 @@ def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None
         gb.raise_on_flags(strict_k=False)
         if log is not None:
             log(phase, denoise_i, [gb.loss_dict(b)["total"] for b in range(gb.B)])
+    gb.refresh_world()      # the output meshes follow from the FINAL parameters (PL:1614-1618, 1653-1657)
+    torch.cuda.synchronize(gb.device)
     return gb
 
 
@@ -384,6 +386,9 @@ class MeshGuidanceRunner:
             if log is not None:
                 group.synchronize()
                 log(phase, denoise_i, [gb.loss_dict(b)["total"] for gb in group.batches for b in range(gb.B)])
+        for gb, st in zip(group.batches, group.streams):       # output meshes from the FINAL parameters (PL:1614-1618, 1653-1657)
+            with torch.cuda.stream(st):
+                gb.refresh_world()
         group.synchronize()
         self.stats["image_sets"] += 1
         out = []

@@ -144,6 +144,7 @@ def phase_c_loss(scene, p, obj_verts, edges, denoise_i=19, num_inference_steps=2
 
 
 PARAM_KEYS = ["scale_hand", "trans_hand", "rot_hand", "scale_obj", "trans_obj", "rot_obj"]
+SIL_TERM = {"A": ("sil_hand", 1.0), "B": ("sil_obj", 100.0), "C": ("sil_hoi", 10.0)}     # PL:1346, 1436, 1584
 
 
 def make_params(dtype=torch.float32, **over):
@@ -234,3 +235,30 @@ class PhaseStepper:
         if update:
             self.opt.step()
         return total.detach(), {k: v.detach() for k, v in terms.items()}, aux, grads
+
+
+def loss_without_silhouette(phase, scene, params, denoise_i=19, num_inference_steps=20, grid_res=64):
+    """Total loss of one iteration of `phase` WITHOUT its silhouette BCE term, and its gradients, at `params` (no update).
+
+    The BCE of a silhouette pixel whose alpha rounds to exactly 1 is clamped (log(0) -> -100, gradient / 1e-12): a jump the
+    last bit of one expf decides.  Parity tests compare steps that hold such a pixel on both sides of the clamp through
+    this function -- everything but that term -- instead of skipping them."""
+    p = leafify(params, PARAM_KEYS)
+    ov = scene["obj_verts"].detach().clone().requires_grad_(phase != "A")
+    edges = R.unique_edges(scene["obj_faces"])
+    if phase == "A":
+        total, terms, _ = phase_a_loss(scene, p)
+        keys = ["scale_hand", "trans_hand", "rot_hand"]
+    elif phase == "B":
+        total, terms, _ = phase_b_loss(scene, p, ov, edges)
+        keys = ["scale_obj", "trans_obj", "rot_obj"]
+    else:
+        total, terms, _ = phase_c_loss(scene, p, ov, edges, denoise_i, num_inference_steps, grid_res=grid_res)
+        keys = PARAM_KEYS
+    name, w = SIL_TERM[phase]
+    rest = total - w * terms[name]
+    rest.backward()
+    grads = {k: p[k].grad.detach().clone() for k in keys}
+    if phase != "A":
+        grads["obj_verts"] = ov.grad.detach().clone()
+    return rest.detach(), grads

@@ -203,14 +203,15 @@ def test_guidance_driver_under_torchrun_two_ranks(tmp_path):
 
 
 def _tame(cfg, a, b, c):
-    """A short schedule with learning rates a fiftieth of the reference's: at its own settings (quaternion learning rate 0.5
+    """A short schedule with learning rates 1/500 of the reference's: at its own settings (quaternion learning rate 0.5
     with eps 1e-4, CFG:21-26) the reference's optimisation is chaotic -- the 1e-7 noise of atomic float sums decides single
     Adam steps -- and two runs of the SAME code on the same inputs part ways within a few iterations.
-    Tests that compare two executions of a schedule (batched against one by one, slot re-use against a fresh slot) run it
-    where the trajectory is a function of the inputs."""
+    (scripts/dev_determinism.py: at the reference's rates a fresh runner and the exact-size driver end 4 + 2 + 9 x 2
+    iterations 4e-2 m apart, at a fiftieth of them 1.6e-4 m).  Tests that compare two executions of a schedule (batched
+    against one by one, slot re-use against a fresh slot) run it where the trajectory is a function of the inputs."""
     cfg.optimization_steps_hand, cfg.optimization_steps_scale, cfg.optimization_steps_joint = a, b, c
     for name in ("phase1_hand_lrs", "phase2_hand_lrs", "obj_2half_lrs", "obj_lrs"):
-        setattr(cfg, name, {k: v / 50.0 for k, v in getattr(cfg, name).items()})
+        setattr(cfg, name, {k: v / 500.0 for k, v in getattr(cfg, name).items()})
     return cfg
 
 
@@ -277,7 +278,7 @@ def test_batched_driver_equals_one_image_at_a_time(tmp_path, monkeypatch, capsys
         sc = scenes[idx]
         for (v4, f4), (v1, f1) in zip(r4[idx], r1[idx]):
             assert np.array_equal(f4, f1) and v4.shape == v1.shape
-            assert np.abs(v4 - v1).max() < 2e-4, idx
+            assert np.abs(v4 - v1).max() < 5e-5, idx
         assert np.array_equal(r4[idx][0][1], sc["obj_faces"]) and np.array_equal(r4[idx][1][1], sc["hand_faces"])
     # ... and against the exact-size driver (host / device topology builders, its own graphs) for three of the images
     for idx in (idxs[0], idxs[4], idxs[8]):
@@ -285,9 +286,11 @@ def test_batched_driver_equals_one_image_at_a_time(tmp_path, monkeypatch, capsys
         back = inputs.load_scene_from_files(p, scenes[idx]["J_regressor"], E.hip_render_fn("cuda"))
         gb = inputs.run_mesh_guidance([back], short)
         (ov, _), (hv, _) = inputs.export_meshes(gb, 0, str(tmp_path / "e_obj.ply"), str(tmp_path / "e_hand.ply"))
-        assert np.abs(ov - r4[idx][0][0]).max() < 2e-4 and np.abs(hv - r4[idx][1][0]).max() < 2e-4, idx
+        assert np.abs(ov - r4[idx][0][0]).max() < 5e-5 and np.abs(hv - r4[idx][1][0]).max() < 5e-5, idx
     # different images really are different (the comparison above is not vacuous)
     assert np.abs(r4[idxs[0]][1][0] - r4[idxs[2]][1][0]).max() > 1e-2
+    # the outputs carry the LAST optimiser update (one lagging update at these rates is ~1e-5 m: not resolved here, see
+    # test_exported_meshes_follow_the_final_parameters)
 
 
 @gpu
@@ -310,10 +313,41 @@ def test_runner_reuses_slots_and_graphs_across_image_sets():
     # a repeat of the first set on the re-used slots gives the first set's answer
     a2 = runner.run([mk("ico3", 1), mk("ico2", 2)])
     for r, r2 in zip(a, a2):
-        assert np.abs(r["hand"][0] - r2["hand"][0]).max() < 2e-4 and np.abs(r["obj"][0] - r2["obj"][0]).max() < 2e-4
+        assert np.abs(r["hand"][0] - r2["hand"][0]).max() < 5e-5 and np.abs(r["obj"][0] - r2["obj"][0]).max() < 5e-5
     big = runner.run([mk("ico4", 6)])
     assert big[0]["ok"] and runner.stats["groups_built"] == 2 and len(big[0]["obj"][0]) == 2562
     sc = mk("ico2", 7)
     sc["obj_faces"] = sc["obj_faces"][:-2]         # a hole: not a closed manifold
     opened = runner.run([sc])
     assert not opened[0]["ok"] and opened[0]["reason"] == "fallback"
+
+
+@gpu
+def test_exported_meshes_follow_the_final_parameters():
+    """The meshes a job returns are the input meshes under the FINAL parameters (the reference builds debug_mano /
+    debug_transformed_obj_mesh after the last optimiser step, PL:1614-1618, 1653-1657), not the vertices the last iteration
+    started from: both drivers against a float64 similarity transform of the inputs with the parameters they report."""
+    from followmyhold_amd import engine as E
+    from oracle import ref_ops as R
+    cfg = E.OptimizationConfig()            # the reference's learning rates: one update moves the hand by centimetres
+    cfg.optimization_steps_hand, cfg.optimization_steps_scale, cfg.optimization_steps_joint = 3, 2, 1
+    sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="ico2", H=64, W=64, seed=11)
+
+    def expect(params):
+        p = torch.from_numpy(np.asarray(params, np.float64))
+        hv = torch.from_numpy(sc["hand_verts"].astype(np.float64))
+        ov = torch.from_numpy(sc["obj_verts"].astype(np.float64))
+        hand = R.transform_around_center_w_scale(hv, R.quaternion_to_matrix(p[4:8]), p[1:4], p[0:1])
+        moge = R.transform_hunyuan2moge(ov, torch.from_numpy(sc["T_h2m"].astype(np.float64)))
+        obj = R.transform_around_center_w_scale(moge, R.quaternion_to_matrix(p[12:16]), p[9:12], p[8:9])
+        return hand.numpy(), obj.numpy()
+
+    res = inputs.MeshGuidanceRunner(cfg, in_flight=1, grid_res=16).run([sc])[0]
+    hand, obj = expect(res["params"])
+    assert np.abs(res["hand"][0] - hand).max() < 1e-5 and np.abs(res["obj"][0] - obj).max() < 1e-5
+    assert np.abs(res["hand"][0] - sc["hand_verts"]).max() > 1e-3               # the hand did move
+    gb = inputs.run_mesh_guidance([sc], cfg)
+    hand, obj = expect(gb.params[0].cpu().numpy())
+    m = gb.meta[0]
+    world = gb.region("world", torch.float32, (-1, 3)).cpu().numpy()
+    assert np.abs(world[:m["Vh"]] - hand).max() < 1e-5 and np.abs(world[m["Vh"]:m["Vh"] + m["Vo"]] - obj).max() < 1e-5
