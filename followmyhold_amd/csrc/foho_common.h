@@ -311,6 +311,28 @@ __device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf
     return true;
 }
 
+// Signed squared edge distance of a fragment that eval_frag ACCEPTED (the winner k_resolve decodes from the z key): the
+// same three seg_d2 values and minimum, bit for bit, and the inside test without eval_frag's nine other divisions.
+// inside <=> w_i = t_i / max(t0 + t1 + t2, eps) > 0 for all i with t_0 = a_0 z_1 z_2, a_i = e_i / area: the divisor is
+// positive and neither quotient can underflow to zero (|e_i| >= ~1e-22 where it is not exactly zero, |area| <= 4, depths
+// <= zfar), so sign(w_i) = sign(e_i) sign(area) sign(z_j z_k) -- compared as products, never divided.
+__device__ __forceinline__ float winner_sdist(const float* __restrict__ fv, float xf, float yf) {
+    const float x0 = fv[0], y0 = fv[1], z0 = fv[2];
+    const float x1 = fv[3], y1 = fv[4], z1 = fv[5];
+    const float x2 = fv[6], y2 = fv[7], z2 = fv[8];
+    const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
+    const float sa = (area > 0.0f) ? 1.0f : ((area < 0.0f) ? -1.0f : 0.0f);
+    const float s0 = (edge_fn(xf, yf, x1, y1, x2, y2) * sa) * (z1 * z2);
+    const float s1 = (edge_fn(xf, yf, x2, y2, x0, y0) * sa) * (z0 * z2);
+    const float s2 = (edge_fn(xf, yf, x0, y0, x1, y1) * sa) * (z0 * z1);
+    const float d01 = seg_d2(xf, yf, x0, y0, x1, y1);
+    const float d02 = seg_d2(xf, yf, x0, y0, x2, y2);
+    const float d12 = seg_d2(xf, yf, x1, y1, x2, y2);
+    const float dist = fminf(fminf(d01, d02), d12);
+    const bool inside = (s0 > 0.0f) && (s1 > 0.0f) && (s2 > 0.0f);
+    return inside ? -dist : dist;
+}
+
 // d(seg_d2)/d(a,b) with the projection parameter held constant (envelope; pytorch3d
 // PointLineDistanceBackward).  Accumulates g * d(dist)/d(.) into ga[2], gb[2].
 // a / b through v_rcp_f32 (1 ulp) for GRADIENT arithmetic only: parity there is 1e-4 relative, and the correctly

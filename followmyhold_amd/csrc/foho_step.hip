@@ -21,8 +21,8 @@
 //                  (PL:1578-1601)                                              [k_backward.inc, k_final.inc]
 //
 // Data layout in HBM: vertices AoS (V,3) f32, faces (F,3) i32 global ids, per-face NDC copy (F,9) f32 written by
-// the rasteriser's setup; per render scatter planes (z-key u64, fragment counter, two product sums; all-zero
-// between steps) and a G-buffer (face id i32 for every pixel; z, signed dist, silhouette product, colour for
+// the rasteriser's setup; per render scatter planes (z-key u64, full-coverage byte, fractional-fragment counter and
+// fixed-point log sum; all-zero between steps) and a G-buffer (face id i32 for every pixel; z, signed dist, silhouette product, colour for
 // hit pixels only).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -178,7 +178,7 @@ struct WS {
     size_t total;
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
     size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, bwd_list, bwd_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
-    size_t zkey, fcnt, psum, plog;
+    size_t zkey, fullb, nfrac, plog;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, frac_seg, seg_count, rstats, rslot, loss_part, stats2;
     int nseg;
@@ -253,10 +253,10 @@ static WS make_ws(const foho_dims& d) {
     // it consumed, FOHO_STAGE_BBOX clears everything (first use / after an aborted step)
     w.clean_begin = o;
     w.zkey = take(R * B * P * 8);  // ~(z bits << 32 | face id), atomicMax; 0 = no fragment
-    w.fcnt = take(R * B * P * 4);  // fragments per pixel (low 20 bits) | fully covering fragments (upper bits)
-    w.psum = take(R * B * P * 4);  // sum of (1 - p) over the fractional fragments (exact product for one fragment)
+    w.fullb = take(R * B * P);     // 1 = some fragment covers the pixel fully (1 - p == 0): plain byte stores, every writer stores 1
+    w.nfrac = take(R * B * P * 4); // fractional-coverage fragments per pixel (the K = 100 test); only they touch it
     w.plog = take(R * B * P * 8);  // sum of -log2(1 - p) over the fractional fragments in 2^-40 fixed point (integer atomics:
-                                   // exact, order independent) -> their product
+                                   // exact, order independent) -> their product; non-zero <=> the pixel has such a fragment
     w.tile_touched = take(R * B * (size_t)w.nbtiles);  // 1 = a face's pixel box overlaps the tile this step (raster setup)
     w.tile_clean = take(R * B * (size_t)w.nbtiles);    // 1 = the tile's p2f entries are known to be all -1
     w.sim_acc = take(2 * B * (size_t)SIM_ACC * 4);     // deferred update: per step parity, the 36 partial sums of the final stage (float atomics)
@@ -321,7 +321,7 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
         case FOHO_WS_FRAC_COUNT: off = w.frac_count; n = R * B * 4; break;
         case FOHO_WS_STATS: off = w.stats2; n = R * B * NSTAT * 4; break;
         case FOHO_WS_PARITY: off = w.parity; n = B * 2 * (size_t)G1 * G1 * 16; break;
-        case FOHO_WS_FRAG_COUNT: off = w.fcnt; n = R * B * P * 4; break;
+        case FOHO_WS_FRAG_COUNT: off = w.nfrac; n = R * B * P * 4; break;
         case FOHO_WS_SEG_COUNT: off = w.seg_count; n = R * B * (size_t)w.nseg * 4; break;
         default: return -1;
     }
@@ -376,8 +376,8 @@ struct Ctx {
     float* state_next;
     float* sim_acc;
     unsigned long long* zkey;
-    unsigned* fcnt;
-    float* psum;
+    uint8_t* fullb;
+    unsigned* nfrac;
     unsigned long long* plog;
     FracEntry* frac;
     unsigned* frac_count;
