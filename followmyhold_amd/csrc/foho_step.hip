@@ -127,7 +127,7 @@ extern "C" void foho_debug_spans_clear(void) { (void)hipMemset((void*)nullptr, 0
 // ------------------------------------------------------------------------------------------------
 constexpr int BTX = 32, BTY = 8;      // pixel tile of k_resolve / k_pix_bwd (one pixel per lane; 32 px = one 128-B line of a 4-B plane)
 constexpr int RF = 64;                // faces per workgroup of the scatter rasteriser (= one wave for the setup scan)
-constexpr int RQ_CAP = 2048;          // LDS queue of (face slot, pixel) candidates per enumerate round
+constexpr int RQ_CAP = 1024;          // LDS queue of (face slot, pixel) candidates per enumerate round (4 KB: with the staged nearest-neighbour role, k_stage2 needs ~8 KB of LDS per workgroup)
 constexpr int FRAC_SEG = 256;          // fractional-coverage fragments a raster workgroup keeps in its own list segment per render
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
 constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
