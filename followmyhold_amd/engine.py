@@ -832,6 +832,51 @@ class _SdfObjectiveFn(torch.autograd.Function):
         return gs.reshape(ctx.shape), None, None, None
 
 
+_STREAM_SETS = {}
+
+
+def concurrent_streams(n, device="cuda", candidates=16):
+    """`n` torch streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by
+    default) and two streams that share a queue serialise; which streams share one is not a simple function of their
+    creation order (measured on ROCm 7.2: the pool's streams map to queues a b c d d c b a d c b a ..., so four
+    CONSECUTIVE streams starting at the wrong offset sit on only two queues -- the same 8-image job then takes 13.5 ms per
+    image instead of 8.6, scripts/dev_streams_queues.py).  Streams are therefore picked by measurement: a candidate is kept
+    when a short spin kernel on it overlaps with one on every stream kept so far.  Asking for more streams than there are
+    hardware queues returns the concurrent ones first and fills up with the rest.  Cached per (device, n)."""
+    import time
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, int(n))
+    if key in _STREAM_SETS:
+        return _STREAM_SETS[key]
+    cand = [torch.cuda.Stream(dev) for _ in range(max(int(candidates), int(n)))]
+    if n <= 1 or not hasattr(torch.cuda, "_sleep"):
+        _STREAM_SETS[key] = cand[:n]
+        return _STREAM_SETS[key]
+
+    def spin(ss, cycles=300_000):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for st in ss:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    with torch.cuda.device(dev):
+        spin(cand[:1])
+        one = min(spin(cand[:1]) for _ in range(3))
+        kept, rest = [cand[0]], []
+        for st in cand[1:]:
+            if len(kept) < n and all(min(spin([k, st]) for _ in range(2)) < 1.5 * one for k in kept):
+                kept.append(st)
+            else:
+                rest.append(st)
+    _STREAM_SETS[key] = (kept + rest)[:n]
+    return _STREAM_SETS[key]
+
+
 class GuidanceGroup:
     """Several independent GuidanceBatch loops, each on its own HIP stream with its own hipGraph.
 
@@ -846,7 +891,7 @@ class GuidanceGroup:
         chunks = [scenes[i:i + per] for i in range(0, len(scenes), per)]
         self.device = torch.device(device)
         self.batches = [GuidanceBatch(c, device=device, **kw) for c in chunks]
-        self.streams = [torch.cuda.Stream(self.device) for _ in chunks]
+        self.streams = list(concurrent_streams(len(chunks), self.device))     # streams on DIFFERENT hardware queues
         self.graphs, self.joint, self.main, self.multi, self.steps_per_graph = [], None, None, [], 1
 
     @property
