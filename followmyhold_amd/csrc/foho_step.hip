@@ -207,6 +207,10 @@ static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& 
     // the workgroup with the largest faces does not set the length of the launch
     rf_h = std::max(2, raster_faces_per_block(Fh_max, d.B) / 2);
     rf_o = raster_faces_per_block(Fo_max, d.B);
+#ifdef FOHO_STAMPS  // development build: faces per raster workgroup from the environment (sweeps)
+    if (const char* e = getenv("FOHO_DEBUG_RFH")) rf_h = std::max(1, std::min(atoi(e), RF));
+    if (const char* e = getenv("FOHO_DEBUG_RFO")) rf_o = std::max(1, std::min(atoi(e), RF));
+#endif
     nRh = cdiv(Fh_max, rf_h);
     nRo = cdiv(Fo_max, rf_o);
 }

@@ -117,3 +117,34 @@ def test_floater_and_degenerate_removal_and_the_reference_chain(tmp_path):
     assert np.array_equal(rf, m3.faces) and np.allclose(rv, m3.vertices)
     with pytest.raises(Exception):
         PP.decimate(verts, np.array([[0, 1, 10 ** 6]]), 10)
+
+
+def test_decimator_against_an_independent_bruteforce_qem():
+    """foho_mesh_decimate (lazy-deletion heap, time stamps) against oracle/decimate_ref.py, which recomputes the cost of
+    EVERY edge before every collapse and takes the cheapest admissible one.  On a smooth closed mesh no candidate is ever
+    rejected, the two orders of collapses coincide and the results are IDENTICAL; on a noisy open surface (rejections, the
+    boundary constraint) the product may defer a once-rejected edge, so there the results are compared by what the
+    algorithm minimises: the mean squared distance of the original vertices to the simplified surface."""
+    from oracle import decimate_ref as D
+    v, f = synthetic.icosphere(2, 1.0)                      # 320 faces, closed
+    rng = np.random.default_rng(3)
+    v = (v * (1.0 + 0.05 * rng.standard_normal((len(v), 1)))).astype(np.float32)     # generic positions: no cost ties
+    ov, of = PP.decimate(v, f, 200)
+    rv, rf = D.decimate_bruteforce(v, f, 200)
+    assert len(of) == len(rf) == 200
+    assert np.array_equal(of, rf) and np.abs(ov - rv).max() < 1e-6
+    # open, noisy height field: 2 x 10 x 10 = 200 faces -> 80
+    n = 10
+    ys, xs = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    z = 0.08 * np.sin(xs / n * 5.0) * np.cos(ys / n * 4.0) + 0.01 * rng.standard_normal(xs.shape)
+    hv = np.stack([xs / n, ys / n, z], -1).reshape(-1, 3).astype(np.float32)
+    q = (ys[:-1, :-1] * (n + 1) + xs[:-1, :-1]).reshape(-1)
+    hf = np.concatenate([np.stack([q, q + 1, q + n + 2], 1), np.stack([q, q + n + 2, q + n + 1], 1)]).astype(np.int64)
+    ov, of = PP.decimate(hv, hf, 80)
+    rv, rf = D.decimate_bruteforce(hv, hf, 80)
+    assert len(of) <= 80 and len(rf) <= 80 and abs(len(of) - len(rf)) <= 2
+    e_prod, e_ref = D.mean_sq_distance_to_mesh(hv, ov, of), D.mean_sq_distance_to_mesh(hv, rv, rf)
+    assert e_ref < 2e-4 and e_prod <= 1.3 * e_ref + 1e-7, (e_prod, e_ref)
+    # both keep the outline of the sheet (boundary planes of weight 3)
+    for vv in (ov, rv):
+        assert np.allclose(vv[:, :2].min(0), 0, atol=2e-3) and np.allclose(vv[:, :2].max(0), 1, atol=2e-3)
