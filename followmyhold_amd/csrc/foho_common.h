@@ -333,6 +333,110 @@ __device__ __forceinline__ float winner_sdist(const float* __restrict__ fv, floa
     return inside ? -dist : dist;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Near plane.  MeshRasterizer hands z_clip_value = znear / 2 to rasterize_meshes for perspective cameras (reference
+// src/foho/guidance/run.py:84-105, z_clip_value=None), which runs pytorch3d's clip_faces on the (x_ndc, y_ndc, z_view)
+// face vertices first: a face with all three vertices nearer than the plane is dropped, a face that straddles it is
+// replaced by ONE triangle (two vertices behind: (p4, p5, p1), p1 the vertex in front) or by TWO (one vertex behind:
+// (p4, p2, p5) and (p5, p2, p3), p1 the vertex behind; p2, p3 follow p1 in the face's cyclic order; p4 / p5 = where the
+// edges p1p2 / p1p3 cross the plane, w = (z1 - c) / (z1 - z_o), z = z1 (1 - w) + z_o w, xy = ((xy1 z1)(1 - w) +
+// (xy_o z_o) w) / c for a perspective camera).  The two halves of a split face never both leave a fragment on a pixel: the
+// second replaces the first when its unsigned edge distance is smaller (rasterize_meshes, CheckPixelInsideFace).
+// Everything below is selects and straight-line arithmetic on scalars (run-time indexed private arrays would live in
+// scratch memory); it only runs for faces that straddle the plane -- none in the path's working range, the hand and the
+// object sit decimetres in front of the camera.
+// ------------------------------------------------------------------------------------------------
+struct ClipGeom {
+    int n;        // sub-triangles: 0 = culled, 1, 2
+    int i1;       // position of p1 in the face
+    float w2, w3; // crossing weights on p1p2 / p1p3
+};
+__device__ __forceinline__ void sel_rot(const float* fv, int i1, float* p1, float* p2, float* p3) {
+    // values first, selects second: selecting between the LOADS lets the optimiser turn them into one load with a run-time
+    // index, and a run-time indexed private array is moved to LDS / scratch memory
+    const bool r1 = i1 == 1, r2 = i1 == 2;
+    _Pragma("unroll") for (int q = 0; q < 3; q++) {
+        const float a = fv[q], b = fv[3 + q], c = fv[6 + q];
+        p1[q] = r1 ? b : (r2 ? c : a);
+        p2[q] = r1 ? c : (r2 ? a : b);
+        p3[q] = r1 ? a : (r2 ? b : c);
+    }
+}
+__device__ __forceinline__ void plane_crossing(const float* p1, const float* po, float c, float& w, float* out) {
+    w = (p1[2] - c) / (p1[2] - po[2]);
+    const float u = 1.0f - w;
+    out[0] = ((p1[0] * p1[2]) * u + (po[0] * po[2]) * w) / c;
+    out[1] = ((p1[1] * p1[2]) * u + (po[1] * po[2]) * w) / c;
+    out[2] = p1[2] * u + po[2] * w;
+}
+// sub-triangles of a face with at least one vertex nearer than c (the caller checks that): t0, t1 (t1 only when n == 2)
+__device__ __forceinline__ ClipGeom clip_subtris(const float* fv, float c, float* t0, float* t1) {
+    const bool b0 = fv[2] < c, b1 = fv[5] < c, b2 = fv[8] < c;
+    const int nb = (int)b0 + (int)b1 + (int)b2;
+    ClipGeom g;
+    g.n = (nb == 3 || nb == 0) ? 0 : ((nb == 2) ? 1 : 2);
+    g.i1 = (nb == 2) ? (!b0 ? 0 : (!b1 ? 1 : 2)) : (b0 ? 0 : (b1 ? 1 : 2));
+    g.w2 = g.w3 = 0.0f;
+    if (g.n == 0) return g;
+    float p1[3], p2[3], p3[3], p4[3], p5[3];
+    sel_rot(fv, g.i1, p1, p2, p3);
+    plane_crossing(p1, p2, c, g.w2, p4);
+    plane_crossing(p1, p3, c, g.w3, p5);
+    _Pragma("unroll") for (int q = 0; q < 3; q++) {
+        t0[q] = p4[q];
+        t0[3 + q] = (g.n == 1) ? p5[q] : p2[q];
+        t0[6 + q] = (g.n == 1) ? p1[q] : p5[q];
+        t1[q] = p5[q];
+        t1[3 + q] = p2[q];
+        t1[6 + q] = p3[q];
+    }
+    return g;
+}
+// eval_frag for a face that may straddle the near plane; sub = -1 (not clipped), 0 or 1 (the sub-triangle the surviving
+// fragment belongs to).  Barycentrics in `out` are the sub-triangle's.
+__device__ __forceinline__ bool eval_frag_near(const float* __restrict__ fv, float zc, float xf, float yf, float blur_radius,
+                                               float sqrt_blur, Frag& out, int& sub) {
+    sub = -1;
+    if (!(fminf(fminf(fv[2], fv[5]), fv[8]) < zc)) return eval_frag(fv, xf, yf, blur_radius, sqrt_blur, out);
+    float t0[9], t1[9];
+    const ClipGeom g = clip_subtris(fv, zc, t0, t1);
+    if (g.n == 0) return false;
+    Frag f0, f1;
+    const bool r0 = eval_frag(t0, xf, yf, blur_radius, sqrt_blur, f0);
+    bool r1 = false;
+    if (g.n == 2) r1 = eval_frag(t1, xf, yf, blur_radius, sqrt_blur, f1);
+    if (!r0 && !r1) return false;
+    const bool second = r1 && (!r0 || fabsf(f1.sdist) < fabsf(f0.sdist));  // the neighbour replaces only when strictly closer
+    sub = second ? 1 : 0;
+    out = second ? f1 : f0;
+    return true;
+}
+// barycentrics of a sub-triangle fragment -> barycentrics w.r.t. the unclipped face (pytorch3d
+// convert_clipped_rasterization_to_original_faces): rows of the conversion = barycentrics of the sub-triangle's vertices
+__device__ __forceinline__ void subtri_bary_to_face(const float* fv, float zc, int sub, float* b) {
+    float t0[9], t1[9];
+    const ClipGeom g = clip_subtris(fv, zc, t0, t1);
+    // barycentrics of p4, p5 in (p1, p2, p3) order: p4 = (1 - w2, w2, 0), p5 = (1 - w3, 0, w3)
+    float r[3];  // weights of p1, p2, p3
+    if (g.n == 1) {  // (p4, p5, p1)
+        r[0] = b[0] * (1.0f - g.w2) + b[1] * (1.0f - g.w3) + b[2];
+        r[1] = b[0] * g.w2;
+        r[2] = b[1] * g.w3;
+    } else if (sub == 0) {  // (p4, p2, p5)
+        r[0] = b[0] * (1.0f - g.w2) + b[2] * (1.0f - g.w3);
+        r[1] = b[0] * g.w2 + b[1];
+        r[2] = b[2] * g.w3;
+    } else {  // (p5, p2, p3)
+        r[0] = b[0] * (1.0f - g.w3);
+        r[1] = b[1];
+        r[2] = b[0] * g.w3 + b[2];
+    }
+    // p1, p2, p3 sit at positions i1, i1 + 1, i1 + 2 (mod 3) of the face
+    b[0] = (g.i1 == 0) ? r[0] : ((g.i1 == 1) ? r[2] : r[1]);
+    b[1] = (g.i1 == 0) ? r[1] : ((g.i1 == 1) ? r[0] : r[2]);
+    b[2] = (g.i1 == 0) ? r[2] : ((g.i1 == 1) ? r[1] : r[0]);
+}
+
 // d(seg_d2)/d(a,b) with the projection parameter held constant (envelope; pytorch3d
 // PointLineDistanceBackward).  Accumulates g * d(dist)/d(.) into ga[2], gb[2].
 // a / b through v_rcp_f32 (1 ulp) for GRADIENT arithmetic only: parity there is 1e-4 relative, and the correctly
@@ -461,6 +565,76 @@ __device__ __forceinline__ void eval_frag_bwd(const float* __restrict__ fv, floa
         gv[6] += (sel != 0) ? gb[0] : 0.0f;
         gv[7] += (sel != 0) ? gb[1] : 0.0f;
     }
+}
+
+// gradient of a crossing point p4 = f(p1, po) (plane_crossing) pushed back onto p1 and po
+__device__ __forceinline__ void plane_crossing_bwd(const float* p1, const float* po, float c, float w, const float* g4, float* g1,
+                                                   float* go) {
+    const float u = 1.0f - w, ic = 1.0f / c;
+    g1[0] += g4[0] * p1[2] * u * ic;
+    g1[1] += g4[1] * p1[2] * u * ic;
+    go[0] += g4[0] * po[2] * w * ic;
+    go[1] += g4[1] * po[2] * w * ic;
+    const float gw = (g4[0] * (po[0] * po[2] - p1[0] * p1[2]) + g4[1] * (po[1] * po[2] - p1[1] * p1[2])) * ic + g4[2] * (po[2] - p1[2]);
+    const float dz = p1[2] - po[2], idz2 = 1.0f / (dz * dz);
+    g1[2] += (g4[0] * p1[0] + g4[1] * p1[1]) * u * ic + g4[2] * u + gw * (c - po[2]) * idz2;
+    go[2] += (g4[0] * po[0] + g4[1] * po[1]) * w * ic + g4[2] * w + gw * (p1[2] - c) * idz2;
+}
+// eval_frag_bwd for a face that may straddle the near plane: the fragment's sub-triangle is found again with the forward
+// rule, differentiated, and its vertex gradients are pushed through the cut onto the face's own vertices (the cut moves
+// with them).  g_cin refers to the SUB-TRIANGLE's barycentrics (the fused step never sends gradient into barycentrics).
+__device__ __forceinline__ void eval_frag_near_bwd(const float* __restrict__ fv, float zc, float blur_radius, float sqrt_blur,
+                                                   float xf, float yf, float g_z, const float* g_cin, float g_sd, float* gv) {
+    // One straight path, no early returns: stores into gv[] from several exits get merged by the optimiser into ONE store
+    // through a selected pointer, i.e. a run-time index, which moves the caller's accumulator array to scratch memory.
+    const bool near = fminf(fminf(fv[2], fv[5]), fv[8]) < zc;
+    float t0[9], t1[9];
+    _Pragma("unroll") for (int q = 0; q < 9; q++) t0[q] = t1[q] = fv[q];
+    ClipGeom g;
+    g.n = 1;
+    g.i1 = 0;
+    g.w2 = g.w3 = 0.5f;
+    bool second = false, live = true;
+    if (near) {
+        g = clip_subtris(fv, zc, t0, t1);
+        Frag f0, f1;
+        const bool r0 = g.n > 0 && eval_frag(t0, xf, yf, blur_radius, sqrt_blur, f0);
+        const bool r1 = g.n == 2 && eval_frag(t1, xf, yf, blur_radius, sqrt_blur, f1);
+        second = r1 && (!r0 || fabsf(f1.sdist) < fabsf(f0.sdist));
+        live = r0 || r1;
+    }
+    float ts[9], gt[9];
+    _Pragma("unroll") for (int q = 0; q < 9; q++) {
+        ts[q] = second ? t1[q] : t0[q];
+        gt[q] = 0.0f;
+    }
+    eval_frag_bwd(ts, xf, yf, live ? g_z : 0.0f, g_cin, live ? g_sd : 0.0f, gt);
+    float d[9];
+    _Pragma("unroll") for (int q = 0; q < 9; q++) d[q] = gt[q];
+    if (near) {
+        float p1[3], p2[3], p3[3], g1[3] = {0.f, 0.f, 0.f}, g2[3] = {0.f, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+        float g4[3], g5[3];
+        sel_rot(fv, g.i1, p1, p2, p3);
+        const bool one = g.n == 1;
+        _Pragma("unroll") for (int q = 0; q < 3; q++) {
+            // (p4, p5, p1) | (p4, p2, p5) | (p5, p2, p3)
+            g4[q] = (one || !second) ? gt[q] : 0.0f;
+            g5[q] = one ? gt[3 + q] : (second ? gt[q] : gt[6 + q]);
+            g1[q] = one ? gt[6 + q] : 0.0f;
+            g2[q] = one ? 0.0f : gt[3 + q];
+            g3[q] = (!one && second) ? gt[6 + q] : 0.0f;
+        }
+        plane_crossing_bwd(p1, p2, zc, g.w2, g4, g1, g2);
+        plane_crossing_bwd(p1, p3, zc, g.w3, g5, g1, g3);
+        const bool r1 = g.i1 == 1, r2 = g.i1 == 2;
+        _Pragma("unroll") for (int q = 0; q < 3; q++) {  // p1, p2, p3 back to positions i1, i1 + 1, i1 + 2 (mod 3)
+            const float a = g1[q], b = g2[q], c = g3[q];
+            d[q] = r1 ? c : (r2 ? b : a);
+            d[3 + q] = r1 ? a : (r2 ? c : b);
+            d[6 + q] = r1 ? b : (r2 ? a : c);
+        }
+    }
+    _Pragma("unroll") for (int q = 0; q < 9; q++) gv[q] += d[q];
 }
 
 // sigmoid in fp32 (torch.sigmoid: 1 / (1 + exp(-x)))

@@ -152,9 +152,7 @@ class _RasterFn(torch.autograd.Function):
         ov = int(out["overflow"].item())
         if (ov & 4) and want_sil:
             raise ops.L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
-        if ov & 8:      # pytorch3d's clip_faces would split such a face; this rasteriser culls it
-            raise ops.L.FohoError("a face crosses the near plane z = znear / 2: near-plane clipping is not implemented, "
-                                  "keep the meshes in front of the camera")
+        ctx.blur = float(blur)
         ctx.save_for_backward(verts_ndc.detach(), faces, out["pix_to_face"])
         ctx.mark_non_differentiable(out["pix_to_face"])
         prod = out["sil_prod"] if want_sil else torch.zeros(0, device=verts_ndc.device)
@@ -164,7 +162,7 @@ class _RasterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_p2f, g_z, g_b, g_d, g_prod):
         v, f, p2f = ctx.saved_tensors
-        g = ops.raster_bwd(v, f, p2f, g_z, g_b, g_d)
+        g = ops.raster_bwd(v, f, p2f, g_z, g_b, g_d, blur_radius=ctx.blur)
         return g, None, None, None, None, None, None
 
 

@@ -50,8 +50,8 @@ def raster_fwd(verts_ndc, faces, H, W, blur_radius, sigma=1e-8, want_sil=True):
     return dict(pix_to_face=p2f, zbuf=zb, bary=ba, dists=di, sil_prod=pr, overflow=ov, _keep=(v, f, ws))
 
 
-def raster_bwd(verts_ndc, faces, pix_to_face, grad_zbuf=None, grad_bary=None, grad_dists=None):
-    """Backward of the K=1 fragments -> grad w.r.t. verts_ndc (V,3)."""
+def raster_bwd(verts_ndc, faces, pix_to_face, grad_zbuf=None, grad_bary=None, grad_dists=None, blur_radius=0.0):
+    """Backward of the K=1 fragments -> grad w.r.t. verts_ndc (V,3).  blur_radius: the forward call's."""
     lib = L.lib()
     v, f = _f32(verts_ndc), faces.detach().to(torch.int32).contiguous()
     H, W = pix_to_face.shape[-2:]
@@ -62,7 +62,8 @@ def raster_bwd(verts_ndc, faces, pix_to_face, grad_zbuf=None, grad_bary=None, gr
     p2f = pix_to_face.contiguous()
     L.check(lib.foho_raster_bwd(P(v.data_ptr()), P(f.data_ptr()), v.shape[0], f.shape[0], H, W, P(p2f.data_ptr()),
                                 P(gz.data_ptr()) if gz is not None else None, P(gb.data_ptr()) if gb is not None else None,
-                                P(gd.data_ptr()) if gd is not None else None, P(g.data_ptr()), _stream(v)), "foho_raster_bwd")
+                                P(gd.data_ptr()) if gd is not None else None, P(g.data_ptr()), ctypes.c_float(blur_radius),
+                                _stream(v)), "foho_raster_bwd")
     return g
 
 

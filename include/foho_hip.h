@@ -153,7 +153,7 @@ typedef struct {
     float* grad_params;              /* (B,16)                                                       */
     float* grad_verts_in;            /* (Vtot,3)  dL/d verts_in (object rows are the autograd sink)  */
     int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel,
-                                        bit3 a face straddling z = znear/2 was culled instead of clipped,
+                                        (bit3 unused since near-plane clipping is implemented),
                                         bit4 / bit5: capacity mode, see foho_object_update                      */
     void* workspace;
     size_t workspace_bytes;
@@ -209,17 +209,20 @@ const char* foho_kernel_name(int i);
  * verts_ndc (V,3) = (x_ndc, y_ndc, z_view); faces (F,3) int32.  Outputs (H,W): pix_to_face int64
  * (-1 background), zbuf, bary (H,W,3), dists (signed, squared NDC).  sil_prod (H,W) optional:
  * prod_k(1 - sigmoid(-d_k/sigma)) over every fragment of the pixel (SoftSilhouetteShader alpha = 1 - it).
- * Near plane (MeshRasterizer's z_clip_value = znear / 2 = 0.005 for the path's camera, RUN:84-105): faces with a vertex
- * nearer than that are culled; *overflow_flag gets bit2 (4) when the K = 100 cut-off could not be reproduced and
- * bit3 (8) when a culled face straddled the plane (pytorch3d would have clipped it into sub-triangles). */
+ * Near plane (MeshRasterizer's z_clip_value = znear / 2 = 0.005 for the path's camera, RUN:84-105): faces entirely nearer
+ * are culled, faces that straddle it are rasterised as the one or two sub-triangles pytorch3d's clip_faces cuts them into
+ * (pix_to_face and bary refer to the unclipped face); *overflow_flag gets bit2 (4) when the K = 100 cut-off could not be
+ * reproduced. */
 int foho_raster_fwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     float blur_radius, float sigma, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                     float* sil_prod, int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream);
 size_t foho_raster_workspace_bytes(int32_t V, int32_t F, int32_t H, int32_t W);
-/* backward of the K=1 fragments: grad_verts_ndc (V,3) += d(zbuf,bary,dists)/d verts_ndc */
+/* backward of the K=1 fragments: grad_verts_ndc (V,3) += d(zbuf,bary,dists)/d verts_ndc.  blur_radius = the forward
+ * call's (it decides which half of a near-clipped face left a fragment; for such faces grad_bary is taken w.r.t. the
+ * sub-triangle's barycentrics) */
 int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
-                    const float* grad_dists, float* grad_verts_ndc, void* stream);
+                    const float* grad_dists, float* grad_verts_ndc, float blur_radius, void* stream);
 /* K=1 nearest neighbour: d2 (N1), idx (N1) int64; ties -> lowest index */
 int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
 

@@ -37,11 +37,17 @@ def set_z_clip(z=0.01 * 0.5):
 
 
 def count_near_clipped(face_verts):
-    """Faces that straddle the near plane: pytorch3d's clip_faces would split them, the restatement culls them."""
+    """Faces that straddle the near plane: clip_faces splits them into one or two sub-triangles."""
     fv = np.ascontiguousarray(face_verts, dtype=np.float32).reshape(-1, 9)
     f = lib().foho_oracle_count_near_clipped
     f.restype = ctypes.c_int64
     return int(f(_p(fv, ctypes.c_float), ctypes.c_int64(fv.shape[0])))
+
+
+def get_z_clip():
+    f = lib().foho_oracle_get_z_clip
+    f.restype = ctypes.c_float
+    return float(f())
 
 
 def set_threads(n):
@@ -68,8 +74,9 @@ def rasterize(face_verts, H, W, blur_radius, K=1, perspective_correct=True, clip
 
 def render_pass(face_verts, H, W, blur_radius, K_sil=100):
     """Nearest fragment per pixel + compact list of all K_sil-buffer fragments.
-    Returns dict(pix_to_face (H,W) int64, zbuf, bary (H,W,3), dists, count (H,W) int32,
-    pairs (n,2) int64 [pixel, face], pair_dist (n,) float32)."""
+    Returns dict(pix_to_face (H,W) int64, zbuf, bary (H,W,3), dists, count (H,W) int32, sub (H,W) int8 [sub-triangle of a
+    near-clipped face the nearest fragment belongs to, -1 = the face itself], pairs (n,3) int64 [pixel, face, sub],
+    pair_dist (n,) float32)."""
     fv = np.ascontiguousarray(face_verts, dtype=np.float32).reshape(-1, 9)
     F = fv.shape[0]
     p2f = np.empty((H, W), np.int64)
@@ -77,6 +84,7 @@ def render_pass(face_verts, H, W, blur_radius, K_sil=100):
     ba = np.empty((H, W, 3), np.float32)
     di = np.empty((H, W), np.float32)
     cnt = np.empty((H, W), np.int32)
+    sub = np.empty((H, W), np.int8)
     pp = ctypes.POINTER(ctypes.c_int64)()
     pd = ctypes.POINTER(ctypes.c_float)()
     n = ctypes.c_int64(0)
@@ -84,19 +92,19 @@ def render_pass(face_verts, H, W, blur_radius, K_sil=100):
     rc = L.foho_oracle_render_pass(
         _p(fv, ctypes.c_float), ctypes.c_int64(F), H, W, ctypes.c_float(blur_radius), K_sil,
         _p(p2f, ctypes.c_int64), _p(zb, ctypes.c_float), _p(ba, ctypes.c_float), _p(di, ctypes.c_float),
-        _p(cnt, ctypes.c_int32), ctypes.byref(pp), ctypes.byref(pd), ctypes.byref(n))
+        _p(cnt, ctypes.c_int32), _p(sub, ctypes.c_int8), ctypes.byref(pp), ctypes.byref(pd), ctypes.byref(n))
     assert rc == 0
     n = n.value
     if n > 0:
-        pairs = np.ctypeslib.as_array(pp, shape=(n, 2)).copy()
+        pairs = np.ctypeslib.as_array(pp, shape=(n, 3)).copy()
         pdist = np.ctypeslib.as_array(pd, shape=(n,)).copy()
     else:
-        pairs = np.zeros((0, 2), np.int64)
+        pairs = np.zeros((0, 3), np.int64)
         pdist = np.zeros((0,), np.float32)
     L.foho_oracle_free.argtypes = [ctypes.c_void_p]
     L.foho_oracle_free(ctypes.cast(pp, ctypes.c_void_p))
     L.foho_oracle_free(ctypes.cast(pd, ctypes.c_void_p))
-    return dict(pix_to_face=p2f, zbuf=zb, bary=ba, dists=di, count=cnt, pairs=pairs, pair_dist=pdist)
+    return dict(pix_to_face=p2f, zbuf=zb, bary=ba, dists=di, count=cnt, sub=sub, pairs=pairs, pair_dist=pdist)
 
 
 def inside(verts, faces, pts):

@@ -69,9 +69,11 @@ static inline float seg_d2(float px, float py, float ax, float ay, float bx, flo
 
 typedef struct {
     float z;
-    int64_t face;
+    int64_t face;   /* index into the caller's (unclipped) face list */
     float sdist;
     float b0, b1, b2;
+    int32_t sub;    /* -1: the face itself; 0 / 1: which sub-triangle of a face clipped at the near plane */
+    int64_t cidx;   /* index into the clipped face list (neighbour matching) */
 } frag_t;
 
 /* Evaluate one (pixel centre, face) pair.  Returns 1 when the face produces a
@@ -171,11 +173,23 @@ static inline void kbuf_sort(frag_t* q, int n) { /* stable bubble sort by z */
 }
 
 /* Near plane.  MeshRasterizer passes z_clip_value = znear / 2 to rasterize_meshes for perspective cameras
- * (raster_settings.z_clip_value is None at reference src/foho/guidance/run.py:95-105; znear = 0.01, run.py:84-90):
- * clip_faces() removes faces entirely nearer than the plane and SPLITS faces that straddle it.  Restated policy
- * (SURVEY.md Appendix A.1): any face with a vertex nearer than the plane is culled; straddling faces are counted by
- * foho_oracle_count_near_clipped() so that callers can tell when pytorch3d would have clipped instead.  The
- * default is the path's only camera; tests may move or disable (z_clip < -1e30) the plane. */
+ * (raster_settings.z_clip_value is None at reference src/foho/guidance/run.py:95-105; znear = 0.01, run.py:84-90) and
+ * rasterize_meshes runs pytorch3d.renderer.mesh.clip.clip_faces on the (x_ndc, y_ndc, z_view) face vertices first.
+ * Restated here from the published algorithm (pytorch3d is not vendored: parity unpinned), per face, with
+ * clipped_i = (z_i < z_clip):
+ *   0 clipped   the face is rasterised as it is
+ *   3 clipped   culled
+ *   2 clipped   p1 = the vertex in front, p2 / p3 = the next two in cyclic order; p4 / p5 = where the edges p1p2 / p1p3
+ *               cross the plane; ONE triangle (p4, p5, p1)
+ *   1 clipped   p1 = the vertex behind, p2 / p3 as above; the remaining quadrilateral p4 p2 p3 p5 is split into TWO
+ *               triangles (p4, p2, p5) and (p5, p2, p3), consecutive in the clipped list and each other's "neighbour"
+ *   crossing    w = (z1 - c) / (z1 - z_other); z = z1 (1 - w) + z_other w; perspective cameras interpolate x z and y z
+ *               ("world" xy) and divide by c, so the cut is straight in space, not in the image
+ * The rasteriser then runs over the clipped list.  A pixel can receive a fragment from at most one of two neighbours: when
+ * the second one arrives while the first sits in the pixel's K-buffer, it REPLACES it if its unsigned edge distance is
+ * smaller and is dropped otherwise (rasterize_meshes' CheckPixelInsideFace).  Face ids are mapped back to the caller's
+ * faces and barycentrics to the unclipped face (bary_unclipped = bary_sub . barycentrics of the sub-triangle's vertices).
+ * The default plane is the path's only camera's; tests may move or disable (z_clip < -1e30) it. */
 static float g_z_clip = 0.01f * 0.5f;
 void foho_oracle_set_z_clip(float z) { g_z_clip = z; }
 float foho_oracle_get_z_clip(void) { return g_z_clip; }
@@ -189,23 +203,141 @@ int64_t foho_oracle_count_near_clipped(const float* face_verts, int64_t F) {
     return n;
 }
 
-/* Per-face screen boxes (inflated by sqrt(blur)); used only to skip
- * eval_pixel_face() early -- it re-tests exactly the same box.  Near-culled faces get an empty box. */
-static float* make_face_boxes(const float* face_verts, int64_t F, float sqrt_blur) {
-    float* box = (float*)malloc(sizeof(float) * 4 * (F > 0 ? F : 1));
+typedef struct {
+    float v[9];       /* the triangle that is rasterised */
+    float bc[9];      /* row k: barycentrics of its vertex k w.r.t. the unclipped face */
+    int64_t face;     /* unclipped face */
+    int64_t neighbor; /* index of the other half of a split face in the clipped list, -1 otherwise */
+    int32_t sub;
+} cface_t;
+
+/* point where the edge p1 -> po crosses z = c, and its barycentrics (i1, io = positions of p1, po in the face) */
+static inline void plane_crossing(const float* p1, const float* po, int i1, int io, float c, int perspective, float* out,
+                                  float* bc) {
+    const float w = (p1[2] - c) / (p1[2] - po[2]);
+    const float u = 1.0f - w;
+    out[0] = p1[0] * u + po[0] * w;
+    out[1] = p1[1] * u + po[1] * w;
+    out[2] = p1[2] * u + po[2] * w;
+    if (perspective) {
+        out[0] = ((p1[0] * p1[2]) * u + (po[0] * po[2]) * w) / c;
+        out[1] = ((p1[1] * p1[2]) * u + (po[1] * po[2]) * w) / c;
+    }
+    bc[0] = bc[1] = bc[2] = 0.0f;
+    bc[i1] = u;
+    bc[io] = w;
+}
+
+/* sub-triangles of one face: returns their number (0: culled, 1 or 2), -1 when the face is not clipped at all */
+static inline int clip_one_face(const float* fv, float c, int perspective, float tri[2][9], float bc[2][9]) {
+    const int b0 = fv[2] < c, b1 = fv[5] < c, b2 = fv[8] < c;
+    const int n = b0 + b1 + b2;
+    if (n == 0) return -1;
+    if (n == 3) return 0;
+    /* p1: the one vertex on its side of the plane */
+    const int i1 = (n == 2) ? (!b0 ? 0 : (!b1 ? 1 : 2)) : (b0 ? 0 : (b1 ? 1 : 2));
+    const int i2 = (i1 + 1) % 3, i3 = (i1 + 2) % 3;
+    const float *p1 = fv + 3 * i1, *p2 = fv + 3 * i2, *p3 = fv + 3 * i3;
+    float p4[3], p5[3], b4[3], b5[3], e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0}, e3[3] = {0, 0, 0};
+    plane_crossing(p1, p2, i1, i2, c, perspective, p4, b4);
+    plane_crossing(p1, p3, i1, i3, c, perspective, p5, b5);
+    e1[i1] = e2[i2] = e3[i3] = 1.0f;
+#define PUT(t, k, P, B)                                  \
+    do {                                                 \
+        for (int q_ = 0; q_ < 3; q_++) {                 \
+            tri[t][3 * (k) + q_] = (P)[q_];              \
+            bc[t][3 * (k) + q_] = (B)[q_];               \
+        }                                                \
+    } while (0)
+    if (n == 2) {
+        PUT(0, 0, p4, b4);
+        PUT(0, 1, p5, b5);
+        PUT(0, 2, p1, e1);
+        return 1;
+    }
+    PUT(0, 0, p4, b4);
+    PUT(0, 1, p2, e2);
+    PUT(0, 2, p5, b5);
+    PUT(1, 0, p5, b5);
+    PUT(1, 1, p2, e2);
+    PUT(1, 2, p3, e3);
+#undef PUT
+    return 2;
+}
+
+static cface_t* clip_faces(const float* face_verts, int64_t F, int perspective, int64_t* n_out) {
+    cface_t* out = (cface_t*)malloc(sizeof(cface_t) * (size_t)(2 * F + 1));
+    int64_t n = 0;
+    const int enabled = g_z_clip > -1e30f;
     for (int64_t f = 0; f < F; f++) {
-        const float* v = face_verts + 9 * f;
-        if (fminf(fminf(v[2], v[5]), v[8]) < g_z_clip) {
-            box[4 * f + 0] = box[4 * f + 2] = 1.0f;
-            box[4 * f + 1] = box[4 * f + 3] = 0.0f;
+        float tri[2][9], bc[2][9];
+        const int k = enabled ? clip_one_face(face_verts + 9 * f, g_z_clip, perspective, tri, bc) : -1;
+        if (k == 0) continue;
+        if (k < 0) {
+            cface_t* c = &out[n++];
+            memcpy(c->v, face_verts + 9 * f, sizeof(float) * 9);
+            for (int q = 0; q < 9; q++) c->bc[q] = (q % 4 == 0) ? 1.0f : 0.0f;
+            c->face = f;
+            c->neighbor = -1;
+            c->sub = -1;
             continue;
         }
+        for (int t = 0; t < k; t++) {
+            cface_t* c = &out[n + t];
+            memcpy(c->v, tri[t], sizeof(float) * 9);
+            memcpy(c->bc, bc[t], sizeof(float) * 9);
+            c->face = f;
+            c->sub = t;
+            c->neighbor = (k == 2) ? n + (1 - t) : -1;
+        }
+        n += k;
+    }
+    *n_out = n;
+    return out;
+}
+
+/* Per-entry screen boxes (inflated by sqrt(blur)); used only to skip eval_pixel_face() early -- it re-tests exactly the
+ * same box. */
+static float* make_face_boxes(const cface_t* cf, int64_t n, float sqrt_blur) {
+    float* box = (float*)malloc(sizeof(float) * 4 * (n > 0 ? n : 1));
+    for (int64_t f = 0; f < n; f++) {
+        const float* v = cf[f].v;
         box[4 * f + 0] = fminf(fminf(v[0], v[3]), v[6]) - sqrt_blur;
         box[4 * f + 1] = fmaxf(fmaxf(v[0], v[3]), v[6]) + sqrt_blur;
         box[4 * f + 2] = fminf(fminf(v[1], v[4]), v[7]) - sqrt_blur;
         box[4 * f + 3] = fmaxf(fmaxf(v[1], v[4]), v[7]) + sqrt_blur;
     }
     return box;
+}
+
+/* one fragment of clipped entry ci into the pixel's K-buffer (CheckPixelInsideFace's neighbour rule, then kbuf_insert);
+ * barycentrics are converted to the unclipped face on the way in */
+static inline void kbuf_insert_entry(frag_t* q, int* q_size, float* q_max_z, int* q_max_idx, int K, frag_t* fr,
+                                     const cface_t* cf, int64_t ci) {
+    const cface_t* c = &cf[ci];
+    fr->face = c->face;
+    fr->sub = c->sub;
+    fr->cidx = ci;
+    if (c->sub >= 0) {
+        const float s0 = fr->b0, s1 = fr->b1, s2 = fr->b2;
+        fr->b0 = (s0 * c->bc[0] + s1 * c->bc[3]) + s2 * c->bc[6];
+        fr->b1 = (s0 * c->bc[1] + s1 * c->bc[4]) + s2 * c->bc[7];
+        fr->b2 = (s0 * c->bc[2] + s1 * c->bc[5]) + s2 * c->bc[8];
+    }
+    if (c->neighbor >= 0) {
+        for (int i = 0; i < *q_size; i++)
+            if (q[i].cidx == c->neighbor) {
+                if (fabsf(fr->sdist) < fabsf(q[i].sdist)) {
+                    q[i] = *fr;
+                    if (fr->z > *q_max_z) {
+                        *q_max_z = fr->z;
+                        *q_max_idx = i;
+                    }
+                }
+                return;
+            }
+    }
+    kbuf_insert(q, q_size, q_max_z, q_max_idx, K, fr);
 }
 
 /*
@@ -218,7 +350,9 @@ int foho_oracle_rasterize(const float* face_verts, int64_t F, int H, int W, floa
                           int64_t* pix_to_face, float* zbuf, float* bary, float* dists) {
     if (K < 1 || K > 256) return -1;
     const float sqrt_blur = sqrtf(blur_radius);
-    float* box = make_face_boxes(face_verts, F, sqrt_blur);
+    int64_t nc = 0;
+    cface_t* cf = clip_faces(face_verts, F, perspective_correct, &nc);
+    float* box = make_face_boxes(cf, nc, sqrt_blur);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int yi = 0; yi < H; yi++) {
         frag_t q[256];
@@ -227,15 +361,13 @@ int foho_oracle_rasterize(const float* face_verts, int64_t F, int H, int W, floa
             const float xf = pix_to_ndc(W - 1 - xi, W, H);
             int q_size = 0, q_max_idx = -1;
             float q_max_z = -1000.0f;
-            for (int64_t f = 0; f < F; f++) {
+            for (int64_t f = 0; f < nc; f++) {
                 frag_t fr;
                 const float* bx = box + 4 * f;
                 if (!(bx[0] <= xf && xf <= bx[1] && bx[2] <= yf && yf <= bx[3])) continue;
-                if (eval_pixel_face(face_verts + 9 * f, xf, yf, blur_radius, sqrt_blur,
-                                    perspective_correct, clip_bary, cull_backfaces, &fr)) {
-                    fr.face = f;
-                    kbuf_insert(q, &q_size, &q_max_z, &q_max_idx, K, &fr);
-                }
+                if (eval_pixel_face(cf[f].v, xf, yf, blur_radius, sqrt_blur,
+                                    perspective_correct, clip_bary, cull_backfaces, &fr))
+                    kbuf_insert_entry(q, &q_size, &q_max_z, &q_max_idx, K, &fr, cf, f);
             }
             kbuf_sort(q, q_size);
             const int64_t base = ((int64_t)yi * W + xi) * K;
@@ -259,6 +391,7 @@ int foho_oracle_rasterize(const float* face_verts, int64_t F, int H, int W, floa
         }
     }
     free(box);
+    free(cf);
     return 0;
 }
 
@@ -266,17 +399,21 @@ int foho_oracle_rasterize(const float* face_verts, int64_t F, int H, int W, floa
  * One render pass = what the reference obtains from renderer(mesh) [K=1] plus
  * sil_renderer(mesh) [K=K_sil] on the same mesh (pipelines.py:1546-1547), in a
  * single sweep: nearest fragment per pixel + the compact list of every fragment
- * kept by the K_sil-buffer (pixel, face, signed dist), sorted by z per pixel.
+ * kept by the K_sil-buffer (pixel, face, sub-triangle, signed dist), sorted by z per pixel.
  * The list is returned malloc'ed; free it with foho_oracle_free.
  * count[p] = number of kept fragments of pixel p.
  */
 int foho_oracle_render_pass(const float* face_verts, int64_t F, int H, int W, float blur_radius,
                             int K_sil, int64_t* pix_to_face, float* zbuf, float* bary,
-                            float* dists, int32_t* count, int64_t** pairs_out,
+                            float* dists, int32_t* count, int8_t* sub, int64_t** pairs_out,
                             float** pair_dist_out, int64_t* n_pairs_out) {
+    /* sub (H,W): which sub-triangle of a near-clipped face the nearest fragment comes from (-1: the face itself);
+     * pairs are (pixel, face, sub) triples */
     if (K_sil < 1 || K_sil > 256) return -1;
     const float sqrt_blur = sqrtf(blur_radius);
-    float* box = make_face_boxes(face_verts, F, sqrt_blur);
+    int64_t nc = 0;
+    cface_t* cf = clip_faces(face_verts, F, 1, &nc);
+    float* box = make_face_boxes(cf, nc, sqrt_blur);
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
@@ -300,19 +437,17 @@ int foho_oracle_render_pass(const float* face_verts, int64_t F, int H, int W, fl
                 const float xf = pix_to_ndc(W - 1 - xi, W, H);
                 int q_size = 0, q_max_idx = -1;
                 float q_max_z = -1000.0f;
-                for (int64_t f = 0; f < F; f++) {
+                for (int64_t f = 0; f < nc; f++) {
                     frag_t fr;
                     const float* bx = box + 4 * f;
                     if (!(bx[0] <= xf && xf <= bx[1] && bx[2] <= yf && yf <= bx[3])) continue;
-                    if (eval_pixel_face(face_verts + 9 * f, xf, yf, blur_radius, sqrt_blur, 1, 1,
-                                        0, &fr)) {
-                        fr.face = f;
-                        kbuf_insert(q, &q_size, &q_max_z, &q_max_idx, K_sil, &fr);
-                    }
+                    if (eval_pixel_face(cf[f].v, xf, yf, blur_radius, sqrt_blur, 1, 1, 0, &fr))
+                        kbuf_insert_entry(q, &q_size, &q_max_z, &q_max_idx, K_sil, &fr, cf, f);
                 }
                 kbuf_sort(q, q_size);
                 const int64_t p = (int64_t)yi * W + xi;
                 count[p] = q_size;
+                sub[p] = (int8_t)((q_size > 0) ? q[0].sub : -1);
                 if (q_size > 0) {
                     pix_to_face[p] = q[0].face;
                     zbuf[p] = q[0].z;
@@ -328,12 +463,13 @@ int foho_oracle_render_pass(const float* face_verts, int64_t F, int H, int W, fl
                 }
                 if (t_n[t] + q_size > t_cap[t]) {
                     t_cap[t] = (t_cap[t] + q_size) * 2 + 1024;
-                    t_pairs[t] = (int64_t*)realloc(t_pairs[t], sizeof(int64_t) * 2 * t_cap[t]);
+                    t_pairs[t] = (int64_t*)realloc(t_pairs[t], sizeof(int64_t) * 3 * t_cap[t]);
                     t_dist[t] = (float*)realloc(t_dist[t], sizeof(float) * t_cap[t]);
                 }
                 for (int k = 0; k < q_size; k++) {
-                    t_pairs[t][2 * t_n[t] + 0] = p;
-                    t_pairs[t][2 * t_n[t] + 1] = q[k].face;
+                    t_pairs[t][3 * t_n[t] + 0] = p;
+                    t_pairs[t][3 * t_n[t] + 1] = q[k].face;
+                    t_pairs[t][3 * t_n[t] + 2] = q[k].sub;
                     t_dist[t][t_n[t]] = q[k].sdist;
                     t_n[t]++;
                 }
@@ -342,12 +478,12 @@ int foho_oracle_render_pass(const float* face_verts, int64_t F, int H, int W, fl
     }
     int64_t total = 0;
     for (int t = 0; t < nthreads; t++) total += t_n[t];
-    int64_t* pairs = (int64_t*)malloc(sizeof(int64_t) * 2 * (total > 0 ? total : 1));
+    int64_t* pairs = (int64_t*)malloc(sizeof(int64_t) * 3 * (total > 0 ? total : 1));
     float* pd = (float*)malloc(sizeof(float) * (total > 0 ? total : 1));
     int64_t o = 0;
     for (int t = 0; t < nthreads; t++) {
         if (t_n[t]) {
-            memcpy(pairs + 2 * o, t_pairs[t], sizeof(int64_t) * 2 * t_n[t]);
+            memcpy(pairs + 3 * o, t_pairs[t], sizeof(int64_t) * 3 * t_n[t]);
             memcpy(pd + o, t_dist[t], sizeof(float) * t_n[t]);
         }
         o += t_n[t];
@@ -355,6 +491,7 @@ int foho_oracle_render_pass(const float* face_verts, int64_t F, int H, int W, fl
         free(t_dist[t]);
     }
     free(box);
+    free(cf);
     free(t_pairs);
     free(t_dist);
     free(t_n);

@@ -148,14 +148,59 @@ def _seg_d2(px, py, ax, ay, bx, by):
     return torch.where(l2 <= K_EPS, ex * ex + ey * ey, d_seg)
 
 
-def eval_fragments(verts_ndc, faces, pix, face_idx, H, W, blur_radius=0.0):
-    """Differentiable per-(pixel, face) evaluation: returns zbuf, bary_clip (n,3), signed dist, inside."""
+def clip_subtriangles(fv, sub, z_clip):
+    """pytorch3d clip_faces (renderer/mesh/clip.py) for the rows of fv (n,3,3) [x_ndc, y_ndc, z_view] whose `sub` (n,) is
+    0 or 1: the sub-triangle a face straddling z = z_clip is rasterised as -- differentiable w.r.t. fv, same operations and
+    order as oracle/foho_oracle.c::clip_one_face (perspective camera).  Rows with sub < 0 come back unchanged.
+      two vertices behind   p1 = the vertex in front, p2 / p3 the next two (cyclic): triangle (p4, p5, p1)
+      one vertex behind     p1 = that vertex: sub 0 = (p4, p2, p5), sub 1 = (p5, p2, p3)
+      p4 / p5               crossings of p1p2 / p1p3: w = (z1 - c) / (z1 - z_o), z = z1 (1 - w) + z_o w,
+                            xy = ((xy1 z1)(1 - w) + (xy_o z_o) w) / c"""
+    sel = sub >= 0
+    if not bool(sel.any()):
+        return fv
+    rows = sel.nonzero(as_tuple=True)[0]
+    f = fv[rows]
+    c = torch.tensor(z_clip, dtype=torch.float32).to(fv.dtype)
+    behind = f[:, :, 2] < c
+    nb = behind.sum(1)
+    if not bool(((nb == 1) | (nb == 2)).all()):
+        raise ValueError("clip_subtriangles: a fragment's sub-triangle index does not match its face (not straddling the plane)")
+    lone = torch.where((nb == 2)[:, None], ~behind, behind)          # the one vertex on its own side
+    i1 = lone.to(torch.int64).argmax(1)
+    i2, i3 = (i1 + 1) % 3, (i1 + 2) % 3
+    ar = torch.arange(f.shape[0])
+    p1, p2, p3 = f[ar, i1], f[ar, i2], f[ar, i3]
+
+    def crossing(po):
+        w = (p1[:, 2] - c) / (p1[:, 2] - po[:, 2])
+        u = 1.0 - w
+        z = p1[:, 2] * u + po[:, 2] * w
+        x = ((p1[:, 0] * p1[:, 2]) * u + (po[:, 0] * po[:, 2]) * w) / c
+        y = ((p1[:, 1] * p1[:, 2]) * u + (po[:, 1] * po[:, 2]) * w) / c
+        return torch.stack([x, y, z], 1)
+
+    p4, p5 = crossing(p2), crossing(p3)
+    tri_two = torch.stack([p4, p5, p1], 1)
+    tri_a = torch.stack([p4, p2, p5], 1)
+    tri_b = torch.stack([p5, p2, p3], 1)
+    s_ = sub[rows]
+    out = torch.where((nb == 2)[:, None, None], tri_two, torch.where((s_ == 0)[:, None, None], tri_a, tri_b))
+    return fv.index_put((rows,), out)
+
+
+def eval_fragments(verts_ndc, faces, pix, face_idx, H, W, blur_radius=0.0, sub=None):
+    """Differentiable per-(pixel, face) evaluation: returns zbuf, bary_clip (n,3), signed dist, inside.  `sub` (n,): the
+    sub-triangle of a near-clipped face the fragment belongs to (rasterize_select's "sub" / third pair column), -1 / None
+    for faces rasterised as they are; barycentrics are then those of the sub-triangle."""
     dt = verts_ndc.dtype
     yi = torch.div(pix, W, rounding_mode="floor")
     xi = pix - yi * W
     yf = pix_ndc(H - 1 - yi, H, W, dt)
     xf = pix_ndc(W - 1 - xi, W, H, dt)
     fv = verts_ndc[faces[face_idx]]  # (n,3,3)
+    if sub is not None:
+        fv = clip_subtriangles(fv, sub, clib.get_z_clip())
     x0, y0, z0 = fv[:, 0, 0], fv[:, 0, 1], fv[:, 0, 2]
     x1, y1, z1 = fv[:, 1, 0], fv[:, 1, 1], fv[:, 1, 2]
     x2, y2, z2 = fv[:, 2, 0], fv[:, 2, 1], fv[:, 2, 2]
@@ -206,7 +251,8 @@ def render_normals(verts_world, faces, cam, sel, sigma=1e-8, gamma=1e-8):
     p2f = torch.from_numpy(sel["pix_to_face"]).reshape(-1)
     hit = (p2f >= 0).nonzero(as_tuple=True)[0]
     fidx = p2f[hit]
-    pz, bary, sdist, _ = eval_fragments(ndc, faces, hit, fidx, H, W)
+    sub = torch.from_numpy(sel["sub"]).reshape(-1).to(torch.int64)[hit] if "sub" in sel else None
+    pz, bary, sdist, _ = eval_fragments(ndc, faces, hit, fidx, H, W, sub=sub)
     vn = vertex_normals(verts_world, faces)
     fn = vn[faces[fidx]]  # (n,3,3)
     col = (fn[:, 0] + fn[:, 1]) + fn[:, 2]  # interpolate_face_attributes with bary := ones (PL:85-88)
@@ -237,7 +283,7 @@ def render_silhouette(verts_world, faces, cam, sel, sigma=1e-8):
     if pairs.shape[0] == 0:
         return alpha.reshape(H, W)
     pix, fidx = pairs[:, 0], pairs[:, 1]
-    _, _, sdist, _ = eval_fragments(ndc, faces, pix, fidx, H, W)
+    _, _, sdist, _ = eval_fragments(ndc, faces, pix, fidx, H, W, sub=pairs[:, 2] if pairs.shape[1] > 2 else None)
     sig = torch.tensor(sigma, dtype=torch.float32).to(dt)
     one_minus = 1.0 - torch.sigmoid(-sdist / sig)
     # dense (n_hit_pixels, Kmax) layout; pairs arrive grouped by pixel and sorted by z

@@ -320,9 +320,11 @@ def test_rasteriser_fuzz_bit_exact(seed):
     ref = clib.render_pass(tri, H, W, blur)
     p2f, zb, ba, di = _raster_fwd(verts, faces, H, W, blur)
     assert np.array_equal(p2f, ref["pix_to_face"].reshape(-1)), np.flatnonzero(p2f != ref["pix_to_face"].reshape(-1))[:10]
+    # faces 9 and 12 straddle the near plane: both rasterisers cut them into sub-triangles (pytorch3d clip_faces) -- no flag,
+    # and everything below is still compared bit for bit, the barycentrics mapped back to the unclipped faces included
     n_straddle = clib.count_near_clipped(tri)
-    assert n_straddle == (0 if seed % 4 == 3 else 2) and bool(_raster_fwd.flag & 8) == (n_straddle > 0)
-    assert not np.isin(p2f, [8, 13]).any() and (seed % 4 == 3 or not np.isin(p2f, [9, 12]).any())
+    assert n_straddle == (0 if seed % 4 == 3 else 2) and not (_raster_fwd.flag & 8)
+    assert not np.isin(p2f, [8, 13]).any() and (seed % 4 == 3 or np.isin(ref["sub"].reshape(-1)[np.isin(p2f, [9, 12])], [0, 1]).all())
     hit = p2f >= 0
     assert hit.sum() > 50
     assert np.array_equal(zb, ref["zbuf"].reshape(-1)) and np.array_equal(di, ref["dists"].reshape(-1))

@@ -425,20 +425,39 @@ def test_config4_fp16_gbuffer_with_fp32_accumulation():
 
 
 @gpu
-def test_near_plane_flag_in_the_fused_step():
-    """A face across z = znear / 2 is culled and reported (flag bit 3): the object pushed onto the camera."""
+def test_near_plane_clipping_in_the_fused_step():
+    """Faces across z = znear / 2 are rasterised as the sub-triangles pytorch3d's clip_faces cuts them into (no flag, no
+    exception): the object pushed onto the camera so that the plane slices through it -- face ids, depths and edge distances
+    of both renders bit-exact against the oracle, loss terms and every gradient (they flow through the cut: the
+    sub-triangles' vertices move with the face's) within the usual tolerances, and the AdamW update."""
     from followmyhold_amd import engine as E
     from helpers import make_scene
-    sc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in make_scene("ico2", 64, 64, seed=2).items()}
+    sct = make_scene("ico2", 64, 64, seed=2)
+    sc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sct.items()}
+    zc = float(-np.asarray(sc["T_h2m"])[2, 3])                       # the object's centre sits at view depth zc
+    p = S.make_params(trans_obj=torch.tensor([0.0, 0.0, zc - 0.004]), scale_obj=torch.tensor([0.5]))   # ... now across z_view = 0.005
+    st = S.JointStepper(sct, p, denoise_i=19, grid_res=16)
+    total, terms, aux, grads = st.step(update=True)
+    sub = aux["render"]["sel"]["sub"].reshape(-1)
+    hit = aux["render"]["sel"]["pix_to_face"].reshape(-1) >= 0
+    assert (sub[hit] >= 0).sum() > 20 and (sub[hit] < 0).sum() > 20          # clipped and unclipped faces are both on screen
     gb = E.GuidanceBatch([sc], grid_res=16)
+    gb.set_params(0, **{k: v.numpy() for k, v in p.items()})
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
     gb.step(cfg)
     torch.cuda.synchronize()
     assert int(gb.flags[0]) & 8 == 0
-    zc = float(-np.asarray(sc["T_h2m"])[2, 3])                       # the object's centre sits at view depth zc
-    gb.set_params(0, trans_obj=[0.0, 0.0, zc - 0.004])                # ... now across the plane z_view = 0.005
-    gb.step(cfg)
-    torch.cuda.synchronize()
-    assert int(gb.flags[0]) & 8
-    with pytest.raises(E.L.FohoError):
-        gb.raise_on_flags()
+    gb.raise_on_flags()
+    P_ = 64 * 64
+    for r, ren in enumerate([aux["hand"]["render"], aux["render"]]):
+        ref = ren["sel"]["pix_to_face"].reshape(-1)
+        h = ref >= 0
+        assert np.array_equal(gb.region("p2f", torch.int32, (2, P_))[r].cpu().numpy(), ref)
+        assert np.array_equal(gb.region("zbuf", torch.float32, (2, P_))[r].cpu().numpy()[h], ren["sel"]["zbuf"].reshape(-1)[h])
+        assert np.array_equal(gb.region("sdist", torch.float32, (2, P_))[r].cpu().numpy()[h], ren["sel"]["dists"].reshape(-1)[h])
+    l = gb.loss_dict(0)
+    for a, b in NON_SIL["C"] + [("sil1", "sil_hoi")]:
+        assert abs(l[a] - float(terms[b])) <= 1e-4 * max(abs(float(terms[b])), 1e-6), (a, l[a], float(terms[b]))
+    assert abs(l["total"] - float(total)) <= 1e-4 * abs(float(total))
+    _check_grads(E, gb, grads, tol=1e-3)
+    _check_update(E, gb, st, E.PARAM_NAMES)

@@ -56,30 +56,124 @@ def test_k2_nearest_wins_and_equal_depth_keeps_lower_face_id():
     assert np.all(zb2[both][:, 0] <= zb2[both][:, 1])
 
 
-def test_k2b_near_plane_policy():
-    """MeshRasterizer clips at z = znear / 2 = 0.005 (perspective camera, z_clip_value=None; RUN:84-105).  Restated policy:
-    faces with a vertex nearer than the plane are culled (pytorch3d culls the fully-near ones and splits the
-    straddling ones -- the latter are counted so that callers can flag them); a vertex ON the plane is kept."""
-    H = W = 16
-    xy = [[-0.5, -0.5], [0.5, -0.5], [0.0, 0.5]]
-    mk = lambda zs: [[x, y, z] for (x, y), z in zip(xy, zs)]
-    near, straddle, on_plane, far = mk([0.001, 0.002, 0.004]), mk([0.004, 0.3, 0.3]), mk([0.005, 0.3, 0.3]), mk([0.5, 0.5, 0.5])
-    zc = np.float32(0.01) * np.float32(0.5)
-    on_plane[0][2] = float(zc)
-    for fv, visible in [(near, False), (straddle, False), (on_plane, True), (far, True)]:
-        p2f, _, _, _ = clib.rasterize(tri([fv]), H, W, BLUR)
-        assert (p2f >= 0).any() == visible
-    assert clib.count_near_clipped(tri([near, straddle, on_plane, far])) == 1
-    # a culled face in front does not hide the face behind it
-    p2f, zb, _, _ = clib.rasterize(tri([straddle, far]), H, W, BLUR)
-    assert np.all(p2f[p2f >= 0] == 1) and (p2f >= 0).sum() > 20
+def _clip_expectation(P3, c, H, W, margin=0.6):
+    """Ground truth for a view-space triangle P3 (3,3) [X, Y, Z] cut at Z = c, independent of clip_faces' formulas: the
+    polygon is clipped in 3-D (float64), projected with x_ndc = X / Z, and a pixel is `inside` / `outside` when its centre
+    lies deeper than `margin` pixels inside / outside the projected polygon; depth along a pixel's ray from the triangle's
+    plane n . P = d."""
+    P3 = np.asarray(P3, np.float64)
+    poly = []
+    for i in range(3):                                  # Sutherland-Hodgman against Z >= c
+        a, b = P3[i], P3[(i + 1) % 3]
+        if a[2] >= c:
+            poly.append(a)
+        if (a[2] >= c) != (b[2] >= c):
+            t = (a[2] - c) / (a[2] - b[2])
+            poly.append(a + t * (b - a))
+    poly = np.array(poly)
+    q = poly[:, :2] / poly[:, 2:3]                      # projected polygon (convex)
+    n = np.cross(P3[1] - P3[0], P3[2] - P3[0])
+    d = float(n @ P3[0])
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    xf = -1 + (2 * (W - 1 - xs) + 1) / W
+    yf = -1 + (2 * (H - 1 - ys) + 1) / H
+    sd = np.full((H, W), np.inf)                        # signed distance to the polygon's boundary (positive inside)
+    e1_, e2_ = q[1] - q[0], q[2] - q[1]
+    orient = np.sign(e1_[0] * e2_[1] - e1_[1] * e2_[0])
+    for i in range(len(q)):
+        a, b = q[i], q[(i + 1) % len(q)]
+        e = (b[0] - a[0]) * (yf - a[1]) - (b[1] - a[1]) * (xf - a[0])
+        sd = np.minimum(sd, orient * e / np.linalg.norm(b - a))
+    px = 2.0 / W
+    depth = d / (n[0] * xf + n[1] * yf + n[2])
+    return sd > margin * px, sd < -margin * px, depth, len(poly)
+
+
+@pytest.mark.parametrize("case", ["two_behind", "one_behind", "one_behind_the_camera"])
+def test_k2b_near_plane_clipping_coverage_depth_and_barycentrics(case):
+    """MeshRasterizer clips at z = znear / 2 = 0.005 (perspective camera, z_clip_value=None; RUN:84-105): pytorch3d's
+    clip_faces cuts a straddling face into one triangle (two vertices behind the plane) or into a quadrilateral split into
+    two (one vertex behind).  The restatement against 3-D ground truth: the covered pixels are those of the projected clipped
+    polygon, every one exactly once (the two halves of a split face never both leave a fragment), depths lie on the face's
+    plane, and the returned barycentrics refer to the UNCLIPPED face (they interpolate its view depths and sum to one)."""
+    H = W = 96
+    c = float(np.float32(0.01) * np.float32(0.5))
+    P3 = {"two_behind": [[0.0, 0.0006, 0.012], [-0.004, -0.0015, 0.002], [0.004, -0.0012, 0.003]],
+          "one_behind": [[0.0, -0.0009, 0.002], [0.006, 0.004, 0.011], [-0.005, 0.005, 0.013]],
+          "one_behind_the_camera": [[0.0002, -0.004, -0.006], [0.007, 0.005, 0.012], [-0.006, 0.0045, 0.010]]}[case]
+    P3 = np.asarray(P3, np.float64)
+    fv = np.concatenate([P3[:, :2] / P3[:, 2:3], P3[:, 2:3]], 1).astype(np.float32)[None]      # (x_ndc, y_ndc, z_view)
+    inside, outside, depth, n_poly = _clip_expectation(P3, c, H, W)
+    assert n_poly == (3 if case == "two_behind" else 4) and inside.sum() > 150
+    assert clib.count_near_clipped(fv) == 1
+    p2f, zb, ba, di = clib.rasterize(fv, H, W, BLUR, K=2)
+    hit = p2f[..., 0] >= 0
+    assert hit[inside].all() and not hit[outside].any()
+    assert (p2f[..., 1] == -1).all()                                   # no pixel is covered twice
+    # (a pixel centre within the blur radius -- 0.015 px here -- of the quadrilateral's diagonal gets a fragment from BOTH
+    # halves; the neighbour rule keeps the one with the smaller unsigned edge distance, which can be the half the pixel lies
+    # just outside of, with its barycentrics clamped onto the diagonal: such pixels are allowed 1e-3 instead of 2e-4)
+    zerr = np.abs(zb[..., 0][inside] / depth[inside] - 1)
+    assert zerr.max() < 1e-3 and (zerr > 2e-4).sum() <= 2
+    assert zb[..., 0][hit].min() >= c * (1 - 1e-5)                      # nothing nearer than the plane survives
+    b = ba[..., 0, :][inside]
+    assert np.abs(b.sum(-1) - 1).max() < 1e-4
+    berr = np.abs((b * P3[:, 2]).sum(-1) / depth[inside] - 1)                       # barycentrics of the unclipped face
+    assert berr.max() < 1.5e-3 and (berr > 3e-4).sum() <= 2
+    assert (di[..., 0][inside] >= 0).sum() <= 2 and di[..., 0][inside].max() < BLUR
+    ref = clib.render_pass(fv, H, W, BLUR)
+    subs = set(np.unique(ref["sub"][hit]).tolist())
+    assert subs == ({0} if case == "two_behind" else {0, 1}) and (ref["sub"][~hit] == -1).all()
+    assert ref["pairs"].shape[1] == 3 and (ref["count"][hit] == 1).all()
+    # culled / kept around the plane: all three vertices nearer -> gone; a vertex exactly ON the plane is not clipped (strict <)
+    near = np.array([[[0.1, 0.1, 0.001], [-0.1, 0.1, 0.002], [0.0, -0.1, 0.004]]], np.float32)
+    assert (clib.rasterize(near, 16, 16, BLUR)[0] == -1).all() and clib.count_near_clipped(near) == 0
+    on = np.array([[[-0.5, -0.5, c], [0.5, -0.5, 0.3], [0.0, 0.5, 0.3]]], np.float32)
+    on[0, 0, 2] = np.float32(0.01) * np.float32(0.5)
+    assert clib.count_near_clipped(on) == 0 and (clib.rasterize(on, 16, 16, BLUR)[0] >= 0).sum() > 20
+    # a clipped face only hides what its visible part covers
+    far = np.array([[-0.9, -0.9, 0.5], [0.9, -0.9, 0.5], [0.0, 0.9, 0.5]], np.float32)
+    p2, z2, _, _ = clib.rasterize(np.concatenate([fv, far[None]]), H, W, BLUR)
+    behind_face = (p2[..., 0] == 1)
+    assert (p2[..., 0][inside] == 0).all() and behind_face[outside & (z2[..., 0] > 0)].all()
     try:        # plane disabled: the plain zmax < 0 / pz < 0 rules of the naive rasteriser remain
         clib.set_z_clip(-1e30)
-        p2f, _, _, _ = clib.rasterize(tri([straddle]), H, W, BLUR)
-        assert (p2f >= 0).any() and clib.count_near_clipped(tri([straddle])) == 0
+        assert clib.count_near_clipped(fv) == 0 and (clib.render_pass(fv, H, W, BLUR)["sub"] == -1).all()
     finally:
         clib.set_z_clip()
-    assert clib.count_near_clipped(tri([straddle])) == 1
+
+
+def test_k2c_clipped_fragments_are_differentiable_through_the_cut():
+    """The sub-triangle's vertices are functions of the face's vertices (the cut moves with them): float64 finite differences
+    of depth and signed edge distance of fragments on clipped faces against autograd through clip_subtriangles."""
+    H = W = 48
+    P3 = np.array([[[0.0, -0.0009, 0.002], [0.006, 0.004, 0.011], [-0.005, 0.005, 0.013]],
+                   [[0.0, 0.0006, 0.012], [-0.004, -0.0015, 0.002], [0.004, -0.0012, 0.003]]], np.float64)
+    verts = torch.from_numpy(np.concatenate([P3[..., :2] / P3[..., 2:3], P3[..., 2:3]], -1).reshape(-1, 3))
+    faces = torch.arange(6).reshape(2, 3)
+    for f in range(2):
+        sel = clib.render_pass(verts[faces[f:f + 1]].numpy().astype(np.float32), H, W, BLUR)
+        hit = np.flatnonzero(sel["pix_to_face"].reshape(-1) >= 0)
+        pix = torch.from_numpy(hit[:: max(1, len(hit) // 12)])
+        sub = torch.from_numpy(sel["sub"].reshape(-1)[pix.numpy()].astype(np.int64))
+        fidx = torch.full_like(pix, f)
+
+        def fn(v):
+            pz, _, sd, _ = R.eval_fragments(v, faces, pix, fidx, H, W, sub=sub)
+            return (pz * torch.linspace(1.0, 2.0, len(pix), dtype=torch.float64)).sum() + 1e3 * sd.sum()
+
+        v = verts.clone().requires_grad_(True)
+        fn(v).backward()
+        g = v.grad.clone()
+        assert g[faces[f]].abs().max() > 0
+        for i in faces[f].tolist():
+            for k in range(3):
+                h = 1e-7 * max(1.0, abs(float(verts[i, k])))
+                vp, vm = verts.clone(), verts.clone()
+                vp[i, k] += h
+                vm[i, k] -= h
+                fd = (float(fn(vp)) - float(fn(vm))) / (2 * h)
+                assert abs(fd - float(g[i, k])) <= 1e-5 * max(1.0, abs(fd)), (f, i, k, fd, float(g[i, k]))
 
 
 def test_k3_pixel_centre_convention_plus_x_is_left_plus_y_is_up():

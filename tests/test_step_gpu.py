@@ -253,7 +253,7 @@ def test_standalone_raster_and_knn_ops():
     dgz, dgb, dgd = gz.cuda(), gb_.cuda(), gd.cuda()          # keep the device copies alive across the call
     L.check(lib.foho_raster_bwd(P(dv.data_ptr()), P(df.data_ptr()), len(v), len(f), H, W, P(p2f.data_ptr()),
                                 P(dgz.data_ptr()), P(dgb.data_ptr()), P(dgd.data_ptr()),
-                                P(gout.data_ptr()), stream), "foho_raster_bwd")
+                                P(gout.data_ptr()), ctypes.c_float(blur), stream), "foho_raster_bwd")
     torch.cuda.synchronize()
     assert rel_err(gout.cpu().numpy(), n2.grad.numpy()) < 2e-4
     # knn
