@@ -130,6 +130,8 @@ constexpr int RF = 64;                // faces per workgroup of the scatter rast
 constexpr int RQ_CAP = 1024;          // LDS queue of (face slot, pixel) candidates per enumerate round (4 KB: with the staged nearest-neighbour role, k_stage2 needs ~8 KB of LDS per workgroup)
 constexpr int FRAC_SEG = 256;          // fractional-coverage fragments a raster workgroup keeps in its own list segment per render
 constexpr int K_SIL = 100;            // faces_per_pixel of the silhouette rasteriser (RUN:109)
+constexpr int KFIX_MAX = 32;          // pixels per (render, image) whose K-buffer is re-built exactly (k_resolve: kbuffer_fix)
+constexpr int KFIX_FRAGS = 1024;      // fragments such a pixel may hold
 constexpr int LOSS_BLOCKS = 256;      // blocks of the per-pixel loss pass per (render, image)
 constexpr int NPART = 12;             // partial sums per loss block
 constexpr int LOSS_SLOTS = 16;        // copies of a render's 12 loss accumulators (same-address f64 atomics serialise: 3 us of tail with one copy)
@@ -155,6 +157,11 @@ struct FracEntry {
     int face;
     float sdist;
 };
+struct KFixEntry {  // a pixel with more than K_SIL candidate fragments: only fragments with key <= thr are in its K-buffer
+    int pix;
+    int pad;
+    unsigned long long thr;  // (z bits << 32 | face id) of the farthest fragment kept
+};
 
 // raw stats accumulated by the hit workgroups of k_resolve.  Same-address device-scope atomics serialise at a few
 // ns each, so the accumulators are spread over NSLOT cache lines (workgroup i -> slot i % NSLOT) and k_loss
@@ -179,6 +186,7 @@ struct WS {
     size_t world, ndc, vn_raw, vn, mesh_info, face_ndc;
     size_t p2f, zbuf, sdist, prod, pcol, hit_list, hit_count, bwd_list, bwd_count, tile_touched, tile_clean, pair_v, pending, state_next, sim_acc;
     size_t zkey, fullb, nfrac, plog;
+    size_t kfix_count, kfix;
     size_t clean_begin, clean_end;  // scatter planes: cleared by FOHO_STAGE_BBOX, kept clean by k_resolve
     size_t frac, frac_count, frac_seg, seg_count, rstats, rslot, loss_part, stats2;
     int nseg;
@@ -240,6 +248,7 @@ static WS make_ws(const foho_dims& d) {
         w.nseg = nRh + nRo;
     }
     w.seg_count = take(R * B * (size_t)w.nseg * 4);  // entries in every raster workgroup's segment of the fragment list
+    w.kfix_count = take(R * B * 4);  // pixels whose K = 100 buffer was re-built this step (k_resolve -> frac_bwd_role)
     w.hit_count = take(R * B * 4);  // tiles with at least one hit pixel, per (render, image)
     w.bwd_count = take(R * B * 4);  // entries of the backward pass's work list (a dense tile is split into up to 4 entries)
     w.rstats = take(R * B * sizeof(RStats));
@@ -285,6 +294,7 @@ static WS make_ws(const foho_dims& d) {
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));  // overflow of the segments (rare)
     w.frac_seg = take(R * B * (size_t)w.nseg * FRAC_SEG * sizeof(FracEntry));
+    w.kfix = take(R * B * KFIX_MAX * sizeof(KFixEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
     w.stats2 = take(R * B * NSTAT * 4);
     w.g_direct = take(V3);
@@ -387,6 +397,8 @@ struct Ctx {
     unsigned* frac_count;
     FracEntry* frac_seg;
     unsigned* seg_count;
+    unsigned* kfix_count;
+    KFixEntry* kfix;
     int nseg;
     RStats* rstats;
     RSlot* rslot;

@@ -4,6 +4,8 @@ Small cases are compared with the oracle; the 512x512 / 20k- and 40k-face cases 
 seconds to minutes) are checked through properties the domain offers: forward determinism, "the winner is the nearest
 covering face" on sampled pixels (brute force in numpy), invariance of the render under a permutation of the faces,
 losses that do not depend on the batch a scene sits in."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -365,3 +367,64 @@ def test_large_frame_walks_several_hit_tiles_per_workgroup():
     assert np.linalg.norm(g - gref) <= 1e-4 * np.linalg.norm(gref)
     gv, gvr = gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()
     assert np.linalg.norm(gv - gvr) <= 5e-4 * np.linalg.norm(gvr)
+
+
+@gpu
+def test_k100_buffer_is_rebuilt_where_the_all_fragment_product_would_differ():
+    """SoftSilhouetteShader runs on the K = 100 NEAREST fragments of a pixel (RUN:106-116); the scatter rasteriser multiplies
+    over all of them, which is the same thing unless a pixel holds at least 100 fractional-coverage fragments.  Here three
+    pixel centres each sit 1.5e-4 .. 2.9e-4 NDC units outside an edge of 150 stacked slivers (150 fragments with
+    1 - p = 0.90 .. 0.999 each) in front of a face that covers them fully: the reference keeps the 100 nearest slivers
+    (alpha ~ 0.95), all fragments together would give alpha = 1.  Phase B (object only, silhouette weight 100) against the
+    oracle: alpha of those pixels, the loss, and the gradients -- which only the 100 fragments in the buffer receive."""
+    from followmyhold_amd import engine as E
+    H = W = 64
+    sct = make_scene("ico2", H, W, seed=5)
+    k00 = 1.0 / math.tan(math.radians(sct["fov"]) / 2)
+    px, py = 20, 30
+    xf = float(R.pix_ndc(torch.tensor(W - 1 - px), W, H, torch.float32))
+    yf = float(R.pix_ndc(torch.tensor(H - 1 - py), H, W, torch.float32))
+    n = 150
+    rng = np.random.default_rng(0)
+    delta = rng.uniform(1.5e-4, 2.9e-4, n)
+    depth = 0.40 + 0.0005 * np.arange(n)
+    tris = []
+    for k in range(n):                                   # (x_ndc, y_ndc, z_view) of sliver k: edge AB passes delta_k beside the pixel centres
+        a, b, c3 = (xf + delta[k], yf - 0.05), (xf + delta[k], yf + 0.05), (xf + delta[k] + 0.08, yf)
+        tris.append([[a[0], a[1], depth[k]], [b[0], b[1], depth[k]], [c3[0], c3[1], depth[k]]])
+    tris.append([[xf - 0.3, yf - 0.3, 0.6], [xf + 0.3, yf - 0.3, 0.6], [xf, yf + 0.3, 0.6]])      # covers the pixels fully, behind
+    ndc = np.array(tris, np.float64).reshape(-1, 3)
+    view = np.stack([ndc[:, 0] * ndc[:, 2] / k00, ndc[:, 1] * ndc[:, 2] / k00, ndc[:, 2]], 1)
+    world = view * np.array([-1.0, 1.0, -1.0])           # R = diag(-1, 1, -1), T = 0 (RUN:84-90)
+    sct = dict(sct, obj_verts=torch.from_numpy(world.astype(np.float32)), obj_faces=torch.arange(3 * (n + 1)).reshape(-1, 3),
+               T_h2m=torch.eye(4))
+    p = S.make_params()
+    st = S.PhaseStepper("B", sct, p)
+    total, terms, aux, grads = st.step(update=False)
+    sel = aux["render"]["sel"]
+    cnt = sel["count"].reshape(-1)
+    fix_px = [(py + dy) * W + px for dy in (-1, 0, 1)]
+    assert all(cnt[q] == 100 for q in fix_px)                                   # the K-buffer is full there
+    a_ref = aux["render"]["sil"].detach().numpy().reshape(-1)
+    assert all(0.5 < a_ref[q] < 0.999 for q in fix_px)                          # ... and the cut matters (all fragments: alpha = 1)
+    sc = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sct.items()}
+    gb = E.GuidanceBatch([sc], grid_res=16, n_renders=1)
+    cfg, _ = E.phase_cfg("B", do_update=False)
+    gb.step(cfg)
+    torch.cuda.synchronize()
+    assert int(gb.flags[0]) & 4 == 0
+    gb.raise_on_flags()
+    P_ = H * W
+    assert np.array_equal(gb.region("p2f", torch.int32, (1, P_))[0].cpu().numpy(), sel["pix_to_face"].reshape(-1))
+    prod = gb.region("prod", torch.float32, (1, P_))[0].cpu().numpy()
+    for q in fix_px:
+        assert abs((1.0 - prod[q]) - a_ref[q]) <= 1e-6, (q, 1.0 - prod[q], a_ref[q])
+    l = gb.loss_dict(0)
+    assert abs(l["sil0"] - float(terms["sil_obj"])) <= 1e-5 * abs(float(terms["sil_obj"]))
+    assert abs(l["total"] - float(total)) <= 1e-4 * abs(float(total))
+    gv, gvr = gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy()
+    assert np.abs(gvr[: 3 * 100]).max() > 0 and np.linalg.norm(gv - gvr) <= 1e-3 * np.linalg.norm(gvr)
+    # (slivers behind the buffer's cut-off get nothing from the silhouette of those pixels: part of the comparison above)
+    g = gb.grad_params[0].cpu().numpy()
+    for k in ["scale_obj", "trans_obj", "rot_obj"]:
+        assert np.linalg.norm(g[E.PARAM_SLICES[k]] - grads[k].numpy()) <= 1e-3 * max(np.linalg.norm(grads[k].numpy()), 1e-6), k
