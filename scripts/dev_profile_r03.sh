@@ -17,16 +17,16 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b1 -- 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b8 -- $B1 --images-per-gpu 8 --streams 1 > /dev/null 2>&1
 for t in b1 b8; do
   X=""; [ $t = b8 ] && X="--images-per-gpu 8 --streams 1"
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$t -- $NG $X > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$t -- $NG $X > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq_a_$t -- $NG $X > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $O/sq_b_$t -- $NG $X > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/d_fetch_$t -- $NG $X > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/d_write_$t -- $NG $X > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/d_sqa_$t -- $NG $X > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $O/d_sqb_$t -- $NG $X > /dev/null 2>&1
 done
 cd $R
 for t in b1 b8; do
   find $O/kt_$t -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_$t.csv
-  python scripts/summarize_pmc.py $(find $O/pmc_fetch_$t $O/pmc_write_$t -name "*counter_collection.csv") > $O/pmc_fetch_write_$t.csv
-  python scripts/summarize_pmc.py $(find $O/sq_a_$t $O/sq_b_$t -name "*counter_collection.csv") > $O/sq_counters_$t.csv
+  python scripts/summarize_pmc.py $(find $O/d_fetch_$t $O/d_write_$t -name "*counter_collection.csv") > $O/pmc_fetch_write_$t.csv
+  python scripts/summarize_pmc.py $(find $O/d_sqa_$t $O/d_sqb_$t -name "*counter_collection.csv") > $O/sq_counters_$t.csv
 done
-rm -rf $O/kt_b1 $O/kt_b8 $O/pmc_fetch_* $O/pmc_write_b1 $O/pmc_write_b8 $O/sq_a_* $O/sq_b_*
+rm -rf $O/kt_b1 $O/kt_b8 $O/d_fetch_* $O/d_write_* $O/d_sqa_* $O/d_sqb_*
 ls -la $O; cat $O/pmc_fetch_write_b1.csv; cat $O/pmc_fetch_write_b8.csv; head -8 $O/kernel_stats_b1.csv | cut -c1-120; head -8 $O/kernel_stats_b8.csv | cut -c1-120

@@ -1,12 +1,13 @@
-"""profiles/r02_sq_summary.md from the two SQ-counter summaries (scripts/dev_profile_r02.sh)."""
-import csv, collections
-print("# SQ counters of the guidance step, round 2 (rocprofv3 --pmc, two passes, `scripts/dev_profile_r02.sh`)\n")
+"""profiles/rNN_sq_summary.md from the two SQ-counter summaries (scripts/dev_profile_rNN.sh): `python scripts/sq_summary.py r03`."""
+import csv, collections, sys
+RN = sys.argv[1] if len(sys.argv) > 1 else "r02"
+print(f"# SQ counters of the guidance step, round {RN[1:].lstrip('0')} (rocprofv3 --pmc, two passes, `scripts/dev_profile_{RN}.sh`)\n")
 print("`python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-graph [--images-per-gpu 8 --streams 1]`; means per launch.")
 print("dur = GRBM_GUI_ACTIVE / 8 XCDs at 2.4 GHz (inflated by the counter collection: 1.5-2x the un-profiled kernel time);")
 print("resident = SQ_WAVE_CYCLES x 4 / cycles (average waves in flight on the chip); wave life = SQ_WAVE_CYCLES x 4 / SQ_WAVES;")
 print("wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of wave time waiting for memory / LDS / barriers); active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES;")
 print("VALU util = SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs): the share of the chip's VALU issue slots in use during the launch.\n")
-for t, path in (("one image (configs[1])", "profiles/r02_rocprofv3_sq_counters_b1.csv"), ("8 images on one stream", "profiles/r02_rocprofv3_sq_counters_b8_1stream.csv")):
+for t, path in (("one image (configs[1])", f"profiles/{RN}_rocprofv3_sq_counters_b1.csv"), ("8 images on one stream", f"profiles/{RN}_rocprofv3_sq_counters_b8_1stream.csv")):
     d = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
         d[r["kernel"]][r["counter"]] = float(r["mean_per_launch"])
