@@ -12,7 +12,7 @@ print the batch totals.  There is no collective on the data path.  FOHO_DIST_BAC
 CPU-side reduce (several ranks on one GPU / no GPU: tests).
 
 With FOHO_MESH_LEVEL_GUIDANCE=1 (fixed object meshes, no diffusion networks) the rank's images do not go one by one: `run()`
-hands them to followmyhold_amd.inputs.MeshGuidanceRunner, FOHO_IMAGES_IN_FLIGHT (default 8) at a time -- several images per
+hands them to followmyhold_amd.inputs.MeshGuidanceRunner, FOHO_IMAGES_IN_FLIGHT (default 16) at a time -- several images per
 kernel launch on several HIP streams, graphs captured once per process -- with the reference's per-image skip rules and
 error isolation kept (an image that fails is reported and the others go on).
 
@@ -266,7 +266,7 @@ def _mesh_level_batched() -> bool:
     networks are not there (with them, every image is a full pipeline call and stays one at a time like RUN:208-259)."""
     if os.environ.get("FOHO_MESH_LEVEL_GUIDANCE") != "1" or os.environ.get("FOHO_STANDIN_NETWORKS") == "1":
         return False
-    if int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "8")) < 1:
+    if int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")) < 1:
         return False
     try:
         import hy3dgen.shapegen  # noqa: F401
@@ -297,7 +297,7 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     "Error in processing")."""
     from followmyhold_amd import engine as E
     from followmyhold_amd import inputs
-    in_flight = int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "8"))
+    in_flight = int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16"))
     runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
     jr, render_fn = None, None
     n_iter = _n_iterations(config)

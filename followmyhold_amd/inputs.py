@@ -310,13 +310,14 @@ class MeshGuidanceRunner:
     object is not a closed manifold (device-side edge tables refuse: flag bit 5) are reported with ok=False,
     reason="fallback": the caller runs them through `run_mesh_guidance`."""
 
-    def __init__(self, config=None, device="cuda", in_flight=8, n_streams=None, grid_res=64):
+    def __init__(self, config=None, device="cuda", in_flight=16, n_streams=None, grid_res=64):
         from . import engine as E
         self.E = E
         self.config = config if config is not None else E.OptimizationConfig()
         self.device = device
         self.in_flight = max(1, int(in_flight))
-        # two images per stream, at most four streams: the setting bench.py's `batched` record measures (DESIGN.md section 6)
+        # at most four streams (HIP has four hardware queues, DESIGN.md section 6), at least two images per stream; measured for
+        # whole jobs: 116 images/s at 8 in flight (4 x 2, the setting bench.py's `batched` record uses), 160 at 16 (4 x 4)
         self.n_streams = int(n_streams) if n_streams else max(1, min(4, (self.in_flight + 1) // 2))
         self.grid_res = grid_res
         self.group = None
