@@ -121,7 +121,7 @@ def dominant_from_kernel_stats(names, workload):
 
 def pick_spg(steps, cap=0):
     spg = 1
-    for cand in (50, 25, 10, 5):
+    for cand in (50, 25, 20, 10, 5):
         if steps % cand == 0:
             spg = cand
             break
@@ -135,24 +135,26 @@ def make_runner(E, torch, scenes, n_streams, dev, cfg, spg, graph=True, joint=Fa
     ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device=dev)  # PL:1207-1215
 
     state = {"it": 0}
+    window = max(spg, 1) * max(1, round(50 / max(spg, 1)))     # 50 iterations, or the multiple of the graph length next to it
 
     def run_steps(n):
         """Every CFG.joint_iters = 50 iterations the reference starts a new denoising step with a fresh AdamW
         (PL:1478).  The pose parameters are put back to the scene's start point as well, so that the measured
         workload stays the configs[1] scene instead of whatever the synthetic optimisation drifts to (with the
         reference's learning rates the synthetic object shrinks away after ~150 iterations, which would make the
-        rasteriser's job easier than the benchmark claims).  The 50-iteration windows run across calls: a timed
-        region of 20 iterations holds a restart in two out of five repeats, not in every one."""
+        rasteriser's job easier than the benchmark claims).  The windows (50 iterations, 40 when the graphs hold 20) run
+        across calls: a timed region of 20 iterations holds a restart in every second repeat, not in every one."""
         done = 0
         while done < n:
-            if state["it"] % 50 == 0:
+            if state["it"] % window == 0:
                 group.restart(ident)
-            k = min(50 - state["it"] % 50, n - done)
+            k = min(window - state["it"] % window, n - done)
             group.run(cfg, k)
             done += k
             state["it"] += k
 
     run_steps.realign = lambda: state.update(it=0)     # the next call starts a window (with a restart)
+    run_steps.window = window
     return group, run_steps
 
 
@@ -276,7 +278,7 @@ def main():
                                f"{m0['Vo']}-vert/{m0['Fo']}-face object, joint guidance step (phase C)",
                    "images_per_gpu": ipg, "global_images": world * ipg, "parallelism": f"image-sharded x{world}",
                    "hip_graph": not args.no_graph, "steps_per_graph": spg, "streams": len(group.batches),
-                   "restart_every": 50},
+                   "restart_every": run_steps.window},
         "final_loss_mean": float(metrics[2] / max(metrics[0], 1.0)), "nan_images": int(metrics[sharding.IDX["n_nan"]]),
         "metrics": {k: float(v) for k, v in zip(sharding.METRIC_NAMES, metrics.tolist())},
     }
