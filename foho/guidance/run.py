@@ -297,7 +297,8 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     "Error in processing")."""
     from followmyhold_amd import engine as E
     from followmyhold_amd import inputs
-    in_flight = int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16"))
+    # no more slots than list entries: a short list must not be padded up to the default with copies of its first image
+    in_flight = max(1, min(int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")), len(assigned_imgs)))
     runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
     jr, render_fn = None, None
     n_iter = _n_iterations(config)
