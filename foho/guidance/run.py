@@ -275,17 +275,24 @@ def _mesh_level_batched() -> bool:
         return True
 
 
-def _screen(cropped_obj_img, dirs):
-    """RUN:210-236 for one list entry: paths, skip rules, fov.  Returns (paths, fovx) or None when the image is skipped."""
+def _screen(cropped_obj_img, dirs, say=print):
+    """RUN:210-236 for one list entry: paths, skip rules, fov.  Returns (paths, fovx), or None when the image is skipped
+    (say=print: the reference's message is printed; say=None: the message is returned instead, for callers that report in
+    list order)."""
     p = derive_paths(cropped_obj_img, **dirs)
     index = p["index"]
+    msg = None
     if os.path.exists(p["save_path_obj"]) and os.path.exists(p["save_path_hand"]):
-        print(f"{index} already exists, skipping")
-        return None
-    with open(p["moge_fov_path"], "r", encoding="utf-8") as f:
-        fovx = float(json.load(f)["fov_x"])
-    if _read_mask(p["cropped_hand_mask_path"]).max() == 0 or _read_mask(p["cropped_obj_mask_path"]).max() == 0:
-        print(f"Skipping {index} due to empty mask")
+        msg = f"{index} already exists, skipping"
+    else:
+        with open(p["moge_fov_path"], "r", encoding="utf-8") as f:
+            fovx = float(json.load(f)["fov_x"])
+        if _read_mask(p["cropped_hand_mask_path"]).max() == 0 or _read_mask(p["cropped_obj_mask_path"]).max() == 0:
+            msg = f"Skipping {index} due to empty mask"
+    if msg is not None:
+        if say is None:
+            return msg
+        say(msg)
         return None
     return p, fovx
 
@@ -300,7 +307,6 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     # no more slots than list entries: a short list must not be padded up to the default with copies of its first image
     in_flight = max(1, min(int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")), len(assigned_imgs)))
     runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
-    jr, render_fn = None, None
     n_iter = _n_iterations(config)
     pending = []                     # (list entry, paths, scene)
 
@@ -343,24 +349,63 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
             except Exception as e:  # noqa: BLE001 -- RUN:257-259
                 fail(name, e)
 
-    for cropped_obj_img in assigned_imgs:
+    # Reading an image's files (two masks, three meshes -- the MoGe image mesh has half a million faces --, key points) and
+    # rendering its target maps costs the host 35 ms, five times the image's share of the GPU job: the list entries are
+    # prepared by a pool of threads, a bounded number ahead of the set the GPU is working on (file parsing releases the GIL;
+    # every worker renders on its own stream and waits for that stream only).  Messages, results and failures are consumed in
+    # list order, so the log reads like the reference's sequential loop.
+    import concurrent.futures as cf
+    import threading
+    import torch
+    jr = inputs.load_j_regressor()
+    local = threading.local()
+    dev_index = torch.device(device).index
+    if dev_index is None:
+        dev_index = torch.cuda.current_device()      # the GPU _dist_setup() bound; the current device is a per-thread setting
+
+    def prepare(cropped_obj_img):
         try:
-            scr = _screen(cropped_obj_img, dirs)
-            if scr is None:
-                continue
+            scr = _screen(cropped_obj_img, dirs, say=None)
+            if isinstance(scr, str):
+                return ("skip", scr)
             p, fovx = scr
-            print(f"Processing {p['index']}")
-            if jr is None:
-                jr, render_fn = inputs.load_j_regressor(), E.hip_render_fn(device)
-            scene = inputs.load_scene_from_files(p, jr, render_fn)
+            if not hasattr(local, "stream"):
+                torch.cuda.set_device(dev_index)
+                local.stream, local.render_fn = torch.cuda.Stream(device), E.hip_render_fn(device)
+            with torch.cuda.stream(local.stream):
+                scene = inputs.load_scene_from_files(p, jr, local.render_fn)
+                local.stream.synchronize()
             scene["fov"] = float(fovx)
-            pending.append((cropped_obj_img, p, scene))
+            return ("ok", p, scene)
         except Exception as e:  # noqa: BLE001 -- RUN:257-259
-            fail(cropped_obj_img, e)
-            continue
-        if len(pending) >= in_flight:
-            flush()
-    flush()
+            return ("fail", e)
+
+    workers = max(1, min(int(os.environ.get("FOHO_LOADER_THREADS", "8")), os.cpu_count() or 1))
+    ahead = max(2 * in_flight, workers)
+    with cf.ThreadPoolExecutor(max_workers=workers) as pool:
+        todo = iter(assigned_imgs)
+        queue = []
+        for name in todo:
+            queue.append((name, pool.submit(prepare, name)))
+            if len(queue) >= ahead:
+                break
+        while queue:
+            name, fut = queue.pop(0)
+            nxt = next(todo, None)
+            if nxt is not None:
+                queue.append((nxt, pool.submit(prepare, nxt)))
+            out = fut.result()
+            if out[0] == "skip":
+                print(out[1])
+                continue
+            if out[0] == "fail":
+                fail(name, out[1])
+                continue
+            print(f"Processing {out[1]['index']}")
+            pending.append((name, out[1], out[2]))
+            if len(pending) >= in_flight:
+                flush()
+        flush()
 
 
 def _tally_named(**kw) -> None:

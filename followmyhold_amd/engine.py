@@ -1038,7 +1038,7 @@ def hip_render_fn(device="cuda"):
         cfg, _ = phase_cfg("B", do_update=False)
         cfg.world_space_input = 1     # the reference renders the target mesh as it is (PL:1247-1256)
         gb.step(cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream(gb.device).synchronize()     # this stream only: loader threads render next to a running job
         gb.raise_on_flags()
         P = H * W
         p2f = gb.region("p2f", torch.int32, (P,)).long()
