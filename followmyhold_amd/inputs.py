@@ -80,11 +80,12 @@ def load_glb(path):
     if magic != _GLB_MAGIC or version != 2:
         raise ValueError(f"{path}: not a binary glTF 2.0 file")
     off, gltf, binary = 12, None, b""
+    view = memoryview(data)          # chunk slices without copying the (megabytes of) geometry
     while off + 8 <= min(length, len(data)):
         clen, ctype = struct.unpack_from("<II", data, off)
-        chunk = data[off + 8:off + 8 + clen]
+        chunk = view[off + 8:off + 8 + clen]
         if ctype == _CHUNK_JSON:
-            gltf = json.loads(chunk.decode("utf-8"))
+            gltf = json.loads(bytes(chunk).decode("utf-8"))
         elif ctype == _CHUNK_BIN:
             binary = chunk
         off += 8 + clen
@@ -100,14 +101,19 @@ def load_glb(path):
             for prim in gltf["meshes"][node["mesh"]]["primitives"]:
                 if prim.get("mode", 4) != 4:
                     continue
-                p = _accessor(gltf, binary, prim["attributes"]["POSITION"]).astype(np.float64)
-                p = p @ m[:3, :3].T + m[:3, 3]
+                p = _accessor(gltf, binary, prim["attributes"]["POSITION"])
+                if np.array_equal(m, np.eye(4)):     # the usual case (MoGe writes one untransformed primitive): no float64 round trip
+                    p = p.astype(np.float32, copy=False)
+                else:
+                    p = (p.astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
                 if "indices" in prim:
                     idx = _accessor(gltf, binary, prim["indices"]).reshape(-1).astype(np.int64)
                 else:
                     idx = np.arange(len(p), dtype=np.int64)
-                verts.append(p.astype(np.float32))
-                faces.append(idx.reshape(-1, 3) + voff)
+                if voff:
+                    idx = idx + voff
+                verts.append(p)
+                faces.append(idx.reshape(-1, 3))
                 voff += len(p)
         for c in node.get("children", []):
             visit(c, m)
@@ -118,6 +124,8 @@ def load_glb(path):
         visit(r, np.eye(4))
     if not verts:
         raise ValueError(f"{path}: no triangle primitive")
+    if len(verts) == 1:
+        return np.ascontiguousarray(verts[0]), faces[0]
     return np.concatenate(verts, 0), np.concatenate(faces, 0)
 
 
