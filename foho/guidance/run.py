@@ -371,10 +371,16 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
             p, fovx = scr
             if not hasattr(local, "stream"):
                 torch.cuda.set_device(dev_index)
-                local.stream, local.render_fn = torch.cuda.Stream(device), E.hip_render_fn(device)
+                render = E.hip_render_fn(device)
+
+                def locked_render(*a):      # never while the runner captures a graph (MeshGuidanceRunner.gpu_lock)
+                    with runner.gpu_lock:
+                        return render(*a)
+                with runner.gpu_lock:
+                    local.stream = torch.cuda.Stream(device)
+                local.render_fn = locked_render
             with torch.cuda.stream(local.stream):
                 scene = inputs.load_scene_from_files(p, jr, local.render_fn)
-                local.stream.synchronize()
             scene["fov"] = float(fovx)
             return ("ok", p, scene)
         except Exception as e:  # noqa: BLE001 -- RUN:257-259

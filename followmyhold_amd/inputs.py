@@ -331,6 +331,10 @@ class MeshGuidanceRunner:
         self.group = None
         self.graphs = {}
         self.stats = dict(captures=0, groups_built=0, image_sets=0)
+        # hipGraph capture does not tolerate GPU work from other threads of the process (torch: "capture_error_mode global"):
+        # whoever prepares inputs on the GPU next to a running runner (the driver's loader threads) holds this lock meanwhile
+        import threading
+        self.gpu_lock = threading.Lock()
 
     # -------------------------------------------------------------------------------------------- slots
     @staticmethod
@@ -358,9 +362,10 @@ class MeshGuidanceRunner:
         if g is None:
             import torch
             g = []
-            for gb, st in zip(group.batches, group.streams):
-                with torch.cuda.stream(st):
-                    g.append(gb.capture(cfg, steps_per_graph=spg))
+            with self.gpu_lock:
+                for gb, st in zip(group.batches, group.streams):
+                    with torch.cuda.stream(st):
+                        g.append(gb.capture(cfg, steps_per_graph=spg))
             self.graphs[key] = g
             self.stats["captures"] += 1
         return g
