@@ -373,12 +373,12 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
                 torch.cuda.set_device(dev_index)
                 render = E.hip_render_fn(device)
 
-                def locked_render(*a):      # never while the runner captures a graph (MeshGuidanceRunner.gpu_lock)
-                    with runner.gpu_lock:
+                def gated_render(*a):      # never while the runner captures a graph (inputs.GpuGate)
+                    with runner.gpu_gate.shared():
                         return render(*a)
-                with runner.gpu_lock:
+                with runner.gpu_gate.shared():
                     local.stream = torch.cuda.Stream(device)
-                local.render_fn = locked_render
+                local.render_fn = gated_render
             with torch.cuda.stream(local.stream):
                 scene = inputs.load_scene_from_files(p, jr, local.render_fn)
             scene["fov"] = float(fovx)

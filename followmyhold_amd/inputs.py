@@ -302,6 +302,55 @@ def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None
     return gb
 
 
+class GpuGate:
+    """Many `shared()` holders OR one `exclusive()` holder.  hipGraph capture does not tolerate GPU work from other threads of
+    the process (torch's capture_error_mode "global"): the runner captures under exclusive(), whoever prepares inputs on the
+    GPU next to it (the driver's loader threads) works under shared() -- loaders do not exclude each other."""
+
+    def __init__(self):
+        import threading
+        self._cv = threading.Condition()
+        self._shared, self._excl = 0, False
+
+    class _Ctx:
+        def __init__(self, enter, leave):
+            self._enter, self._leave = enter, leave
+
+        def __enter__(self):
+            self._enter()
+
+        def __exit__(self, *a):
+            self._leave()
+
+    def shared(self):
+        def enter():
+            with self._cv:
+                while self._excl:
+                    self._cv.wait()
+                self._shared += 1
+
+        def leave():
+            with self._cv:
+                self._shared -= 1
+                self._cv.notify_all()
+        return GpuGate._Ctx(enter, leave)
+
+    def exclusive(self):
+        def enter():
+            with self._cv:
+                while self._excl:
+                    self._cv.wait()
+                self._excl = True            # new shared holders wait from here on
+                while self._shared:
+                    self._cv.wait()
+
+        def leave():
+            with self._cv:
+                self._excl = False
+                self._cv.notify_all()
+        return GpuGate._Ctx(enter, leave)
+
+
 class MeshGuidanceRunner:
     """The mesh-level guidance job for MANY images per GPU ("within a GPU, batch the rank's images through
     each kernel launch"; the reference walks its list one image at a time with batch size 1, RUN:208-259, CFG:9).
@@ -331,10 +380,7 @@ class MeshGuidanceRunner:
         self.group = None
         self.graphs = {}
         self.stats = dict(captures=0, groups_built=0, image_sets=0)
-        # hipGraph capture does not tolerate GPU work from other threads of the process (torch: "capture_error_mode global"):
-        # whoever prepares inputs on the GPU next to a running runner (the driver's loader threads) holds this lock meanwhile
-        import threading
-        self.gpu_lock = threading.Lock()
+        self.gpu_gate = GpuGate()      # captures under exclusive(), loader threads under shared()
 
     # -------------------------------------------------------------------------------------------- slots
     @staticmethod
@@ -362,7 +408,7 @@ class MeshGuidanceRunner:
         if g is None:
             import torch
             g = []
-            with self.gpu_lock:
+            with self.gpu_gate.exclusive():
                 for gb, st in zip(group.batches, group.streams):
                     with torch.cuda.stream(st):
                         g.append(gb.capture(cfg, steps_per_graph=spg))
