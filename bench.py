@@ -21,6 +21,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   cpu_baseline        the CPU oracle ("port" of the reference path) on this box's host cores, bounded sample;
   cpu_baseline_1t     the same with one thread, the reference's own thread policy (src/foho/main.py:65-68)
   batched             configs[2]'s per-GPU regime: 8 frames per GPU, 4 streams x 2 frames
+  job                 the 750-iteration per-image job through the product entry point's engine at 1 / 8 / 16 images in flight
+  driver_on_files     foho.guidance.run.run() on scene folders in the reference's file formats, wall time per image
   topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
 """
 import argparse
@@ -347,7 +349,8 @@ def main():
                             ("batched_f16_gbuffer", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)),
                             ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
-                            ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev))):
+                            ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
+                            ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
                 try:
                     out[key] = fn()
                 except Exception as e:  # noqa: BLE001
@@ -486,6 +489,62 @@ def topology_record(E, torch, scene, dev, steps=200):
             "launches_per_step": 18,
             "what": "SDF -> FlexiCubes -> new object installed on the device (records, topology tables, pair table, AABB) -> "
                     "fused joint step -> dL/dSDF; new topology every iteration, one hipGraph replay, no host sync"}
+
+
+def driver_record(E, torch, np, synthetic, render_fn, args, n_img=32):
+    """The product entry point itself, on FILES: `foho.guidance.run.run(...)` (FOHO_MESH_LEVEL_GUIDANCE=1) over n_img scene
+    folders in the reference's formats and names -- masks, key points, aligned MANO and Hunyuan meshes, the 4 x 4 transform,
+    fov.json and a 522 k-face MoGe image mesh (mesh.glb) per image --, wall time from the call to the last written
+    `{idx}_obj.ply` / `{idx}_hand.ply`: file parsing, the target-map render of the image mesh, uploads, the 750-iteration job,
+    read-back and PLY export included.  Second of two calls (the first pays module loads); graphs are captured per call."""
+    import shutil
+    import tempfile
+    import contextlib
+    import io
+    from followmyhold_amd import inputs
+    from foho.guidance import run as G
+    H = W = args.size
+    tmp = tempfile.mkdtemp(prefix="foho_bench_")
+    try:
+        names = ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir", "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir"]
+        d = {k: os.path.join(tmp, k) for k in names}
+        ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")          # MoGe-style image mesh: one vertex per pixel
+        t = np.tan(np.radians(60.0) / 2)
+        z = 0.5 + 0.1 * np.sin(xs / W * 6.0) * np.cos(ys / H * 5.0)
+        mv = np.stack([(xs + 0.5 - W / 2) / (W / 2) * t * z * 0.9, -(ys + 0.5 - H / 2) / (H / 2) * t * z * 0.9, -z], -1).reshape(-1, 3).astype(np.float32)
+        i = (ys[:-1, :-1] * W + xs[:-1, :-1]).reshape(-1)
+        mf = np.concatenate([np.stack([i, i + W, i + 1], 1), np.stack([i + 1, i + W, i + W + 1], 1)], 0).astype(np.int64)
+        sc = None
+        for k in range(n_img):
+            sc = synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=300 + k)
+            inputs.save_scene_files(sc, mv, mf, d, f"{k:04d}")
+        jr = os.path.join(tmp, "J.npy")
+        np.save(jr, sc["J_regressor"])
+        env = {"FOHO_J_REGRESSOR": jr, "FOHO_MESH_LEVEL_GUIDANCE": "1"}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            rec = {}
+            for rep in range(2):
+                out_dir = os.path.join(tmp, f"out{rep}")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    tot = G.run(project_root=tmp, task_list_file=None, guidance_out_dir=out_dir, **d)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                rec = {"images": n_img, "images_per_s": n_img / dt, "ms_per_image": dt * 1e3 / n_img, "n_images": tot["n_images"],
+                       "n_failed": tot["n_failed"], "meshes_written": len(os.listdir(out_dir)), "moge_mesh_faces": int(len(mf)),
+                       "in_flight": int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")), "loader_threads": int(os.environ.get("FOHO_LOADER_THREADS", "8"))}
+            return rec
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def parity_record(E, torch, np, scene, dev, first):
