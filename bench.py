@@ -439,7 +439,7 @@ def job_record(E, torch, synthetic, render_fn, args, dev):
         ok = sum(1 for r in res if r["ok"])
         rec[f"in_flight_{in_flight}"] = {"images": n_img, "ok": ok, "images_per_s": n_img / dt, "ms_per_image": dt * 1e3 / n_img,
                                          "guidance_steps_per_s": n_img * n_iter / dt, "streams": runner.n_streams,
-                                         "graph_captures": runner.stats["captures"], "groups_built": runner.stats["groups_built"]}
+                                         "graph_captures": runner.stats["captures"], "slots_built": runner.stats["slots_built"]}
     return rec
 
 

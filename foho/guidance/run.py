@@ -302,13 +302,11 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     per image: a file that does not load, an image the runner hands back (object not a closed manifold -> the exact-size
     single-image driver), a NaN in phase B (the reference's pipeline returns None there, PL:1442-1444, which surfaces as
     "Error in processing")."""
-    from followmyhold_amd import engine as E
     from followmyhold_amd import inputs
     # no more slots than list entries: a short list must not be padded up to the default with copies of its first image
     in_flight = max(1, min(int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")), len(assigned_imgs)))
     runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
     n_iter = _n_iterations(config)
-    pending = []                     # (list entry, paths, scene)
 
     def fail(name, e):
         print(f"Error in processing {name} : {e}")
@@ -317,9 +315,10 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     def finish(name, p, res):
         if not res["ok"] and res.get("reason") == "fallback":      # any mesh goes through the exact-size driver
             res = None
-            obj_mesh, hand_mesh = _mesh_level_guidance(
-                None, p["hamer_for_guid_path"], p["aligned_mano_mesh_path"], p["cropped_obj_mask_path"], p["cropped_hand_mask_path"],
-                p["moge_mesh_path"], p["T_h2m_path"], p["hunyuan_hoi_mesh_path"], p["save_path_obj"], p["save_path_hand"], config, device)
+            with runner.gpu_gate.exclusive():      # it captures graphs of its own: not next to the loader threads' renders
+                obj_mesh, hand_mesh = _mesh_level_guidance(
+                    None, p["hamer_for_guid_path"], p["aligned_mano_mesh_path"], p["cropped_obj_mask_path"], p["cropped_hand_mask_path"],
+                    p["moge_mesh_path"], p["T_h2m_path"], p["hunyuan_hoi_mesh_path"], p["save_path_obj"], p["save_path_hand"], config, device)
         else:
             if not res["ok"]:
                 raise RuntimeError(res["reason"])
@@ -333,35 +332,13 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
             return
         print(f"Reconstructed object {p['index']}")
 
-    def flush():
-        if not pending:
-            return
-        names, paths, scenes = zip(*pending)
-        pending.clear()
-        try:
-            results = runner.run(list(scenes))
-        except Exception as e:  # noqa: BLE001 -- the image set as a whole failed: every image gets its own try, one at a time
-            print(f"Image set of {len(names)} failed as a whole ({e}); retrying its images one by one")
-            results = [dict(ok=False, reason="fallback") for _ in names]
-        for name, p, res in zip(names, paths, results):
-            try:
-                finish(name, p, res)
-            except Exception as e:  # noqa: BLE001 -- RUN:257-259
-                fail(name, e)
-
-    # Reading an image's files (two masks, three meshes -- the MoGe image mesh has half a million faces --, key points) and
-    # rendering its target maps costs the host 35 ms, five times the image's share of the GPU job: the list entries are
-    # prepared by a pool of threads, a bounded number ahead of the set the GPU is working on (file parsing releases the GIL;
-    # every worker renders on its own stream and waits for that stream only).  Messages, results and failures are consumed in
-    # list order, so the log reads like the reference's sequential loop.
-    import concurrent.futures as cf
-    import threading
-    import torch
+    # Reading an image's files (two masks, three meshes -- the MoGe image mesh has half a million faces --, key points) costs
+    # the host 25-35 ms, five times the image's share of the GPU job: the list entries are prepared by a pool of threads, a
+    # bounded number ahead of the images on the GPU.  The threads do HOST work only (file parsing releases the GIL); the
+    # image mesh travels with the scene and is rendered into the target maps on the device, inside the image's job
+    # (engine.TargetRenderer) -- GPU work from loader threads would queue behind whole jobs on the shared hardware queues.
+    # Messages, results and failures are consumed in list order, so the log reads like the reference's sequential loop.
     jr = inputs.load_j_regressor()
-    local = threading.local()
-    dev_index = torch.device(device).index
-    if dev_index is None:
-        dev_index = torch.cuda.current_device()      # the GPU _dist_setup() bound; the current device is a per-thread setting
 
     def prepare(cropped_obj_img):
         try:
@@ -369,18 +346,7 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
             if isinstance(scr, str):
                 return ("skip", scr)
             p, fovx = scr
-            if not hasattr(local, "stream"):
-                torch.cuda.set_device(dev_index)
-                render = E.hip_render_fn(device)
-
-                def gated_render(*a):      # never while the runner captures a graph (inputs.GpuGate)
-                    with runner.gpu_gate.shared():
-                        return render(*a)
-                with runner.gpu_gate.shared():
-                    local.stream = torch.cuda.Stream(device)
-                local.render_fn = gated_render
-            with torch.cuda.stream(local.stream):
-                scene = inputs.load_scene_from_files(p, jr, local.render_fn)
+            scene = inputs.load_scene_from_files(p, jr, None)
             scene["fov"] = float(fovx)
             return ("ok", p, scene)
         except Exception as e:  # noqa: BLE001 -- RUN:257-259
@@ -388,30 +354,52 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
 
     workers = max(1, min(int(os.environ.get("FOHO_LOADER_THREADS", "8")), os.cpu_count() or 1))
     ahead = max(2 * in_flight, workers)
+    # The main thread feeds the GPU with many short calls that release the interpreter lock (graph replays, copies, event
+    # waits); with the default 5 ms switch interval every re-acquisition may wait that long for a loader thread in the middle
+    # of Python code.  A short interval for the duration of the batch keeps the hand-overs in the 0.1 ms range.
+    import sys
+    old_interval = sys.getswitchinterval()
+    sys.setswitchinterval(1e-4)
+    try:
+        _feed(runner, assigned_imgs, prepare, workers, ahead, fail, finish)
+    finally:
+        sys.setswitchinterval(old_interval)
+
+
+def _feed(runner, assigned_imgs, prepare, workers, ahead, fail, finish) -> None:
+    import concurrent.futures as cf
     with cf.ThreadPoolExecutor(max_workers=workers) as pool:
-        todo = iter(assigned_imgs)
-        queue = []
-        for name in todo:
-            queue.append((name, pool.submit(prepare, name)))
-            if len(queue) >= ahead:
-                break
-        while queue:
-            name, fut = queue.pop(0)
-            nxt = next(todo, None)
-            if nxt is not None:
-                queue.append((nxt, pool.submit(prepare, nxt)))
-            out = fut.result()
-            if out[0] == "skip":
-                print(out[1])
-                continue
-            if out[0] == "fail":
-                fail(name, out[1])
-                continue
-            print(f"Processing {out[1]['index']}")
-            pending.append((name, out[1], out[2]))
-            if len(pending) >= in_flight:
-                flush()
-        flush()
+        def loaded():
+            """(list entry, paths), scene of every entry that passes the skip rules and loads, in list order."""
+            todo = iter(assigned_imgs)
+            queue = []
+            for name in todo:
+                queue.append((name, pool.submit(prepare, name)))
+                if len(queue) >= ahead:
+                    break
+            while queue:
+                name, fut = queue.pop(0)
+                nxt = next(todo, None)
+                if nxt is not None:
+                    queue.append((nxt, pool.submit(prepare, nxt)))
+                out = fut.result()
+                if out[0] == "skip":
+                    print(out[1])
+                elif out[0] == "fail":
+                    fail(name, out[1])
+                else:
+                    print(f"Processing {out[1]['index']}")
+                    yield (name, out[1]), out[2]
+
+        # the runner keeps `in_flight` images on the GPU and as many queued behind them; a finished image is exported while
+        # the next ones run (inputs.MeshGuidanceRunner.run_stream)
+        for (name, p), res in runner.run_stream(loaded(), total=len(assigned_imgs)):
+            try:
+                if "error" in res:
+                    print(f"The job of {p['index']} failed as a whole ({res['error']}); retrying the image on its own")
+                finish(name, p, res)
+            except Exception as e:  # noqa: BLE001 -- RUN:257-259
+                fail(name, e)
 
 
 def _tally_named(**kw) -> None:

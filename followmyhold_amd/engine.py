@@ -165,6 +165,9 @@ def phase_cfg(phase, config=None, denoise_i=19, do_update=True, sigma=1e-8, gamm
     return c, n_renders
 
 
+_WARMED_DEVICES = set()     # GPUs on which this process has launched the step once (GuidanceBatch.capture)
+
+
 class GuidanceBatch:
     """Device-resident state of B guidance loops.
 
@@ -177,7 +180,8 @@ class GuidanceBatch:
                  gbuf_f16=False):
         """topology: "auto" builds the tables on the device (foho_topology_tables; closed manifold object meshes) and falls
         back to the host builders when the validity flag says so; "host" always uses the numpy builders; "render" builds
-        the incidence lists only (target-map renders need no edge tables).
+        the incidence lists only (target-map renders need no edge tables); "deferred" allocates the lists and leaves them
+        to the caller.
 
         obj_capacity=(verts, faces): CAPACITY MODE (foho_object_update): every image gets that many object vertex / face
         slots, the actual object of an iteration -- its counts live on the device only -- is installed by
@@ -248,6 +252,11 @@ class GuidanceBatch:
             self.obj_faces64 = torch.zeros(B, self.obj_capacity[1], 3, dtype=torch.int64, device=dev)
             self.lib.foho_object_workspace_bytes.restype = ctypes.c_size_t
             self.obj_ws = torch.zeros(self.lib.foho_object_workspace_bytes(self.Vtot, self.Ftot), dtype=torch.uint8, device=dev)
+        elif topology == "deferred":    # the caller builds the incidence lists itself before the first step (TargetRenderer)
+            ok = True
+            self.inc_off = torch.zeros(self.Vtot + 1, dtype=torch.int32, device=dev)
+            self.inc_fc = torch.zeros(3 * max(self.Ftot, 1), dtype=torch.int32, device=dev)
+            self.nbr_off, self.nbr_idx = torch.zeros(self.Vtot + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
         elif topology in ("auto", "render") and self.Ftot > 0:
             ok = self._device_topology(t(obj_flag, torch.uint8) if topology == "auto" else None)
             if ok and topology == "auto":
@@ -277,8 +286,12 @@ class GuidanceBatch:
         self._images_host = images
         img_bytes = b"".join(bytes(im) for im in images)
         self.images = torch.frombuffer(bytearray(img_bytes), dtype=torch.uint8).to(dev)
-        self.tgt_normal = t(np.stack([s["moge_normal"] for s in scenes]), torch.float32)
-        self.tgt_disp = t(np.stack([s["moge_disp"] for s in scenes]), torch.float32)
+        if all("moge_normal" in s for s in scenes):
+            self.tgt_normal = t(np.stack([s["moge_normal"] for s in scenes]), torch.float32)
+            self.tgt_disp = t(np.stack([s["moge_disp"] for s in scenes]), torch.float32)
+        else:       # target maps come from a TargetRenderer, on the device
+            self.tgt_normal = torch.zeros(B, H, W, 3, device=dev)
+            self.tgt_disp = torch.zeros(B, H, W, device=dev)
         mask = np.stack([(np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1))
                          for s in scenes])
         self.mask = t(mask, torch.uint8)
@@ -305,6 +318,7 @@ class GuidanceBatch:
         d.grid_res, d.frac_cap, d.n_renders = grid_res, frac_cap, n_renders
         d.gbuf_f16 = int(bool(gbuf_f16))     # BASELINE configs[4]: depth / colour planes of the G-buffer in fp16, sums in fp32
         self.dims = d
+        self._pinned, self._uploaded = {}, None      # page-locked upload mirrors of load_scenes()
         self._alloc_workspace()
         if self.obj_capacity is not None:
             self.adopt_objects()        # hands only for now: tables, pair table and AABB of the (still empty) scene
@@ -443,25 +457,52 @@ class GuidanceBatch:
             for k in range(12):
                 im.T_h2m[k] = float(M[k])
             im.Vo = im.Fo = im.n_edges = 0        # the device-side records get the actual counts from foho_object_update
-        up = lambda dst, a: dst.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(dst.dtype), non_blocking=False)
-        up(self.verts_in, verts)
-        for m, hf in zip(self.meta, hfaces):
-            up(self.faces[m["f_off"]:m["f_off"] + m["Fh"]], hf)
-        up(self.obj_faces64, faces64)
-        up(self.obj_counts, counts)
-        up(self.images, np.frombuffer(b"".join(bytes(im) for im in self._images_host), np.uint8))
-        up(self.tgt_normal, np.stack([s["moge_normal"] for s in scenes]))
-        up(self.tgt_disp, np.stack([s["moge_disp"] for s in scenes]))
-        up(self.mask, np.stack([(np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1))
-                                for s in scenes]))
-        up(self.kps_2d, np.stack([s["kps_2d"] for s in scenes]))
-        up(self.params, np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1)))
+        # Uploads go through page-locked mirrors owned by this batch and are ASYNCHRONOUS on the current stream: the host does
+        # not wait behind whatever that stream still has queued (inputs.MeshGuidanceRunner keeps a second slot's whole job
+        # queued on it).  A mirror is rewritten only after the copies of the previous load have run (`_uploaded`).
+        if self._uploaded is not None:
+            self._uploaded.synchronize()
+
+        def up(key, dst, fill):
+            buf = self._pinned.get(key)
+            if buf is None:
+                buf = self._pinned[key] = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
+            fill(buf.numpy())
+            dst.copy_(buf, non_blocking=True)
+
+        def put(a):
+            def fill(view):
+                view[...] = np.asarray(a).reshape(view.shape)
+            return fill
+
+        def per_image(get):
+            def fill(view):
+                for b, s in enumerate(scenes):
+                    view[b] = get(s)
+            return fill
+
+        up("verts", self.verts_in, put(verts))
+        for b, (m, hf) in enumerate(zip(self.meta, hfaces)):
+            up(("hand_faces", b), self.faces[m["f_off"]:m["f_off"] + m["Fh"]], put(hf))
+        up("obj_faces", self.obj_faces64, put(faces64))
+        up("counts", self.obj_counts, put(counts))
+        up("images", self.images, put(np.frombuffer(b"".join(bytes(im) for im in self._images_host), np.uint8)))
+        if all("moge_normal" in s for s in scenes):      # else: the caller renders them into tgt_normal / tgt_disp (TargetRenderer)
+            up("tgt_normal", self.tgt_normal, per_image(lambda s: s["moge_normal"]))
+            up("tgt_disp", self.tgt_disp, per_image(lambda s: s["moge_disp"]))
+        up("mask", self.mask, per_image(lambda s: np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1)))
+        up("kps", self.kps_2d, per_image(lambda s: s["kps_2d"]))
+        up("params", self.params, put(np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1))))
+        if self._uploaded is None:
+            self._uploaded = torch.cuda.Event()
+        self._uploaded.record()
         self.reset_optimizer()
         self.adopt_objects()
         self.load_flags = self.flags.clone()
         self.flags.zero_()
         self._targets_dirty = True
-        self.prepare()
+        if all("moge_normal" in s for s in scenes):
+            self.prepare()
 
     # ------------------------------------------------------------------ state
     def reset_optimizer(self):
@@ -655,15 +696,22 @@ class GuidanceBatch:
     def capture(self, cfg, steps_per_graph=1):
         """Capture `steps_per_graph` consecutive iterations into one hipGraph (the step has no host sync:
         NaN break, intersection-weight gate and Adam state all live on the device)."""
-        s = torch.cuda.Stream(self.device)
-        s.wait_stream(torch.cuda.current_stream(self.device))
-        state = [t.clone() for t in (self.params, self.adam_m, self.adam_v, self.adam_t, self.flags)]
-        with torch.cuda.stream(s):
-            self.step(cfg)  # warm-up launch outside capture (module load); its optimiser update is undone below
-        torch.cuda.current_stream(self.device).wait_stream(s)
-        torch.cuda.synchronize(self.device)
-        for t, saved in zip((self.params, self.adam_m, self.adam_v, self.adam_t, self.flags), state):
-            t.copy_(saved)
+        self.prepare()      # per-input stages that are due run now, eagerly: the graph holds the step only
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if dev_index not in _WARMED_DEVICES:
+            # first capture of the process on this GPU: one launch outside capture (the code object is loaded lazily, which a
+            # capture does not allow); its optimiser update is undone.  The only device-wide synchronisation of a capture.
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            state = [t.clone() for t in (self.params, self.adam_m, self.adam_v, self.adam_t, self.flags)]
+            with torch.cuda.stream(s):
+                self.step(cfg)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            for t, saved in zip((self.params, self.adam_m, self.adam_v, self.adam_t, self.flags), state):
+                t.copy_(saved)
+            torch.cuda.synchronize(self.device)
+            _WARMED_DEVICES.add(dev_index)
         # Several iterations in one graph: every iteration but the last leaves its final stage (loss assembly, parameter
         # gradients, Adam) to the prologue of the next one (foho_step_cfg.deferred_update) -- the serial last-workgroup
         # tail of k_vert_bwd disappears from the chain -- and one foho_step_finalize launch closes the graph.
@@ -672,12 +720,19 @@ class GuidanceBatch:
             c2 = L.FohoStepCfg.from_buffer_copy(bytes(cfg))
             c2.deferred_update = 1 + (k & 1)
             return c2
+        # Recorded on a stream of its own with capture_begin / capture_end: `with torch.cuda.graph(g)` synchronises the DEVICE
+        # and empties the allocator cache on entry, i.e. a capture would wait for every other slot's running job.  Nothing
+        # executes and nothing is allocated during the recording.
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for k in range(steps_per_graph):
-                self.step(numbered(k) if deferred else cfg)
-            if deferred:
-                self.finalize(numbered(steps_per_graph - 1))
+        with torch.cuda.stream(torch.cuda.Stream(self.device)):
+            g.capture_begin()
+            try:
+                for k in range(steps_per_graph):
+                    self.step(numbered(k) if deferred else cfg)
+                if deferred:
+                    self.finalize(numbered(steps_per_graph - 1))
+            finally:
+                g.capture_end()
         return g
 
     def finalize(self, cfg, stream=None):
@@ -1021,6 +1076,98 @@ def save_grid(img1, img2, path):
     Image.fromarray((out * 255.0 + 0.5).astype(np.uint8)).save(path)
 
 
+class TargetRenderer:
+    """Target maps of an image on the DEVICE: the reference renders the MoGe image mesh once per image with
+    render_normal_and_disparity (PL:272-289, called at PL:1247-1256 on the mesh as it is) and masks the two maps with the
+    hand-object mask (PL:1252-1253).  `render_into` does that straight into a GuidanceBatch's tgt_normal[b] / tgt_disp[b],
+    asynchronously on the current stream: page-locked upload of the mesh (any vertex / face count within the capacity; the
+    sizes of a render are its own, nothing is padded), incidence tables on the device, vertex + raster stages, the map
+    arithmetic of `hip_render_fn` in torch.  No host synchronisation; `flags` (device, int32[2]) collects what the render
+    reported: [0] the step's flag word, [1] foho_topology_tables' (non-zero: a valence above 48 -- not an image mesh)."""
+
+    def __init__(self, H, W, vcap, fcap, device="cuda"):
+        self.H, self.W, self.vcap, self.fcap = int(H), int(W), int(vcap), int(fcap)
+        dummy = dict(obj_verts=np.zeros((self.vcap, 3), np.float32), obj_faces=np.zeros((self.fcap, 3), np.int64),     # sizes only
+                     hand_verts=np.zeros((0, 3), np.float32),
+                     hand_faces=np.zeros((0, 3), np.int64), T_h2m=np.eye(4, dtype=np.float32),
+                     J_regressor=np.zeros((16, 1), np.float32), kps_2d=np.zeros((21, 2), np.float32),
+                     moge_normal=np.zeros((H, W, 3), np.float32), moge_disp=np.zeros((H, W), np.float32),
+                     hand_mask=np.zeros((H, W), bool), obj_mask=np.zeros((H, W), bool), fov=60.0, H=H, W=W)
+        gb = self.gb = GuidanceBatch([dummy], device=device, n_renders=1, grid_res=2, topology="deferred")
+        dev = gb.device
+        gb.lib.foho_topology_workspace_bytes.restype = ctypes.c_size_t
+        self.topo_ws = torch.empty(gb.lib.foho_topology_workspace_bytes(self.vcap), dtype=torch.uint8, device=dev)
+        self.flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.cfg, _ = phase_cfg("B", do_update=False)
+        self.cfg.world_space_input = 1
+        self._mirrors = {}
+
+    def fits(self, verts, faces, H, W):
+        return len(verts) <= self.vcap and len(faces) <= self.fcap and (int(H), int(W)) == (self.H, self.W) and len(faces) > 0
+
+    def render_into(self, key, verts, faces, fov, mask_u8, out_normal, out_disp):
+        """`key` names the page-locked mirrors this call stages the mesh in (they must not be rewritten before the copies
+        have run: one key per image the caller has in flight).  mask_u8: (H, W) device tensor, non-zero = inside the
+        hand-object mask."""
+        gb, H, W = self.gb, self.H, self.W
+        v, f = len(verts), len(faces)
+        if not self.fits(verts, faces, H, W):
+            raise L.FohoError(f"TargetRenderer: image mesh of {v} vertices / {f} faces does not fit ({self.vcap} / {self.fcap})")
+        mir = self._mirrors.get(key)
+        if mir is None:
+            mir = self._mirrors[key] = (torch.empty(self.vcap, 3, dtype=torch.float32, pin_memory=True),
+                                        torch.empty(self.fcap, 3, dtype=torch.int32, pin_memory=True),
+                                        torch.empty(gb.images.shape, dtype=torch.uint8, pin_memory=True))
+        pv, pf, pim = mir
+        pv.numpy()[:v] = verts
+        pf.numpy()[:f] = faces
+        # this render's own sizes: the step takes every bound from dims / the image record, the buffers keep the capacity
+        m, im, d = gb.meta[0], gb._images_host[0], gb.dims
+        m.update(Vo=v, Fo=f)
+        im.Vo, im.Fo = v, f
+        im.k00, im.k11 = fov_focal(float(fov))
+        d.Vtot, d.Ftot, d.Vmax, d.Fmax, d.Vo_max, d.Fo_max = v, f, v, f, v, f
+        gb.Vtot, gb.Ftot = v, f
+        gb._desc = None
+        pim.numpy()[...] = np.frombuffer(bytes(im), np.uint8)
+        gb.verts_in[:v].copy_(pv[:v], non_blocking=True)
+        gb.faces[:f].copy_(pf[:f], non_blocking=True)
+        gb.images.copy_(pim, non_blocking=True)
+        P = ctypes.c_void_p
+        stream = torch.cuda.current_stream(gb.device).cuda_stream
+        L.check(gb.lib.foho_topology_tables(P(gb.faces.data_ptr()), v, f, None, P(gb.inc_off.data_ptr()), P(gb.inc_fc.data_ptr()),
+                                            P(gb.nbr_idx.data_ptr()), P(self.flags[1:].data_ptr()), P(self.topo_ws.data_ptr()),
+                                            ctypes.c_size_t(self.topo_ws.numel()), P(stream)), "foho_topology_tables")
+        gb.flags.zero_()
+        gb._bbox_dirty = True        # new vertices, and the scatter planes of THIS layout start clean
+        gb.step(self.cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)
+        self.flags[0:1].copy_(gb.flags)
+        nn, disp, _ = _maps_from_gbuffer(gb, H * W)
+        inside = mask_u8.reshape(-1) != 0
+        out_normal.copy_(torch.where(inside[:, None], nn, torch.zeros_like(nn)).reshape(H, W, 3))
+        out_disp.copy_(torch.where(inside, disp, torch.zeros_like(disp)).reshape(H, W))
+
+
+def _maps_from_gbuffer(gb, P):
+    """Normal map and disparity of render 0 of image 0 the way render_normal_and_disparity builds them (PL:272-289), from
+    the G-buffer the raster stage left: (P, 3), (P,), pix_to_face (P,) -- device tensors."""
+    p2f = gb.region("p2f", torch.int32, (P,)).long()
+    z = gb.region("zbuf", torch.float32, (P,))
+    sd = gb.region("sdist", torch.float32, (P,))
+    vn = gb.region("vn", torch.float32, (-1, 3))
+    hit = p2f >= 0
+    f = gb.faces.long()[p2f.clamp(min=0)]
+    col = vn[f].sum(1)
+    p = torch.sigmoid(-sd / 1e-8)
+    rgb = torch.where(hit[:, None], (p[:, None] * col + 1e-10) / (p[:, None] + 1e-10), torch.ones_like(col))
+    nn = (rgb - rgb.min()) / (rgb.max() - rgb.min() + 1e-6)
+    nn = torch.where(hit[:, None], nn, torch.zeros_like(nn))
+    depth = torch.where(hit, z, torch.full_like(z, 10.0))
+    disp = 1 / (depth + 1e-6)
+    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-6)
+    return nn, disp, p2f
+
+
 def hip_render_fn(device="cuda"):
     """Target-map renderer for synthetic scenes backed by the HIP rasteriser (data generation only):
     returns render_fn(verts, faces, H, W, fov) -> (normal (H,W,3), disp (H,W), pix_to_face (H,W)) following
@@ -1040,21 +1187,7 @@ def hip_render_fn(device="cuda"):
         gb.step(cfg, stages=L.STAGE_VERTEX | L.STAGE_RASTER)
         torch.cuda.current_stream(gb.device).synchronize()     # this stream only: loader threads render next to a running job
         gb.raise_on_flags()
-        P = H * W
-        p2f = gb.region("p2f", torch.int32, (P,)).long()
-        z = gb.region("zbuf", torch.float32, (P,))
-        sd = gb.region("sdist", torch.float32, (P,))
-        vn = gb.region("vn", torch.float32, (-1, 3))
-        hit = p2f >= 0
-        f = gb.faces.long()[p2f.clamp(min=0)]
-        col = vn[f].sum(1)
-        p = torch.sigmoid(-sd / 1e-8)
-        rgb = torch.where(hit[:, None], (p[:, None] * col + 1e-10) / (p[:, None] + 1e-10), torch.ones_like(col))
-        nn = (rgb - rgb.min()) / (rgb.max() - rgb.min() + 1e-6)
-        nn = torch.where(hit[:, None], nn, torch.zeros_like(nn))
-        depth = torch.where(hit, z, torch.full_like(z, 10.0))
-        disp = 1 / (depth + 1e-6)
-        disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-6)
+        nn, disp, p2f = _maps_from_gbuffer(gb, H * W)
         return (nn.reshape(H, W, 3).cpu().numpy(), disp.reshape(H, W).cpu().numpy(), p2f.reshape(H, W).cpu().numpy())
 
     return render

@@ -71,9 +71,11 @@ def _node_matrix(node):
     return m
 
 
-def load_glb(path):
-    """Triangle geometry of a binary glTF 2.0 file: (verts (V,3) float32, faces (F,3) int64), all primitives of all
-    scene nodes concatenated with their node transforms applied (the MoGe mesh is a single primitive)."""
+def load_glb(path, index_dtype=np.int64):
+    """Triangle geometry of a binary glTF 2.0 file: (verts (V,3) float32, faces (F,3) `index_dtype`), all primitives of all
+    scene nodes concatenated with their node transforms applied (the MoGe mesh is a single primitive).  index_dtype=np.int32
+    with 32-bit indices in the file (what MoGe writes) returns a VIEW of the file's bytes: no conversion pass over the
+    half million faces."""
     with open(path, "rb") as f:
         data = f.read()
     magic, version, length = struct.unpack_from("<III", data, 0)
@@ -107,9 +109,13 @@ def load_glb(path):
                 else:
                     p = (p.astype(np.float64) @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
                 if "indices" in prim:
-                    idx = _accessor(gltf, binary, prim["indices"]).reshape(-1).astype(np.int64)
+                    idx = _accessor(gltf, binary, prim["indices"]).reshape(-1)
+                    if idx.dtype == np.dtype("<u4") and index_dtype == np.int32 and len(p) < 2 ** 31:
+                        idx = idx.view(np.int32)
+                    else:
+                        idx = idx.astype(index_dtype)
                 else:
-                    idx = np.arange(len(p), dtype=np.int64)
+                    idx = np.arange(len(p), dtype=index_dtype)
                 if voff:
                     idx = idx + voff
                 verts.append(p)
@@ -196,7 +202,7 @@ def load_fov(path):
 def load_scene_from_files(p, J_regressor, render_fn, n_hand_verts=778, fov=None, with_object=True):
     """Scene dict for `engine.GuidanceBatch` from the reference's per-image files.  `p` = `foho.guidance.run.derive_paths`
     output; `render_fn(verts, faces, H, W, fov) -> (normal, disp, pix_to_face)` renders the MoGe mesh into the target
-    maps (engine.hip_render_fn on the GPU).  `fov` overrides fov.json (the pipeline gets it from the renderer's camera,
+    maps (engine.hip_render_fn on the GPU); render_fn=None returns the mesh itself as scene["moge_mesh"] instead of the maps.  `fov` overrides fov.json (the pipeline gets it from the renderer's camera,
     RUN:90); with_object=False leaves the object empty (the pipeline decodes it from the latent every iteration)."""
     hand_mask, obj_mask = load_mask(p["cropped_hand_mask_path"]), load_mask(p["cropped_obj_mask_path"])
     H, W = hand_mask.shape
@@ -208,18 +214,22 @@ def load_scene_from_files(p, J_regressor, render_fn, n_hand_verts=778, fov=None,
         obj_v, obj_f = meshio.load_ply(p["hunyuan_hoi_mesh_path"])
     else:
         obj_v, obj_f = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64)
-    mv, mf = load_glb(p["moge_mesh_path"])
-    normal, disp, _ = render_fn(mv, mf, H, W, fov)
-    hoi = (hand_mask | obj_mask).astype(np.float32)                         # PL:1243, 1252-1253
+    mv, mf = load_glb(p["moge_mesh_path"], np.int64 if render_fn is not None else np.int32)
     jr = np.asarray(J_regressor, dtype=np.float32)
     if jr.shape[1] != n_hand_verts:
         raise ValueError("J_regressor must be (16, number of MANO vertices)")
-    return dict(
+    scene = dict(
         hand_verts=hand_moge.astype(np.float32), hand_faces=mano_f.astype(np.int64),
         obj_verts=obj_v.astype(np.float32), obj_faces=obj_f.astype(np.int64), T_h2m=T.astype(np.float32),
         J_regressor=jr, kps_2d=load_kps_for_guidance(p["hamer_for_guid_path"]),
-        moge_normal=(normal * hoi[..., None]).astype(np.float32), moge_disp=(disp * hoi).astype(np.float32),
         hand_mask=hand_mask, obj_mask=obj_mask, fov=fov, H=int(H), W=int(W))
+    if render_fn is None:      # host work only: the image mesh travels with the scene, MeshGuidanceRunner renders it on the device
+        scene["moge_mesh"] = (np.ascontiguousarray(mv, np.float32), np.ascontiguousarray(mf, np.int32))
+        return scene
+    normal, disp, _ = render_fn(mv, mf, H, W, fov)
+    hoi = (hand_mask | obj_mask).astype(np.float32)                         # PL:1243, 1252-1253
+    scene.update(moge_normal=(normal * hoi[..., None]).astype(np.float32), moge_disp=(disp * hoi).astype(np.float32))
+    return scene
 
 
 def save_scene_files(scene, moge_verts, moge_faces, dirs, index, hand_verts_hunyuan=None):
@@ -262,9 +272,11 @@ def job_schedule(config):
 
 
 def _steps_per_graph(iters):
-    # iterations per hipGraph replay: a capture costs the device ~30 us of idle time per iteration recorded, a replay
-    # boundary ~10 us -- 10 iterations per graph beat 50 (44.9 against 47.5 ms per job)
-    return max([d for d in range(1, 11) if iters % d == 0]) if iters > 0 else 1
+    # iterations per hipGraph replay.  Recording costs the host ~20 us per iteration (1.1 ms for 50; measured with
+    # scripts/dev_replay_cost.py -- the 10 ms of earlier rounds were the device synchronisation of `torch.cuda.graph`, which
+    # GuidanceBatch.capture no longer goes through), a replay ~1.5 us per iteration plus a release / re-acquisition of the
+    # interpreter lock per call, a replay boundary ~10 us of device time: 50 per graph
+    return max([d for d in range(1, 51) if iters % d == 0]) if iters > 0 else 1
 
 
 def run_mesh_guidance(scenes, config=None, device="cuda", capture=True, log=None):
@@ -351,21 +363,46 @@ class GpuGate:
         return GpuGate._Ctx(enter, leave)
 
 
+class _Slot:
+    """One capacity-mode GuidanceBatch of a MeshGuidanceRunner: its stream, its hipGraphs, the job queued on it and the
+    page-locked buffers that job's results land in."""
+
+    def __init__(self, gb, stream):
+        import torch
+        self.gb, self.stream = gb, stream
+        self.graphs = {}
+        self.job = None                 # [(tag, scene)] of the job queued on the stream, None when idle
+        self.done = torch.cuda.Event()
+        with torch.cuda.stream(stream):
+            self.seen = torch.zeros_like(gb.flags)       # flags of every loop of the job, OR-ed
+            self.nan_b = torch.zeros_like(gb.flags)      # the NaN bit as phase B left it
+            self.render_flags = torch.zeros(gb.B, 2, dtype=torch.int32, device=gb.device)    # engine.TargetRenderer.flags per image
+        src = dict(seen=self.seen, nan_b=self.nan_b, losses=gb.losses, params=gb.params, faces=gb.faces,
+                   world=gb.region("world", torch.float32, (-1, 3)), render_flags=self.render_flags)
+        self.src = src
+        self.out = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in src.items()}
+
+
 class MeshGuidanceRunner:
     """The mesh-level guidance job for MANY images per GPU ("within a GPU, batch the rank's images through
     each kernel launch"; the reference walks its list one image at a time with batch size 1, RUN:208-259, CFG:9).
 
-    `in_flight` images are optimised at once: `n_streams` independent capacity-mode GuidanceBatch slots (engine.
-    GuidanceGroup), each with its own HIP stream and its own hipGraphs.  A new set of images is loaded INTO the slots
-    (GuidanceBatch.load_scenes: same buffers, objects installed on the device), so the graphs of the schedule -- phase A,
-    phase B, phase C with and without the intersection gate -- are captured once per process, not once per image, and no
-    workspace is re-allocated between phases (foho_step_cfg.n_active_renders).  No host synchronisation inside an image
-    set: NaN break, optimiser state and flags live on the device; flags of every loop are OR-ed into `flags_seen`.
+    `in_flight` images are optimised at once: `n_streams` HIP streams on different hardware queues, each running a SLOT --
+    a capacity-mode GuidanceBatch of in_flight / n_streams images with its own hipGraphs.  A job is one slot's images through
+    the whole schedule (phase A, phase B, nine phase-C loops), queued on the slot's stream in one go: uploads from page-locked
+    mirrors (GuidanceBatch.load_scenes: same buffers, objects installed on the device), graph replays, the final transform,
+    read-back into page-locked result buffers, an event.  Nothing in it waits for the host -- NaN break, optimiser state and
+    flags live on the device -- and the host waits for nothing but that event.  Long lists (run_stream) use TWO slots
+    per stream, alternately: while one slot's job runs, the other's finished job is read, exported and replaced by the next
+    images, and its new job is queued behind the running one -- a stream never idles between jobs.  The graphs of the
+    schedule (phase A, phase B, phase C with and without the intersection gate) are captured once per slot and process, not
+    once per image, and no workspace is re-allocated between phases (foho_step_cfg.n_active_renders).
 
     run(scenes) -> one result per scene: dict(ok, flags, losses (dict of the last step), params (16,), hand (verts, faces),
-    obj (verts, faces), nan_in_phase_b).  Scenes the slots cannot take (other image size / hand topology) and images whose
-    object is not a closed manifold (device-side edge tables refuse: flag bit 5) are reported with ok=False,
-    reason="fallback": the caller runs them through `run_mesh_guidance`."""
+    obj (verts, faces), nan_in_phase_b); run_stream(items) is the same as a generator over (tag, scene) pairs that yields
+    (tag, result) in submission order while later images are still on the GPU.  Images whose object is not a closed
+    manifold (device-side edge tables refuse: flag bit 5) are reported with ok=False, reason="fallback": the caller runs them
+    through `run_mesh_guidance`."""
 
     def __init__(self, config=None, device="cuda", in_flight=16, n_streams=None, grid_res=64):
         from . import engine as E
@@ -376,10 +413,15 @@ class MeshGuidanceRunner:
         # at most four streams (HIP has four hardware queues), at least two images per stream; measured for
         # whole jobs: 116 images/s at 8 in flight (4 x 2, the setting bench.py's `batched` record uses), 160 at 16 (4 x 4)
         self.n_streams = int(n_streams) if n_streams else max(1, min(4, (self.in_flight + 1) // 2))
+        self.per_slot = (self.in_flight + self.n_streams - 1) // self.n_streams
+        self.n_streams = (self.in_flight + self.per_slot - 1) // self.per_slot
         self.grid_res = grid_res
-        self.group = None
-        self.graphs = {}
-        self.stats = dict(captures=0, groups_built=0, image_sets=0)
+        self.slots = {}                 # ring position -> _Slot
+        self.renderers = {}             # stream index -> engine.TargetRenderer
+        self.streams = None
+        self._turn = {}                 # stream index -> jobs its feeder has taken so far (which of its slots is next)
+        self._lock = __import__("threading").Lock()
+        self.stats = dict(captures=0, slots_built=0, jobs=0)
         self.gpu_gate = GpuGate()      # captures under exclusive(), loader threads under shared()
 
     # -------------------------------------------------------------------------------------------- slots
@@ -388,112 +430,241 @@ class MeshGuidanceRunner:
         rnd = lambda x, q: ((int(x) + q - 1) // q) * q
         return (rnd(max(len(s["obj_verts"]) for s in scenes) * 1.125 + 1, 1024), rnd(max(len(s["obj_faces"]) for s in scenes) * 1.125 + 2, 2048))
 
-    def _group_for(self, scenes):
-        """A group whose slots take `scenes` (exactly in_flight of them); rebuilt -- graphs and all -- when they do not fit."""
-        if self.group is not None and self.group.fits(scenes):
-            return self.group
+    def _slot_for(self, pos, scenes):
+        """The slot at ring position `pos`, able to take `scenes` (exactly per_slot of them); rebuilt -- graphs and all --
+        when they do not fit (other image size / hand topology, larger object than any before)."""
+        import torch
+        slot = self.slots.get(pos)
+        if slot is not None and slot.gb.fits(scenes):
+            return slot
         cap = self._capacity(scenes)
-        if self.group is not None:      # keep the larger of the old and the new capacity: sizes drift, they do not alternate
-            old = self.group.batches[0].obj_capacity
+        for other in list(self.slots.values()):      # sizes drift, they do not alternate: never below what any slot already has
+            old = other.gb.obj_capacity
             cap = (max(cap[0], old[0]), max(cap[1], old[1]))
-        self.group = self.E.GuidanceGroup(scenes, self.n_streams, device=self.device, grid_res=self.grid_res, n_renders=2,
-                                          obj_capacity=cap)
-        self.graphs = {}
-        self.stats["groups_built"] += 1
-        return self.group
+        if self.streams is None:
+            self.streams = list(self.E.concurrent_streams(self.n_streams, torch.device(self.device)))
+        st = self.streams[pos % self.n_streams]
+        with self.gpu_gate.shared(), torch.cuda.stream(st):
+            gb = self.E.GuidanceBatch(scenes, device=self.device, grid_res=self.grid_res, n_renders=2, obj_capacity=cap)
+            slot = _Slot(gb, st)
+            slot.stream_index = pos % self.n_streams
+            gb.load_scenes(scenes)          # real objects in the slot for the launch that precedes the process's first capture
+        # the graphs of the whole schedule, now: a capture excludes every other thread's GPU work (gpu_gate), so it must not
+        # come up in the middle of a job's queueing
+        for phase, iters, denoise_i in job_schedule(self.config):
+            cfg, _ = self.E.phase_cfg(phase, self.config, denoise_i=denoise_i, do_update=True)
+            with torch.cuda.stream(st):
+                self._graph_for(slot, cfg, _steps_per_graph(iters))
+        self.slots[pos] = slot
+        with self._lock:
+            self.stats["slots_built"] += 1
+        return slot
 
-    def _graphs_for(self, group, cfg, spg):
+    def _renderer_for(self, slot, verts, faces, H, W):
+        """The target-map renderer of the slot's stream (the two slots of a stream share it: their jobs run one after the
+        other), sized for an image mesh with one vertex per pixel; rebuilt when a mesh does not fit."""
+        k = slot.stream_index
+        rd = self.renderers.get(k)
+        if rd is None or not rd.fits(verts, faces, H, W):
+            vcap = max(H * W, len(verts), rd.vcap if rd is not None else 0)
+            fcap = max(2 * (H - 1) * (W - 1), len(faces), rd.fcap if rd is not None else 0)
+            rd = self.renderers[k] = self.E.TargetRenderer(H, W, vcap, fcap, device=self.device)
+        return rd
+
+    def _graph_for(self, slot, cfg, spg):
         key = (bytes(cfg), spg)
-        g = self.graphs.get(key)
+        g = slot.graphs.get(key)
         if g is None:
-            import torch
-            g = []
             with self.gpu_gate.exclusive():
-                for gb, st in zip(group.batches, group.streams):
-                    with torch.cuda.stream(st):
-                        g.append(gb.capture(cfg, steps_per_graph=spg))
-            self.graphs[key] = g
-            self.stats["captures"] += 1
+                g = slot.graphs[key] = slot.gb.capture(cfg, steps_per_graph=spg)
+            with self._lock:
+                self.stats["captures"] += 1
         return g
 
-    # -------------------------------------------------------------------------------------------- one image set
-    def _run_set(self, scenes, log):
+    # -------------------------------------------------------------------------------------------- one job
+    def _enqueue(self, slot, chunk, scenes):
+        """Queue the whole job of `scenes` on the slot's stream; returns at once."""
         import torch
         E = self.E
-        group = self._group_for(scenes)
-        group.load_scenes(scenes)
-        seen, nan_b = [], []
-        for gb, st in zip(group.batches, group.streams):       # per-slot tensors live on the slot's stream
-            with torch.cuda.stream(st):
-                seen.append(gb.load_flags.clone())
-                nan_b.append(torch.zeros_like(gb.flags))
-        for phase, iters, denoise_i in job_schedule(self.config):
-            cfg, _ = E.phase_cfg(phase, self.config, denoise_i=denoise_i, do_update=True)
-            spg = _steps_per_graph(iters)
-            graphs = self._graphs_for(group, cfg, spg)
-            for gb, st in zip(group.batches, group.streams):
-                with torch.cuda.stream(st):
-                    gb.reset_optimizer()
-            for _ in range(iters // spg):       # streams interleaved: every slot's replay k is queued before any replay k + 1
-                for g, st in zip(graphs, group.streams):
-                    with torch.cuda.stream(st):
-                        g.replay()
-            for k, (gb, st) in enumerate(zip(group.batches, group.streams)):
-                with torch.cuda.stream(st):
-                    seen[k] |= gb.flags
-                    if phase == "B":
-                        nan_b[k].copy_(gb.flags & 1)
-            if log is not None:
-                group.synchronize()
-                log(phase, denoise_i, [gb.loss_dict(b)["total"] for gb in group.batches for b in range(gb.B)])
-        for gb, st in zip(group.batches, group.streams):       # output meshes from the FINAL parameters (PL:1614-1618, 1653-1657)
-            with torch.cuda.stream(st):
-                gb.refresh_world()
-        group.synchronize()
-        self.stats["image_sets"] += 1
+        gb = slot.gb
+        with torch.cuda.stream(slot.stream):
+            gb.load_scenes(scenes)
+            slot.render_flags.zero_()
+            if any("moge_normal" not in s for s in scenes):       # target maps rendered here, on the device, inside the job
+                for b, s in enumerate(scenes):
+                    if "moge_normal" in s:                         # a mixed job: this image brought its maps along
+                        gb.tgt_normal[b].copy_(torch.from_numpy(np.ascontiguousarray(s["moge_normal"], np.float32)))
+                        gb.tgt_disp[b].copy_(torch.from_numpy(np.ascontiguousarray(s["moge_disp"], np.float32)))
+                        continue
+                    mv, mf = s["moge_mesh"]
+                    rd = self._renderer_for(slot, mv, mf, gb.H, gb.W)
+                    rd.render_into((id(slot), b), mv, mf, s["fov"], gb.mask[b], gb.tgt_normal[b], gb.tgt_disp[b])
+                    slot.render_flags[b].copy_(rd.flags)
+                gb.prepare()
+            slot.seen.copy_(gb.load_flags)
+            slot.nan_b.zero_()
+            for phase, iters, denoise_i in job_schedule(self.config):
+                cfg, _ = E.phase_cfg(phase, self.config, denoise_i=denoise_i, do_update=True)
+                spg = _steps_per_graph(iters)
+                g = self._graph_for(slot, cfg, spg)
+                gb.reset_optimizer()
+                for _ in range(iters // spg):
+                    g.replay()
+                slot.seen |= gb.flags
+                if phase == "B":
+                    slot.nan_b.copy_(gb.flags & 1)
+            gb.refresh_world()      # output meshes from the FINAL parameters (PL:1614-1618, 1653-1657)
+            for k, v in slot.src.items():
+                slot.out[k].copy_(v, non_blocking=True)
+            slot.done.record()
+        slot.job = chunk
+        slot.meta = [dict(m) for m in gb.meta]
+        with self._lock:
+            self.stats["jobs"] += 1
+
+    def _retire(self, slot):
+        """Wait for the slot's job and turn its result buffers into one result per submitted image."""
+        E = self.E
+        slot.done.synchronize()
+        o = {k: v.numpy() for k, v in slot.out.items()}
+        faces = o["faces"].astype(np.int64)
         out = []
-        for k, gb in enumerate(group.batches):
-            fl = seen[k].cpu().numpy()
-            nb = nan_b[k].cpu().numpy()
-            losses = gb.losses.detach().cpu().numpy()
-            params = gb.params.detach().cpu().numpy()
-            world = gb.region("world", torch.float32, (-1, 3)).detach().cpu().numpy()
-            faces = gb.faces.detach().cpu().numpy().astype(np.int64)
-            for b in range(gb.B):
-                m = gb.meta[b]
-                hv = world[m["v_off"]:m["v_off"] + m["Vh"]].copy()
-                ov = world[m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]].copy()
-                hf = faces[m["f_off"]:m["f_off"] + m["Fh"]] - m["v_off"]
-                of = faces[m["f_off"] + m["Fh"]:m["f_off"] + m["Fh"] + m["Fo"]] - m["v_off"] - m["Vh"]
-                f = int(fl[b])
-                res = dict(ok=True, flags=f, losses=dict(zip(E.L.LOSS_NAMES, losses[b].tolist())), losses_row=losses[b].copy(),
-                           params=params[b].copy(), hand=(hv, hf), obj=(ov, of), nan_in_phase_b=bool(nb[b]))
-                if f & (16 | 32):       # capacity (cannot happen: sized from the scenes) / not a closed manifold
-                    res.update(ok=False, reason="fallback")
-                elif f & 2:
-                    res.update(ok=False, reason="fractional-coverage fragment list overflowed")
-                elif f & 64:
-                    res.update(ok=False, reason="empty object mesh")
-                out.append(res)
+        for b, (tag, _) in enumerate(slot.job):
+            m = slot.meta[b]
+            hv = o["world"][m["v_off"]:m["v_off"] + m["Vh"]].copy()
+            ov = o["world"][m["v_off"] + m["Vh"]:m["v_off"] + m["Vh"] + m["Vo"]].copy()
+            hf = faces[m["f_off"]:m["f_off"] + m["Fh"]] - m["v_off"]
+            of = faces[m["f_off"] + m["Fh"]:m["f_off"] + m["Fh"] + m["Fo"]] - m["v_off"] - m["Vh"]
+            f = int(o["seen"][b])
+            rf = o["render_flags"][b]
+            res = dict(ok=True, flags=f, losses=dict(zip(E.L.LOSS_NAMES, o["losses"][b].tolist())), losses_row=o["losses"][b].copy(),
+                       params=o["params"][b].copy(), hand=(hv, hf), obj=(ov, of), nan_in_phase_b=bool(o["nan_b"][b]))
+            if f & (16 | 32) or rf[1]:       # capacity (cannot happen: sized from the scenes) / not a closed manifold / odd image mesh
+                res.update(ok=False, reason="fallback")
+            elif f & 2 or rf[0] & 2:
+                res.update(ok=False, reason="fractional-coverage fragment list overflowed")
+            elif f & 64:
+                res.update(ok=False, reason="empty object mesh")
+            out.append((tag, res))
+        slot.job = None
         return out
 
-    def run(self, scenes, log=None):
-        """Results in the order of `scenes`.  Image sets are filled up to `in_flight` by repeating the set's first image (its
-        copies are computed and dropped): the slots -- and with them the captured graphs -- keep one shape."""
-        results = [None] * len(scenes)
+    # -------------------------------------------------------------------------------------------- feeding the streams
+    def _feed_stream(self, k, slots_per_stream, inbox, outbox, dev_index):
+        """Body of stream k's feeder thread: jobs from `inbox` ([(tag, scene)] lists; None = no more) onto the stream's slots
+        in turn, one list of (tag, result) per job into `outbox`, in the order the jobs came.  The thread blocks where its
+        OWN stream makes it wait -- a full hardware queue in a replay, the event of its oldest job -- and nowhere else, so one
+        stream's backlog never keeps the others from being fed."""
+        import torch
+        torch.cuda.set_device(dev_index)              # the current device is a per-thread setting
+        pending = []                                  # jobs queued on the stream, oldest first: _Slot, or a ready result list
+        turn = self._turn.setdefault(k, 0)
+
+        def retire_oldest():
+            job = pending.pop(0)
+            if isinstance(job, list):
+                outbox.put(job)
+                return
+            tags = [tag for tag, _ in job.job]
+            try:
+                job.done.synchronize()                # outside the gate: this is where the thread spends its time
+                with self.gpu_gate.shared():
+                    outbox.put(self._retire(job))
+            except Exception as e:  # noqa: BLE001
+                job.job = None
+                outbox.put([(tag, dict(ok=False, reason="fallback", error=e)) for tag in tags])
+
+        while True:
+            chunk = inbox.get()
+            if chunk is None:
+                break
+            pos = k + self.n_streams * (turn % slots_per_stream)
+            turn += 1
+            while any(j is self.slots.get(pos) for j in pending if not isinstance(j, list)):
+                retire_oldest()
+            scenes = [s for _, s in chunk]
+            scenes += [scenes[0]] * (self.per_slot - len(scenes))      # copies of the first image fill the slot: one shape, one set of graphs
+            try:
+                slot = self._slot_for(pos, scenes)
+                if slots_per_stream > 1 and pos == k and pos + self.n_streams not in self.slots:
+                    self._slot_for(pos + self.n_streams, scenes)      # the stream's second slot, built while the stream is still idle
+                with self.gpu_gate.shared():
+                    self._enqueue(slot, chunk, scenes)
+                pending.append(slot)
+            except Exception as e:  # noqa: BLE001 -- the job as a whole failed: its images go to the caller's one-by-one path
+                bad = self.slots.pop(pos, None)
+                if bad is not None:
+                    bad.job = None
+                pending.append([(tag, dict(ok=False, reason="fallback", error=e)) for tag, _ in chunk])
+        while pending:
+            retire_oldest()
+        self._turn[k] = turn
+
+    def run_stream(self, items, total=None):
+        """Generator: (tag, scene) pairs in, (tag, result) pairs out in the same order, `in_flight` images on the GPU and --
+        for long lists (`total`, when the caller knows it, above four times that; unknown = long) -- as many again queued
+        behind them.  One feeder thread per stream for the duration of the call (`_feed_stream`); this thread forms the
+        jobs, deals them out round robin and hands back the results."""
+        import queue
+        import threading
+        import torch
+        # a second slot per stream costs its construction and captures (~30 ms) and saves the stream's idle time while the
+        # host reads a job back and loads the next (~20 ms per job): it pays from about five jobs per stream on
+        slots_per_stream = 1 if total is not None and total <= 4 * self.in_flight else 2
+        if self.streams is None:
+            self.streams = list(self.E.concurrent_streams(self.n_streams, torch.device(self.device)))
+        dev_index = torch.device(self.device).index
+        if dev_index is None:
+            dev_index = torch.cuda.current_device()
+        feeders = []
+        for k in range(self.n_streams):
+            inbox, outbox = queue.Queue(maxsize=1), queue.Queue()
+            th = threading.Thread(target=self._feed_stream, args=(k, slots_per_stream, inbox, outbox, dev_index), daemon=True)
+            th.start()
+            feeders.append((th, inbox, outbox))
+        order = []                      # feeder of every job not yet handed back, in submission order
+        n_jobs = 0
+
+        def ready():
+            while order and not feeders[order[0]][2].empty():
+                yield from feeders[order.pop(0)][2].get()
+
+        try:
+            key = lambda s: (int(s["H"]), int(s["W"]), len(s["hand_verts"]), len(s["hand_faces"]))
+            chunk, chunk_key = [], None
+
+            def deal(chunk):
+                nonlocal n_jobs
+                k = n_jobs % self.n_streams
+                n_jobs += 1
+                feeders[k][1].put(chunk)            # blocks while the feeder has not taken its previous job: back-pressure
+                order.append(k)
+
+            for tag, scene in items:
+                k = key(scene)
+                if chunk and (k != chunk_key or len(chunk) == self.per_slot):
+                    deal(chunk)
+                    chunk = []
+                    yield from ready()
+                chunk.append((tag, scene))
+                chunk_key = k
+            if chunk:
+                deal(chunk)
+        finally:
+            for _, inbox, _ in feeders:
+                inbox.put(None)
+        while order:
+            yield from feeders[order.pop(0)][2].get()
+        for th, _, _ in feeders:
+            th.join()
+
+    def run(self, scenes):
+        """Results in the order of `scenes` (same-shape images are queued together, in list order)."""
         key = lambda s: (int(s["H"]), int(s["W"]), len(s["hand_verts"]), len(s["hand_faces"]))
-        order = sorted(range(len(scenes)), key=lambda i: key(scenes[i]))        # stable: same-shape images stay in list order
-        i = 0
-        while i < len(order):
-            j = i
-            while j < len(order) and j - i < self.in_flight and key(scenes[order[j]]) == key(scenes[order[i]]):
-                j += 1
-            ids = order[i:j]
-            batch = [scenes[k] for k in ids]
-            batch += [batch[0]] * (self.in_flight - len(batch))
-            for k, r in zip(ids, self._run_set(batch, log)):
-                results[k] = r
-            i = j
+        order = sorted(range(len(scenes)), key=lambda i: key(scenes[i]))        # stable
+        results = [None] * len(scenes)
+        for i, r in self.run_stream(((i, scenes[i]) for i in order), total=len(scenes)):
+            results[i] = r
         return results
 
 

@@ -22,10 +22,10 @@ for in_flight, n in ((1, 4), (8, 16)):
         print(f"MeshGuidanceRunner in_flight={in_flight}: {dt*1e3/n:.1f} ms per image ({n/dt:.1f} images/s), stats {r.stats}, ok {sum(x['ok'] for x in res)}", flush=True)
 # per-iteration time of each phase on the slot (one image), graphs of 10 iterations
 r = inputs.MeshGuidanceRunner(in_flight=1)
-r.run([sc]); g = r.group; gb = g.batches[0]
+r.run([sc]); slot = r.slots[0]; gb = slot.gb
 for phase, iters, di in (("A", 200, 9), ("B", 100, 10), ("C", 50, 15), ("C", 50, 19)):
     cfg, _ = E.phase_cfg(phase, r.config, denoise_i=di, do_update=True)
-    gr = r._graphs_for(g, cfg, 10)[0]
+    gr = r._graph_for(slot, cfg, 10)
     ts = []
     for rep in range(5):
         gb.reset_optimizer(); torch.cuda.synchronize(); t0 = time.perf_counter()

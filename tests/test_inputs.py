@@ -163,6 +163,31 @@ def test_image_mesh_target_render_matches_oracle():
 
 
 @gpu
+def test_device_side_target_renderer_equals_the_per_image_render():
+    """engine.TargetRenderer (the target maps rendered inside an image's job, straight into the batch's tgt_normal / tgt_disp)
+    against the oracle and engine.hip_render_fn: image meshes of different sizes through ONE renderer, one after the other and
+    back again, masked with the hand-object mask."""
+    from followmyhold_amd import engine as E
+    H = W = 128
+    rd = E.TargetRenderer(H, W, H * W, 2 * (H - 1) * (W - 1))
+    rng = np.random.default_rng(5)
+    mask = torch.from_numpy((rng.random((H, W)) < 0.6).astype(np.uint8)).cuda()
+    out_n, out_d = torch.zeros(H, W, 3, device="cuda"), torch.zeros(H, W, device="cuda")
+    render = E.hip_render_fn("cuda")
+    for k, (n, fov) in enumerate(((96, 60.0), (40, 47.0), (128, 60.0), (96, 60.0))):
+        v, f = _image_mesh(n)
+        rd.render_into(("t", k % 2), v, f.astype(np.int32), fov, mask, out_n, out_d)
+        fl = rd.flags.cpu().numpy()
+        assert fl[0] == 0 and fl[1] == 0
+        n_ref, d_ref, p_ref = render(v, f, H, W, fov)
+        m = mask.cpu().numpy().astype(np.float32)
+        assert np.array_equal(out_n.cpu().numpy(), n_ref * m[..., None]) and np.array_equal(out_d.cpu().numpy(), d_ref * m)
+        if k == 0:
+            n_or, d_or, _ = oracle_render_fn(v, f, H, W, fov)
+            assert np.abs(out_d.cpu().numpy() - d_or * m).max() < 1e-5 and np.abs(out_n.cpu().numpy() - n_or * m[..., None]).max() < 1e-4
+
+
+@gpu
 def test_guidance_driver_under_torchrun_two_ranks(tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 -m foho.guidance.run ...` on a two-image tree (the product
     driver's N>1 path; RUN:178-185, 208-259): each rank binds a GPU (both share the one GPU of this box, so the
@@ -295,19 +320,25 @@ def test_batched_driver_equals_one_image_at_a_time(tmp_path, monkeypatch, capsys
 
 @gpu
 def test_runner_reuses_slots_and_graphs_across_image_sets():
-    """MeshGuidanceRunner: the second and third image set run on the slots and hipGraphs of the first (no new group, no new
-    capture), also when their objects have other vertex / face counts; a larger object than the capacity rebuilds the
-    group once; an open object mesh is handed back for the exact-size driver."""
+    """MeshGuidanceRunner: later jobs run on the slots and hipGraphs of the first ones (no new slot, no new capture), also
+    when their objects have other vertex / face counts; a list longer than `in_flight` brings in the stream's second slot
+    (jobs alternate between the two) and nothing more; a larger object than the capacity rebuilds one slot; an open object
+    mesh is handed back for the exact-size driver."""
     from followmyhold_amd import engine as E
     short = _tame(E.OptimizationConfig(), 4, 2, 2)
     rf = E.hip_render_fn("cuda")
     mk = lambda kind, seed: synthetic.build_scene(rf, obj_kind=kind, H=64, W=64, seed=seed)
     runner = inputs.MeshGuidanceRunner(short, in_flight=2, grid_res=16)
     a = runner.run([mk("ico3", 1), mk("ico2", 2)])
-    caps, groups = runner.stats["captures"], runner.stats["groups_built"]
-    assert groups == 1 and caps == 4               # phase A, phase B, phase C without / with the intersection gate
-    b = runner.run([mk("ico2", 3), mk("ico3", 4), mk("ico2", 5)])       # two sets, the second one padded
-    assert runner.stats["captures"] == caps and runner.stats["groups_built"] == 1 and runner.stats["image_sets"] == 3
+    assert runner.stats["slots_built"] == 1 and runner.stats["captures"] == 4    # phase A, phase B, phase C without / with the intersection gate
+    b = runner.run([mk("ico2", 3), mk("ico3", 4), mk("ico2", 5)])       # two jobs, the second one padded
+    assert runner.stats["slots_built"] == 1 and runner.stats["captures"] == 4 and runner.stats["jobs"] == 3
+    # a long list (length unknown to the runner): the stream's second slot comes in, jobs alternate between the two
+    more = [mk("ico2", 3), mk("ico3", 4), mk("ico2", 5), mk("ico2", 8), mk("ico3", 9)]
+    b2 = [r for _, r in runner.run_stream(((i, s) for i, s in enumerate(more)))]
+    assert runner.stats["slots_built"] == 2 and runner.stats["captures"] == 8 and runner.stats["jobs"] == 6
+    for r, r2 in zip(b, b2):     # whichever slot an image lands in, and whatever ran there before
+        assert np.abs(r["hand"][0] - r2["hand"][0]).max() < 5e-5 and np.abs(r["obj"][0] - r2["obj"][0]).max() < 5e-5
     assert all(r["ok"] and np.isfinite(r["hand"][0]).all() and np.isfinite(r["obj"][0]).all() for r in a + b)
     assert [len(r["obj"][0]) for r in b] == [162, 642, 162]
     # a repeat of the first set on the re-used slots gives the first set's answer
@@ -315,7 +346,7 @@ def test_runner_reuses_slots_and_graphs_across_image_sets():
     for r, r2 in zip(a, a2):
         assert np.abs(r["hand"][0] - r2["hand"][0]).max() < 5e-5 and np.abs(r["obj"][0] - r2["obj"][0]).max() < 5e-5
     big = runner.run([mk("ico4", 6)])
-    assert big[0]["ok"] and runner.stats["groups_built"] == 2 and len(big[0]["obj"][0]) == 2562
+    assert big[0]["ok"] and runner.stats["slots_built"] == 3 and len(big[0]["obj"][0]) == 2562
     sc = mk("ico2", 7)
     sc["obj_faces"] = sc["obj_faces"][:-2]         # a hole: not a closed manifold
     opened = runner.run([sc])
