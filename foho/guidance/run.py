@@ -36,6 +36,7 @@ from foho.configs import OptimizationConfig
 # Per-process tally behind the end-of-batch all-reduce: run_hunyuan_w_guid adds the loss terms of every image it
 # finishes (sharding.METRIC_NAMES order), run() adds wall time and failures.
 _METRICS = np.zeros(len(sharding.METRIC_NAMES), np.float64)
+_RUNNERS = {}      # (device, images in flight, configuration) -> followmyhold_amd.inputs.MeshGuidanceRunner of this process
 
 
 def _tally(vec) -> None:
@@ -305,7 +306,12 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     from followmyhold_amd import inputs
     # no more slots than list entries: a short list must not be padded up to the default with copies of its first image
     in_flight = max(1, min(int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", "16")), len(assigned_imgs)))
-    runner = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
+    # slots, hipGraphs and target renderers belong to the PROCESS: a second run() call with the same settings finds them ready
+    key = (str(device), in_flight, repr(sorted(vars(config).items())))
+    runner = _RUNNERS.get(key)
+    if runner is None:
+        _RUNNERS.clear()             # one set of slots at a time: another configuration replaces it
+        runner = _RUNNERS[key] = inputs.MeshGuidanceRunner(config, device=device, in_flight=in_flight)
     n_iter = _n_iterations(config)
 
     def fail(name, e):

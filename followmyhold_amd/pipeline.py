@@ -318,13 +318,13 @@ class GuidedShapePipeline:
                         if debug_root and n % 10 == 0:
                             spg = 10        # the reference plots the rendered hand normals every 10 iterations (PL:1331-1333)
                         graph = gb.capture(cfg, steps_per_graph=spg)
-                        # capture() ran one iteration from the current parameters and put the optimiser state back: what it
-                        # left in gb.losses are the k = 0 losses the reference prints (PL:1351-1355)
+                        # the k = 0 losses the reference prints (PL:1351-1355): one evaluation at the current parameters, no update
+                        cfg_eval, _ = E.phase_cfg("A", cfg0, denoise_i=i, do_update=False)
+                        gb.step(cfg_eval)
                         l0 = gb.loss_dict(0)
                         loss_log.append(("A", i, 0, l0))
                         say(f"Opt step 0, loss_2d_kps: {l0['kps']}, loss_normal_hand: {l0['normal0']}, loss_disp_hand: {l0['disp0']}")
                         gb.reset_optimizer()
-                        cfg_eval, _ = E.phase_cfg("A", cfg0, denoise_i=i, do_update=False)
                         for rep in range(n // spg):
                             if debug_root and spg == 10:    # the render iteration k = 10 rep starts from
                                 gb.step(cfg_eval)
