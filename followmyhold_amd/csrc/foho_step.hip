@@ -191,7 +191,7 @@ struct WS {
     size_t frac, frac_count, frac_seg, seg_count, rstats, rslot, loss_part, stats2;
     int nseg;
     size_t g_ndc, g_nrm, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc, vbox;
     size_t tile_static, image_static;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
@@ -278,6 +278,7 @@ static WS make_ws(const foho_dims& d) {
     // --- plain scratch ---
     w.mesh_info = take(B * 2 * sizeof(MeshInfo));
     w.xf_part = take(B * 2 * VERT_BLOCKS_MAX * 8 * 4);
+    w.vbox = take(B * (size_t)VERT_BLOCKS_MAX * 4 * 8 * 4);  // world-space AABB of every 64 consecutive object vertices (k_xform -> role_knn)
     w.world = take(V3);
     w.ndc = take(V3);
     w.vn_raw = take(V3);
@@ -405,7 +406,7 @@ struct Ctx {
     float *loss_part, *stats2;
     float *g_ndc, *g_nrm, *g_world, *g_direct;
     int32_t* knn_idx;
-    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special;
+    float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special, *vbox;
     unsigned long long* parity;
     int32_t* int_count;
     unsigned* final_ticket;
