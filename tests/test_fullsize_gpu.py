@@ -461,3 +461,38 @@ def test_near_plane_clipping_in_the_fused_step():
     assert abs(l["total"] - float(total)) <= 1e-4 * abs(float(total))
     _check_grads(E, gb, grads, tol=1e-3)
     _check_update(E, gb, st, E.PARAM_NAMES)
+
+
+@gpu
+def test_nearest_neighbour_pruning_is_exact_over_iterations():
+    """The nearest-neighbour role skips runs of 64 object vertices whose box lies beyond every lane's bound, the distance to
+    last iteration's nearest vertex (k_vertex.inc).  778 x 10 242 vertices over five optimiser steps (the bound is always one
+    iteration old) and once with garbage in its place: index and squared distance equal to a brute-force float32 scan in the
+    kernel's operation order, first minimum."""
+    from followmyhold_amd import engine as E
+    sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=64, W=64, seed=4)
+    gb = E.GuidanceBatch([sc], grid_res=16)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    Vh, Vo = gb.meta[0]["Vh"], gb.meta[0]["Vo"]
+    rng = np.random.default_rng(2)
+
+    def check(tag):
+        torch.cuda.synchronize()
+        world = gb.region("world", torch.float32, (-1, 3))
+        h, o = world[:Vh], world[Vh:Vh + Vo]
+        d = h[:, None, :] - o[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        ref_d, ref_i = d2.min(1)
+        ref_i = (d2 == ref_d[:, None]).float().argmax(1)              # first minimum
+        idx = gb.region("knn_idx", torch.int32)[:Vh].long()
+        kd2 = gb.region("knn_d2", torch.float32)[:Vh]
+        assert torch.equal(idx, ref_i), f"{tag}: {int((idx != ref_i).sum())} indices differ"
+        assert torch.equal(kd2, ref_d), tag
+
+    for it in range(5):
+        gb.step(cfg)
+        check(f"iteration {it}")
+    kreg = gb.region("knn_idx", torch.int32)
+    kreg.copy_(torch.from_numpy(rng.integers(-3, 3 * Vo, kreg.numel()).astype(np.int32)))
+    gb.step(cfg)
+    check("garbage bound")

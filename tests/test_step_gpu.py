@@ -463,7 +463,8 @@ def test_deferred_update_graph_replays_equal_plain_stepping(n, monkeypatch):
 def test_knn_role_ties_keep_lowest_index(layout):
     """Duplicated object vertices make every nearest neighbour a tie (knn_points keeps the first minimum, PL:1529-1532):
     the duplicates sit in different chunks / waves (concatenated, reversed) or in the same selection group (interleaved).
-    Checked for both homes of the key decode: k_knn_decode (vertex stage alone) and the passengers of k_resolve."""
+    Checked for both homes of the key decode: k_knn_decode (vertex stage alone) and the passengers of k_resolve, and for
+    any content of the pruning bound."""
     from followmyhold_amd import engine as E
     sc = _np_scene(make_scene("ico3", 64, 64, seed=3))
     ov, of = sc["obj_verts"], sc["obj_faces"]
@@ -483,7 +484,17 @@ def test_knn_role_ties_keep_lowest_index(layout):
     gb = E.GuidanceBatch([sc], grid_res=16)
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
     out = {}
-    for name, stages in (("decode kernel", E.L.STAGE_VERTEX), ("k_resolve", None)):
+    rng = np.random.default_rng(11)
+    # The role prunes with the distance to whatever index knn_idx holds from the iteration before (k_vertex.inc): the answer
+    # must not depend on it -- cleared (first round), the true answer (second), garbage incl. negative and out-of-range
+    # entries, and the LATER copy of the true answer (a bound that ties with the winner from a higher index).
+    for name, stages in (("decode kernel", E.L.STAGE_VERTEX), ("k_resolve", None), ("garbage bound", E.L.STAGE_VERTEX),
+                         ("later copy as bound", None)):
+        kreg = gb.region("knn_idx", torch.int32)
+        if name == "garbage bound":
+            kreg.copy_(torch.from_numpy(rng.integers(-5, 4 * N, kreg.numel()).astype(np.int32)))
+        elif name == "later copy as bound":
+            kreg[:gb.meta[0]["Vh"]].copy_(torch.from_numpy(second[src[out["k_resolve"]]].astype(np.int32)))
         gb.step(cfg) if stages is None else gb.step(cfg, stages=stages)
         torch.cuda.synchronize()
         world = gb.region("world", torch.float32, (-1, 3)).cpu().numpy()
@@ -498,4 +509,4 @@ def test_knn_role_ties_keep_lowest_index(layout):
         assert np.array_equal(kd2, d2[np.arange(Vh), ref])
         assert np.array_equal(idx, first[src[idx]])         # never the later copy
         out[name] = idx
-    assert np.array_equal(out["decode kernel"], out["k_resolve"])
+    assert all(np.array_equal(out["decode kernel"], v) for v in out.values())
