@@ -286,7 +286,7 @@ def test_guidance_stage_driver_with_standin_networks(tmp_path, monkeypatch):
 
 
 @gpu
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     """tests/golden/ref_pipeline*.npz hold what the REFERENCE's own `__call__` (PL:1044-1679) returned and printed when it
     was executed in the build container on these scenes with the CPU restatement standing in for pytorch3d / kaolin
@@ -332,7 +332,11 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     n_joint = sch["num_inference_steps"] - sch["handopt_start_step"] - 2
     assert pipe.stats == {"inner_iterations": sch["optimization_steps_hand"] + sch["optimization_steps_scale"]
                           + n_joint * sch["optimization_steps_joint"], "skipped_empty": 0}
-    assert np.allclose(after_a["params"].cpu().numpy(), ref["opt0_small"], atol=6e-3)
+    # variant 2 runs phase A at 1 / 500 of the reference's learning rates, where the trajectory itself is comparable
+    d_a = np.abs(after_a["params"].cpu().numpy() - ref["opt0_small"]).max()
+    assert d_a < (2e-5 if var["tag"] == "_tame" else 6e-3), d_a
+    if var["tag"] == "_tame":
+        assert np.abs(ref["opt0_small"] - np.array([1, 0, 0, 0, 1, 0, 0, 0], np.float32)).max() > 1e-4      # it did move
     # first-iteration losses the reference printed (PL:1351-1355, 1446-1450, 1594-1598)
     num = lambda line: dict((k.strip(), float(v)) for k, v in re.findall(r"([A-Za-z_ 0-9]+): ([-+0-9.eE]+)", line.split(",", 1)[1]))
     opt = [num(l) for l in meta["log"] if l.startswith("Opt step 0")]
