@@ -1,6 +1,7 @@
 """bench.py as the driver launches it: the N=1 line's contract fields and the N>1 path (one rank per GPU; here two ranks
 share the box's one GPU and the collectives go through gloo -- FOHO_BENCH_BACKEND -- instead of RCCL)."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -57,6 +58,7 @@ def test_bench_line_n1_and_two_ranks_gloo():
     assert o1["value"] <= 2.0 * o2["value"] and o2["value"] <= 4.0 * o1["value"], (o1["value"], o2["value"])
     m1, m2 = o1["metrics"], o2["metrics"]
     assert m2["n_images"] == 2 and m2["n_steps"] == 2 * 20 * o2["repeats"] and m2["n_nan"] == 0
-    # rank 1 optimises another frame (seed = rank): the summed loss is not twice rank 0's, but of its order
-    assert 0.2 * m1["sum_total_loss"] < m2["sum_total_loss"] - m1["sum_total_loss"] < 5.0 * m1["sum_total_loss"]
+    # the loss terms are summed over the ranks too.  Their values depend on how many repeats the timed region took (the loops
+    # keep optimising) and rank 1 works on another frame (seed = rank), so only the order of magnitude is comparable
+    assert math.isfinite(m2["sum_total_loss"]) and 0.02 * m1["sum_total_loss"] < m2["sum_total_loss"] < 50.0 * m1["sum_total_loss"]
     assert "roofline" in o2 and "cpu_baseline" not in o2
