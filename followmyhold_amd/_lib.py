@@ -64,7 +64,7 @@ N_LOSS = 24
 LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_obj", "verts_obj", "edge", "normal0",
               "disp0", "sil0", "normal1", "disp1", "sil1", "n_intersect", "w_int", "mean_d2"]
 WS_REGIONS = ["world", "ndc", "vn", "p2f", "zbuf", "sdist", "prod", "knn_idx", "knn_d2", "gworld", "frac_count",
-              "stats", "parity", "frag_count", "seg_count"]
+              "stats", "parity", "frag_count", "seg_count", "hand_order"]
 N_KERNELS = 10
 
 

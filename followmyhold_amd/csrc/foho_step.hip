@@ -191,7 +191,7 @@ struct WS {
     size_t frac, frac_count, frac_seg, seg_count, rstats, rslot, loss_part, stats2;
     int nseg;
     size_t g_ndc, g_nrm, g_world, g_direct;
-    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc, vbox;
+    size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc, vbox, hand_order;
     size_t tile_static, image_static;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
@@ -301,6 +301,7 @@ static WS make_ws(const foho_dims& d) {
     w.g_direct = take(V3);
     w.knn_idx = take((size_t)d.Vtot * 4);
     w.knn_d2 = take((size_t)d.Vtot * 4);
+    w.hand_order = take(B * (size_t)std::max(d.Vh_max, 1) * 4);  // lane slot -> hand vertex of the nearest-neighbour role, as a DELTA (all-zero = identity)
     w.kp3d = take(B * 21 * 3 * 4);
     w.g_kp3d = take(B * 21 * 3 * 4);
     w.vert_part = take(B * VERT_BLOCKS_MAX * 8 * 4);
@@ -338,6 +339,7 @@ extern "C" int64_t foho_step_workspace_region(const foho_dims* dims, int region,
         case FOHO_WS_PARITY: off = w.parity; n = B * 2 * (size_t)G1 * G1 * 16; break;
         case FOHO_WS_FRAG_COUNT: off = w.nfrac; n = R * B * P * 4; break;
         case FOHO_WS_SEG_COUNT: off = w.seg_count; n = R * B * (size_t)w.nseg * 4; break;
+        case FOHO_WS_HAND_ORDER: off = w.hand_order; n = B * (size_t)std::max(d.Vh_max, 1) * 4; break;
         default: return -1;
     }
     if (nbytes) *nbytes = (int64_t)n;
@@ -406,6 +408,7 @@ struct Ctx {
     float *loss_part, *stats2;
     float *g_ndc, *g_nrm, *g_world, *g_direct;
     int32_t* knn_idx;
+    const int32_t* hand_order;
     float *knn_d2, *kp3d, *g_kp3d, *vert_part, *sim_part, *xf_part, *g_special, *vbox;
     unsigned long long* parity;
     int32_t* int_count;

@@ -165,6 +165,23 @@ def phase_cfg(phase, config=None, denoise_i=19, do_update=True, sigma=1e-8, gamm
     return c, n_renders
 
 
+def morton_order(points):
+    """Permutation that visits `points` (N, 3) along a Morton (Z-order) curve of their bounding box: neighbours in the order
+    are neighbours in space."""
+    p = np.asarray(points, np.float64).reshape(-1, 3)
+    if len(p) == 0:
+        return np.zeros(0, np.int64)
+    lo, hi = p.min(0), p.max(0)
+    q = ((p - lo) / np.maximum(hi - lo, 1e-30) * 1023.0).astype(np.int64).clip(0, 1023)
+
+    def spread(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+
+
 _WARMED_DEVICES = set()     # GPUs on which this process has launched the step once (GuidanceBatch.capture)
 
 
@@ -319,7 +336,9 @@ class GuidanceBatch:
         d.gbuf_f16 = int(bool(gbuf_f16))     # BASELINE configs[4]: depth / colour planes of the G-buffer in fp16, sums in fp32
         self.dims = d
         self._pinned, self._uploaded = {}, None      # page-locked upload mirrors of load_scenes()
+        self._hand_order = None
         self._alloc_workspace()
+        self._set_hand_order([np.asarray(s["hand_verts"], np.float32) for s in scenes])
         if self.obj_capacity is not None:
             self.adopt_objects()        # hands only for now: tables, pair table and AABB of the (still empty) scene
             self.flags.zero_()          # ... which is not an "empty iso-surface" event (flag bit 6)
@@ -332,6 +351,34 @@ class GuidanceBatch:
         # the AABB of verts_in lives in the workspace (FOHO_STAGE_BBOX); capacity mode recomputes it in adopt_objects()
         self._bbox_dirty = getattr(self, "obj_capacity", None) is None
         self._targets_dirty = True   # ... and so do the static loss sums of the target maps (FOHO_STAGE_TARGETS)
+        if getattr(self, "_hand_order", None) is not None:
+            self._upload_hand_order()
+
+    def _set_hand_order(self, hand_verts_per_image):
+        """Lane -> hand vertex table of the nearest-neighbour role (workspace region "hand_order", stored as a delta on the
+        lane slot): the hand's vertices in Morton order, so that a wave's 64 vertices are neighbours in space and agree more
+        often on the candidate runs they can skip (k_vertex.inc).  Any permutation gives the same results."""
+        vh_max = max(int(self.dims.Vh_max), 1)
+        tab = np.zeros((self.B, vh_max), np.int32)
+        for b, hv in enumerate(hand_verts_per_image):
+            n = len(hv)
+            if n:
+                tab[b, :n] = morton_order(hv) - np.arange(n)
+        self._hand_order = tab
+        self._upload_hand_order()
+
+    def _upload_hand_order(self):
+        reg = self.region("hand_order", torch.int32, self._hand_order.shape)
+        buf = self._pinned.get("hand_order")
+        if buf is None or tuple(buf.shape) != tuple(self._hand_order.shape):
+            buf = self._pinned["hand_order"] = torch.empty(self._hand_order.shape, dtype=torch.int32, pin_memory=True)
+        if self._uploaded is not None:
+            self._uploaded.synchronize()
+        buf.numpy()[...] = self._hand_order
+        reg.copy_(buf, non_blocking=True)
+        if self._uploaded is None:
+            self._uploaded = torch.cuda.Event()
+        self._uploaded.record()
 
     def adopt_objects(self, stream=None):
         """Capacity mode: install the object meshes whose vertices sit in the object slots of verts_in, whose mesh-local
@@ -493,6 +540,15 @@ class GuidanceBatch:
         up("mask", self.mask, per_image(lambda s: np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1)))
         up("kps", self.kps_2d, per_image(lambda s: s["kps_2d"]))
         up("params", self.params, put(np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1))))
+        vh_max = max(int(self.dims.Vh_max), 1)
+
+        def order(view):
+            view[...] = 0
+            for b, s in enumerate(scenes):
+                n = len(s["hand_verts"])
+                view[b, :n] = morton_order(s["hand_verts"]) - np.arange(n)
+            self._hand_order = view.copy()
+        up("hand_order", self.region("hand_order", torch.int32, (self.B, vh_max)), order)
         if self._uploaded is None:
             self._uploaded = torch.cuda.Event()
         self._uploaded.record()

@@ -186,7 +186,7 @@ enum {
 enum {
     FOHO_WS_WORLD = 0, FOHO_WS_NDC, FOHO_WS_VN, FOHO_WS_P2F, FOHO_WS_ZBUF, FOHO_WS_SDIST, FOHO_WS_PROD,
     FOHO_WS_KNN_IDX, FOHO_WS_KNN_D2, FOHO_WS_GWORLD, FOHO_WS_FRAC_COUNT, FOHO_WS_STATS, FOHO_WS_PARITY,
-    FOHO_WS_FRAG_COUNT, FOHO_WS_SEG_COUNT, FOHO_WS_NREGIONS
+    FOHO_WS_FRAG_COUNT, FOHO_WS_SEG_COUNT, FOHO_WS_HAND_ORDER, FOHO_WS_NREGIONS
 };
 
 size_t foho_step_workspace_bytes(const foho_dims* dims);

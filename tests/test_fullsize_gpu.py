@@ -496,3 +496,10 @@ def test_nearest_neighbour_pruning_is_exact_over_iterations():
     kreg.copy_(torch.from_numpy(rng.integers(-3, 3 * Vo, kreg.numel()).astype(np.int32)))
     gb.step(cfg)
     check("garbage bound")
+    # which hand vertex a lane takes is a table (Morton order by default): identity and a random permutation answer alike
+    oreg = gb.region("hand_order", torch.int32, (1, Vh))
+    assert int((oreg != 0).sum()) > Vh // 2                       # the constructor did install an order
+    for tag, perm in (("identity", np.arange(Vh)), ("random order", rng.permutation(Vh))):
+        oreg.copy_(torch.from_numpy((perm - np.arange(Vh)).astype(np.int32))[None])
+        gb.step(cfg)
+        check(tag)
