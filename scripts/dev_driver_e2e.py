@@ -27,7 +27,8 @@ for k in range(N):
 jr = os.path.join(tmp, "J.npy"); np.save(jr, sc["J_regressor"])
 print("fixtures written in %.1f s" % (time.perf_counter() - t0), flush=True)
 os.environ["FOHO_J_REGRESSOR"] = jr; os.environ["FOHO_MESH_LEVEL_GUIDANCE"] = "1"
-for rep, nfl in enumerate((16, 16, 1)):
+FLIGHTS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (16, 16, 1)
+for rep, nfl in enumerate(FLIGHTS):
     os.environ["FOHO_IMAGES_IN_FLIGHT"] = str(nfl)
     dd = dict(d, guidance_out_dir=os.path.join(tmp, f"out{rep}"))
     torch.cuda.synchronize(); t0 = time.perf_counter()
