@@ -354,6 +354,37 @@ def test_runner_reuses_slots_and_graphs_across_image_sets():
 
 
 @gpu
+def test_runner_takes_mixed_image_sizes_and_image_meshes_in_one_list():
+    """One list with two image sizes, scenes that bring their target maps and scenes that bring the image mesh instead (rendered
+    on the device inside the job): jobs are formed per shape, slots and renderers are rebuilt where a shape does not fit, and
+    every image's result equals its own single-image run."""
+    from followmyhold_amd import engine as E
+    short = _tame(E.OptimizationConfig(), 4, 2, 2)
+    rf = E.hip_render_fn("cuda")
+
+    def mk(kind, seed, size, deferred):
+        sc = synthetic.build_scene(rf, obj_kind=kind, H=size, W=size, seed=seed)
+        if deferred:      # the "MoGe mesh" of the synthetic scene: ground-truth hand + object; its render gives the target maps
+            v, f = _gt_mesh(sc)
+            n, d, _ = rf(v, f, size, size, sc["fov"])
+            hoi = (sc["hand_mask"] | sc["obj_mask"]).astype(np.float32)
+            sc["moge_normal"], sc["moge_disp"] = (n * hoi[..., None]).astype(np.float32), (d * hoi).astype(np.float32)
+            dsc = {k: v_ for k, v_ in sc.items() if k not in ("moge_normal", "moge_disp")}
+            dsc["moge_mesh"] = (v.astype(np.float32), f.astype(np.int32))
+            return sc, dsc
+        return sc, sc
+
+    # jobs of two images: (maps, mesh) at 64 x 64, (mesh, maps) at 80 x 80 -- mixed within a job --, then a padded one
+    cases = [mk("ico2", 21, 64, False), mk("ico2", 23, 64, True), mk("ico3", 22, 80, True), mk("ico2", 24, 80, False), mk("ico3", 25, 64, False)]
+    runner = inputs.MeshGuidanceRunner(short, in_flight=2, grid_res=16)
+    got = [r for _, r in runner.run_stream(((i, c[1]) for i, c in enumerate(cases)))]
+    assert len(got) == len(cases) and all(r["ok"] for r in got)
+    for (full, _), r in zip(cases, got):
+        ref = inputs.MeshGuidanceRunner(short, in_flight=1, grid_res=16).run([full])[0]
+        assert np.abs(ref["hand"][0] - r["hand"][0]).max() < 5e-5 and np.abs(ref["obj"][0] - r["obj"][0]).max() < 5e-5
+
+
+@gpu
 def test_exported_meshes_follow_the_final_parameters():
     """The meshes a job returns are the input meshes under the FINAL parameters (the reference builds debug_mano /
     debug_transformed_obj_mesh after the last optimiser step, PL:1614-1618, 1653-1657), not the vertices the last iteration
