@@ -182,7 +182,13 @@ enum {
                                         tgt_normal / tgt_disp / mask                                               */
 };
 
-/* named workspace regions, for parity tests that inspect intermediates */
+/* named workspace regions, for parity tests that inspect intermediates.
+ * FOHO_WS_KNN_IDX persists between steps: the nearest-neighbour role prunes with the distance to the vertex it names (any
+ * content is valid, the true previous answer prunes best).
+ * FOHO_WS_HAND_ORDER (B x Vh_max int32, host-written, optional): which hand vertex lane `slot` of the nearest-neighbour
+ * role takes, stored as a DELTA on the slot -- an all-zero (freshly allocated) region is the identity.  A spatially
+ * coherent order (the Python host writes the Morton order of the input hand) lets the 64 lanes of a wave skip the same runs
+ * of candidates; any PERMUTATION of [0, Vh) gives identical results.  Rewrite it after the workspace is re-allocated. */
 enum {
     FOHO_WS_WORLD = 0, FOHO_WS_NDC, FOHO_WS_VN, FOHO_WS_P2F, FOHO_WS_ZBUF, FOHO_WS_SDIST, FOHO_WS_PROD,
     FOHO_WS_KNN_IDX, FOHO_WS_KNN_D2, FOHO_WS_GWORLD, FOHO_WS_FRAC_COUNT, FOHO_WS_STATS, FOHO_WS_PARITY,
