@@ -14,7 +14,8 @@ vector at the end of the batch).
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline            the dominant kernel: algorithmic bytes per launch / hipEvent-timed duration on the launch stream
   kernels             every launch of the step the same way
-  step_roofline_frac  SURVEY 8(d)'s B_step x steps/s / HBM peak;  step_traffic_frac: the MEASURED bytes per step
+  step_roofline_frac  SURVEY 8(d)'s B_step x steps/s / HBM peak;  step_traffic_frac: the MEASURED bytes per step;
+                      batched.valu_issue_frac: the share of the chip's vector-ALU issue slots the measured rate needs
                       (rocprofv3 PMC summary under profiles/) x steps/s / HBM peak
   parity              first step of the benchmark scene, HIP vs the CPU oracle: loss_rel_err_vs_oracle,
                       pix_to_face_mismatch (the metric's "loss match vs ref")
@@ -366,6 +367,29 @@ def main():
         dist.destroy_process_group()
 
 
+def valu_record(args, image_steps_per_s):
+    """Share of the chip's vector-ALU issue slots a rate of image-steps/s needs: SQ counters of ONE 8-image launch sequence
+    (SQ_ACTIVE_INST_VALU x 4 = busy SIMD cycles, committed under profiles/) against 1024 SIMDs at the 2.4 GHz peak clock."""
+    if (args.obj, args.size) != ("20k", 512):
+        return {}
+    rel = "profiles/r03_rocprofv3_sq_counters_b8_1stream.csv"
+    try:
+        import csv
+        busy = insts = 0.0
+        for r in csv.DictReader(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel))):
+            if r["kernel"] in STEP_KERNELS:
+                if r["counter"] == "SQ_ACTIVE_INST_VALU":
+                    busy += 4.0 * float(r["mean_per_launch"])
+                elif r["counter"] == "SQ_INSTS_VALU":
+                    insts += float(r["mean_per_launch"])
+    except OSError:
+        return {}
+    if busy <= 0:
+        return {}
+    return {"valu_instructions_per_image_step": round(insts / 8.0), "valu_issue_frac": busy / 8.0 * image_steps_per_s / (1024 * 2.4e9),
+            "valu_source": rel + " (SQ_ACTIVE_INST_VALU x 4 busy SIMD cycles per 8-image step)"}
+
+
 def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, steps=200, gbuf_f16=False):
     """configs[2]'s per-GPU regime (64 frames image-sharded over 8 GPUs = 8 frames per GPU): 4 streams x 2 frames,
     one hipGraph of 50 iterations per stream.  gbuf_f16: configs[4]'s numeric regime (8-image batch, fp16 G-buffer planes,
@@ -392,6 +416,9 @@ def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, step
         per_image = sum(pmc.get(k, 0.0) for k in STEP_KERNELS) / 8.0
         rec.update(step_traffic_MB_per_image=round(per_image / 1e6, 3), step_traffic_frac=per_image * v / 1e9 / HBM_PEAK_GBS,
                    traffic_source=src)
+    # ... and the vector-ALU issue slots the step needs (the batch regime's nearer roof)
+    if not gbuf_f16:
+        rec.update(valu_record(args, v))
     return rec
 
 
@@ -440,6 +467,7 @@ def job_record(E, torch, synthetic, render_fn, args, dev):
         rec[f"in_flight_{in_flight}"] = {"images": n_img, "ok": ok, "images_per_s": n_img / dt, "ms_per_image": dt * 1e3 / n_img,
                                          "guidance_steps_per_s": n_img * n_iter / dt, "streams": runner.n_streams,
                                          "graph_captures": runner.stats["captures"], "slots_built": runner.stats["slots_built"]}
+        rec[f"in_flight_{in_flight}"].update({k: v for k, v in valu_record(args, n_img * n_iter / dt).items() if k == "valu_issue_frac"})
     return rec
 
 
