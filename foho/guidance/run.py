@@ -305,9 +305,10 @@ def _run_batched(assigned_imgs, dirs, config, device) -> None:
     "Error in processing")."""
     from followmyhold_amd import inputs
     # no more slots than list entries: a short list must not be padded up to the default with copies of its first image
-    # default: 16 (four streams x four images per launch); long lists 32 -- 10-15 % more images per second (190 against 172
-    # for inputs in host memory, 158 against 138 from files) for twice the memory and latency of a job
-    default_in_flight = 32 if len(assigned_imgs) >= 128 else 16
+    # default: 16 (four streams x four images per launch); long lists 32 -- 10-15 % more images per second in the steady state
+    # (190 against 172 for inputs in host memory, 148-158 against 138 from files) for twice the memory and latency of a job and
+    # a slower start (160 folders on a fresh process: 9.1 against 8.7 ms per image), hence only from 512 entries on
+    default_in_flight = 32 if len(assigned_imgs) >= 512 else 16
     in_flight = max(1, min(int(os.environ.get("FOHO_IMAGES_IN_FLIGHT", default_in_flight)), len(assigned_imgs)))
     # slots, hipGraphs and target renderers belong to the PROCESS: a second run() call with the same settings finds them ready
     key = (str(device), in_flight, repr(sorted(vars(config).items())))

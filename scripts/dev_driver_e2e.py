@@ -30,6 +30,8 @@ os.environ["FOHO_J_REGRESSOR"] = jr; os.environ["FOHO_MESH_LEVEL_GUIDANCE"] = "1
 FLIGHTS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (16, 16, 1)
 for rep, nfl in enumerate(FLIGHTS):
     os.environ["FOHO_IMAGES_IN_FLIGHT"] = str(nfl)
+    if nfl == 0:      # the driver's own default (16, or 32 for long lists)
+        os.environ.pop("FOHO_IMAGES_IN_FLIGHT")
     dd = dict(d, guidance_out_dir=os.path.join(tmp, f"out{rep}"))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     if rep == 1:
