@@ -6,7 +6,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 make -C $R/followmyhold_amd/csrc STAMPS=1 > /dev/null 2>&1
 cd /tmp
-for m in 59 0; do
+for m in 61 0; do
   rm -rf $O/d_$m
   ROLE_MASK=$m timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/d_$m -- python $R/scripts/dev_role_valu.py > /dev/null 2>&1
   python - $m $(find $O/d_$m -name "*counter_collection.csv" | head -1) <<'PY'
