@@ -506,7 +506,7 @@ class MeshGuidanceRunner:
             for phase, iters, denoise_i in job_schedule(self.config):
                 cfg, _ = E.phase_cfg(phase, self.config, denoise_i=denoise_i, do_update=True)
                 spg = _steps_per_graph(iters)
-                g = self._graph_for(slot, cfg, spg)
+                g = slot.graphs[(bytes(cfg), spg)]      # captured when the slot was built (_slot_for); never captured here, under the shared gate
                 gb.reset_optimizer()
                 for _ in range(iters // spg):
                     g.replay()
