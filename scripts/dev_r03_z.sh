@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/r03
-timeout 900 python -m pytest tests/test_step_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x > gpurun_out/r03/z_tests.log 2>&1; tail -n 2 gpurun_out/r03/z_tests.log
+timeout 900 python -m pytest tests/test_step_gpu.py tests/test_fullsize_gpu.py tests/test_edge_gpu.py tests/test_ops_gpu.py tests/test_facade_gpu.py tests/test_inputs.py tests/test_flexi.py -m gpu -q -x > gpurun_out/r03/z_tests.log 2>&1; tail -n 2 gpurun_out/r03/z_tests.log
 for i in 1 2 3; do
 timeout 300 python bench.py --steps 2000 --warmup 100 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
