@@ -105,6 +105,35 @@ def pmc_table(workload):
     return {}, None
 
 
+EA_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_ea_requests_b1.csv")],
+           ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_ea_requests_b8.csv")]}
+
+
+def ea_table(workload):
+    """({kernel: HBM bytes per launch}, file) from the L2's memory-side request counters BY SIZE CLASS -- 32 x RDREQ_32B +
+    64 x RDREQ_64B + 128 x RDREQ_128B read, 64 x WRREQ_64B + 32 x (WRREQ - WRREQ_64B) written (atomics are 32-byte write
+    requests) -- of the committed passes of THIS workload; ({}, None) without one.  The derived FETCH_SIZE tallies gfx950's
+    128-byte requests at 64 (hence the guide's factor 2, which over-charges the 64-byte ones); the size classes need no
+    correction: `scripts/micro/ea_calib.hip` reads / writes 1 GiB in five access shapes and the classes add up to the byte
+    count to 0.003 % (profiles/r03_ea_calibration.csv).  Reported BESIDE the guide's figure, never instead of it."""
+    for rel in EA_CSVS.get(workload, []):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        vals = {}
+        for line in open(path).read().splitlines()[1:]:
+            k, cn, _, mean = line.split(",")
+            vals.setdefault(k, {})[cn] = float(mean)
+        need = ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
+        out = {}
+        for k, v in vals.items():
+            if all(n in v for n in need):
+                out[k] = (32.0 * v["TCC_EA0_RDREQ_32B_sum"] + 64.0 * v["TCC_EA0_RDREQ_64B_sum"] + 128.0 * v["TCC_EA0_RDREQ_128B_sum"]
+                          + 64.0 * v["TCC_EA0_WRREQ_64B_sum"] + 32.0 * (v["TCC_EA0_WRREQ_sum"] - v["TCC_EA0_WRREQ_64B_sum"]))
+        return out, rel
+    return {}, None
+
+
 def dominant_from_kernel_stats(names, workload):
     """(longest step kernel by mean duration, file) in the committed rocprofv3 kernel trace of this workload, (None, None)
     without one.  Reported BESIDE the live choice (`dominant_by_trace`), it never replaces it."""
@@ -321,9 +350,11 @@ def main():
         ipb = gb.B               # images in the profiled batch (the first stream's)
         achieved = kb * ipb / (acc[dom] * 1e-3) / 1e9
         pmc, pmc_src = pmc_table(workload)
+        ea, ea_src = ea_table(workload)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom),
                            "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)" if pmc_src else None,
+                           "traffic_by_request_size": ea.get(dom), "traffic_by_request_size_source": ea_src,
                            "kernel_ms": acc[dom], "kernel_ms_median": med[dom], "algorithmic_bytes_per_launch": kb * ipb,
                            "dominant_by_trace": prof_dom, "trace_source": prof_src}
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
@@ -335,7 +366,8 @@ def main():
             gbs = kbk * ipb / (v * 1e-3) / 1e9
             out["kernels"][k] = {"ms": round(v, 5), "algorithmic_MB": round(kbk * ipb / 1e6, 3), "GBs": round(gbs, 1),
                                  "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                 "traffic_MB": round(pmc[k] / 1e6, 3) if k in pmc else None}
+                                 "traffic_MB": round(pmc[k] / 1e6, 3) if k in pmc else None,
+                                 "traffic_by_request_size_MB": round(ea[k] / 1e6, 3) if k in ea else None}
         out["step_hbm_GBs"] = bstep * value / world / 1e9  # whole-step algorithmic bytes x steps/s per GPU
         out["step_roofline_frac"] = out["step_hbm_GBs"] / HBM_PEAK_GBS
         if pmc:
