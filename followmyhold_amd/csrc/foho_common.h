@@ -67,6 +67,13 @@ __device__ __forceinline__ unsigned wave_max(unsigned v) {
     FOHO_DPP_REDUCE(unsigned, v, 0u, FOHO_OP_MAXU, FOHO_MOV_U);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Block j of a role's n blocks -> the part of the role it takes, such that the blocks an XCD receives (those with equal
+// j mod 8: workgroups go to the XCDs round robin) take a contiguous range: c = j mod 8 gets [c*q + min(c, r), ...) with
+// q = n / 8, r = n mod 8 -- q + 1 parts for c < r, q otherwise.  A bijection of [0, n).
+__device__ __forceinline__ int xcd_order(int j, int n) {
+    const int c = j & 7, q = n >> 3, r = n & 7;
+    return c * q + min(c, r) + (j >> 3);
+}
 // inclusive prefix sum over the 64 lanes of a wave (DPP: shifts inside each row of 16, then row_bcast:15 adds row r's
 // total to row r+1 for rows 1 and 3, row_bcast:31 adds the total of the first 32 lanes to the last 32).  Whole wave.
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
