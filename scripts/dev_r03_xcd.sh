@@ -5,14 +5,14 @@ cd $R
 O=$R/gpurun_out/r03xcd
 rm -rf $O; mkdir -p $O
 LOG=$O/xcd.log
-timeout 900 python -m pytest tests/test_step_gpu.py tests/test_edge_gpu.py -m gpu -x -q 2>&1 | tail -3 >> $LOG
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 >> $LOG
 B="python bench.py --no-cpu-baseline --no-extras --steps 400 --warmup 50"
 run() { label=$1; shift
   for ipg in 1 8 16 32; do
     env "$@" timeout 200 $B --images-per-gpu $ipg 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label ipg $ipg', round(o['value']), o['kernel_ms']['k_stage2'])" >> $LOG 2>&1 || echo "$label ipg $ipg FAILED" >> $LOG
   done
 }
-for rep in 1 2 3; do
+for rep in 1 2; do
 run base FOHO_HIP_SO=$R/followmyhold_amd/libfoho_hip_base.so
 run xcd X=1
 done
