@@ -57,8 +57,20 @@ int main() {
     hipLaunchKernelGGL(k_gather12, dim3(G), dim3(T), 0, 0, (const f3*)a, N / 12, M, sink);
     hipLaunchKernelGGL(k_write16, dim3(G), dim3(T), 0, 0, (float4*)b, N / 16);
     hipLaunchKernelGGL(k_read16, dim3(G), dim3(T), 0, 0, (const float4*)a, N / 16, sink);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(k_atomic8, dim3(G), dim3(T), 0, 0, (unsigned long long*)b, (size_t)(256u << 20) / 8, M);
+    CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k_atomic8: %zu agent-scope 64-bit atomics on random words in %.3f ms = %.1f atomics/ns\n", M, ms, M / (ms * 1e6));
+    // ... and on a plane the size of a z-key plane (2 MB: 512 x 512 x 8 bytes), the step's case
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_atomic8, dim3(G), dim3(T), 0, 0, (unsigned long long*)b, (size_t)(2u << 20) / 8, M);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k_atomic8 on a 2 MB plane: %.3f ms = %.1f atomics/ns\n", ms, M / (ms * 1e6));
     printf("bytes: read16/read4/write16 %zu, read12 %zu, gather12 %zu records (%zu bytes asked), atomic8 %zu ops\n", N, N / 12 * 12, M, M * 12, M);
     return 0;
 }
