@@ -192,7 +192,7 @@ struct WS {
     int nseg;
     size_t g_ndc, g_nrm, g_world, g_direct;
     size_t knn_idx, knn_d2, kp3d, g_kp3d, vert_part, sim_part, xf_part, g_special, parity, int_count, final_ticket, knn_inv, loss_acc, vbox, hand_order;
-    size_t tile_static, image_static;
+    size_t tile_static, image_static, act_list, act_count;
     int btiles_x, nbtiles;
     size_t zero_begin, zero_end;  // region cleared by k_zero every step
 };
@@ -295,6 +295,8 @@ static WS make_ws(const foho_dims& d) {
     w.pcol = take(R * B * P * 12);  // colour n_a + n_b + n_c of the hit face (read back by the loss / backward passes)
     w.frac = take(R * B * (size_t)d.frac_cap * sizeof(FracEntry));  // overflow of the segments (rare)
     w.frac_seg = take(R * B * (size_t)w.nseg * FRAC_SEG * sizeof(FracEntry));
+    w.act_list = take(R * B * (size_t)w.nbtiles * 4);  // batches: tiles k_resolve has work on this step (k_tile_list), per (render, image)
+    w.act_count = take(R * B * 4);
     w.kfix = take(R * B * KFIX_MAX * sizeof(KFixEntry));
     w.loss_part = take(R * B * LOSS_BLOCKS * NPART * 4);
     w.stats2 = take(R * B * NSTAT * 4);
@@ -388,6 +390,8 @@ struct Ctx {
     int* bwd_list;
     unsigned* bwd_count;
     uint8_t *tile_touched, *tile_clean;
+    int* act_list;        // k_tile_list -> k_resolve (batches)
+    unsigned* act_count;
     unsigned long long* pair_v;
     int* pending;
     float* state_next;

@@ -428,3 +428,47 @@ def test_k100_buffer_is_rebuilt_where_the_all_fragment_product_would_differ():
     g = gb.grad_params[0].cpu().numpy()
     for k in ["scale_obj", "trans_obj", "rot_obj"]:
         assert np.linalg.norm(g[E.PARAM_SLICES[k]] - grads[k].numpy()) <= 1e-3 * max(np.linalg.norm(grads[k].numpy()), 1e-6), k
+
+
+@gpu
+@pytest.mark.parametrize("cap", [1, 5, 64])
+def test_listed_resolve_equals_the_dense_launch(cap, monkeypatch):
+    """Batches of eight images and more launch k_resolve over a LIST of the tiles that need work (k_tile_list) instead of over
+    every tile of the frame, `cap` workgroups per (render, image), and k_resolve_ovf takes the entries beyond them.  Forced
+    here on a two-image batch through FOHO_LISTED_CAP with caps far below the number of active tiles (1, 5: nearly everything
+    goes through the overflow kernel) and above it (64): the G-buffer of the first step must be the dense launch's
+    (FOHO_LISTED_CAP=0) bit for bit, losses and parameters of three optimiser steps the same up to the order of the gradient atomics."""
+    from followmyhold_amd import engine as E
+    scenes = [_np_scene(make_scene("ico2", 96, 160, seed=s)) for s in (3, 5)]
+
+    def run(env):
+        monkeypatch.setenv("FOHO_LISTED_CAP", env)
+        gb = E.GuidanceBatch(scenes, grid_res=16)
+        cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+        out = []
+        for _ in range(3):
+            gb.step(cfg)
+            torch.cuda.synchronize()
+            gb.raise_on_flags()
+            P = 96 * 160
+            out.append(dict(p2f=gb.region("p2f", torch.int32, (2, 2, P)).cpu().numpy().copy(),
+                            z=gb.region("zbuf", torch.float32, (2, 2, P)).cpu().numpy().copy(),
+                            sd=gb.region("sdist", torch.float32, (2, 2, P)).cpu().numpy().copy(),
+                            loss=[gb.loss_dict(b)["total"] for b in range(2)], params=gb.params.cpu().numpy().copy()))
+        return out
+
+    dense, listed = run("0"), run(str(cap))
+    # first step: same parameters on both sides, so every plane is the same bit for bit
+    d, l = dense[0], listed[0]
+    assert np.array_equal(d["p2f"], l["p2f"])
+    hit = d["p2f"] >= 0
+    assert hit.any() and (~hit).any()
+    assert np.array_equal(d["z"][hit], l["z"][hit]) and np.array_equal(d["sd"][hit], l["sd"][hit])
+    # later steps start from parameters whose last bits depend on the order of the gradient atomics (on either side): close, and
+    # the planes are compared where both sides see the same face
+    for d, l in zip(dense, listed):
+        np.testing.assert_allclose(l["loss"], d["loss"], rtol=1e-4)
+        np.testing.assert_allclose(l["params"], d["params"], rtol=1e-4, atol=1e-6)
+        same = (d["p2f"] == l["p2f"]) & (d["p2f"] >= 0)
+        assert same.sum() >= 0.995 * (d["p2f"] >= 0).sum()
+        np.testing.assert_allclose(l["z"][same], d["z"][same], rtol=1e-5)
