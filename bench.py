@@ -479,18 +479,19 @@ def job_record(E, torch, synthetic, render_fn, args, dev):
     inputs.MeshGuidanceRunner): the reference's whole schedule -- 200 hand + 100 object + 9 x 50 joint iterations = 750 per
     image (CFG:11-13, PL:1293-1610) -- for images already in host memory, including the upload of every image set, the
     installation of its objects on the device and the export read-back; graphs are captured by a first, untimed image set
-    (once per process).  Images per second and GPU at 1, 8 and 16 images in flight."""
+    (once per process).  Images per second and GPU at 1, 8, 16 and 32 images in flight."""
     from followmyhold_amd import inputs
     H = W = args.size
     cfg0 = E.OptimizationConfig()
     n_iter = sum(it for _, it, _ in inputs.job_schedule(cfg0))
     rec = {"iterations_per_image": n_iter, "schedule": "200 A + 100 B + 9 x 50 C", "unit": "images/s"}
     scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=200 + j) for j in range(16)]
-    for in_flight, n_img in ((1, 4), (8, 16), (16, 32)):
+    scenes = scenes + scenes          # 32 scene dicts (16 distinct images)
+    for in_flight, n_img in ((1, 4), (8, 16), (16, 32), (32, 64)):    # 32: eight images per launch, k_resolve in listed mode
         runner = inputs.MeshGuidanceRunner(cfg0, device=dev, in_flight=in_flight)
         res = runner.run(scenes[:in_flight])              # captures (untimed: once per process)
         torch.cuda.synchronize(dev)
-        todo = [scenes[j % 16] for j in range(n_img)]
+        todo = [scenes[j % 32] for j in range(n_img)]
         t0 = time.perf_counter()
         res = runner.run(todo)
         torch.cuda.synchronize(dev)
