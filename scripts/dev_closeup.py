@@ -9,7 +9,7 @@ rf = E.hip_render_fn("cuda")
 ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device="cuda")
 for fov in [float(a) for a in sys.argv[1:]] or [60.0, 30.0, 22.0]:
     scenes = [synthetic.build_scene(rf, obj_kind="20k", H=512, W=512, fov=fov, seed=100 + j) for j in range(32)]
-    for mode in ("0", None, "384", "512"):
+    for mode in ("0", None):
         if mode is None:
             os.environ.pop("FOHO_LISTED_CAP", None)
         else:
