@@ -198,6 +198,10 @@ enum {
 size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
 int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
+/* One step (or the prefix of it that stage_mask names) on `stream`, asynchronously.  Environment, read at every call (i.e. when
+ * a graph is captured): FOHO_LISTED_CAP -- how the resolve pass finds its tiles: unset = one workgroup per 32x8 tile of the frame
+ * below eight images per launch, a compacted list of the tiles that need work from eight on; 0 = always the former, n > 0 =
+ * always the latter with n workgroups per (render, image).  Same results either way. */
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
 /* Applies the update a deferred_update step left pending (no-op per image when nothing is pending): one small launch;
  * cfg->deferred_update must carry the number of the LAST step run. */
