@@ -263,3 +263,25 @@ def test_guidance_driver_world_size_2_gloo(tmp_path):
     assert tot["sum_total_loss"] == 3 + 11 + 40 + 10 and tot["sum_wall_ms"] > 0
     for i in [3, 10, 11, 40]:
         assert (root / "guidance_out_dir" / f"{i:04d}_obj.ply").exists()
+
+
+def test_bench_traffic_tables_read_the_committed_profiles():
+    """bench.py attaches HBM traffic to its record from the committed rocprofv3 PMC summaries: the guide's 2 x FETCH_SIZE +
+    WRITE_SIZE and, beside it, the bytes counted by request size class.  Both tables must parse, cover the six kernels of the
+    step for the benchmark workload, agree with each other within 25 % (they are separate profiler runs) and stay silent for a
+    workload nobody profiled."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("foho_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for wl in (("20k", 512, 1), ("20k", 512, 8)):
+        pmc, src = bench.pmc_table(wl)
+        ea, ea_src = bench.ea_table(wl)
+        assert src and ea_src and os.path.exists(os.path.join(root, src)) and os.path.exists(os.path.join(root, ea_src))
+        for k in bench.STEP_KERNELS:
+            assert pmc[k] > 0 and ea[k] > 0
+        tot_pmc, tot_ea = sum(pmc[k] for k in bench.STEP_KERNELS), sum(ea[k] for k in bench.STEP_KERNELS)
+        assert abs(tot_pmc - tot_ea) <= 0.25 * tot_pmc, (tot_pmc, tot_ea)
+    assert bench.pmc_table(("40k", 512, 1)) == ({}, None) and bench.ea_table(("ico4", 64, 1)) == ({}, None)
