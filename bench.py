@@ -212,12 +212,19 @@ def main():
     ap.add_argument("--gbuf-f16", action="store_true", help="depth / colour planes of the G-buffer in fp16 (configs[4])")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # plain `python bench.py --gpus N`: this process becomes the launcher
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        # a line that says n_gpus = world while the caller asked for --gpus N would be a mislabelled measurement
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(`python bench.py --gpus {args.gpus}` does it by itself)")
+    import numpy as np
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # FOHO_BENCH_BACKEND=gloo lets the N>1 code path be exercised with several ranks on ONE GPU (development aid);
@@ -225,6 +232,9 @@ def main():
     backend = os.environ.get("FOHO_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} "
+                         "(one rank per GPU over RCCL; FOHO_BENCH_BACKEND=gloo shares GPUs for plumbing tests)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -302,7 +312,8 @@ def main():
     value = world * ipg * args.steps / dt
     out = {
         "metric": "guidance-steps/sec (512x512, 778+20k verts)", "value": value, "unit": "guidance-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+        "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "collective_backend": backend if dist is not None else None,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
         "repeats": len(times), "ms_per_step_min_max": [min(times) * 1e3 / args.steps, max(times) * 1e3 / args.steps],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.gbuf_f16 else "f32 (G-buffer f16)",
         "data": "synthetic",
@@ -397,6 +408,23 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks, one per GPU, under
+    torch.distributed.run (rendezvous on 127.0.0.1, a free port) and return its exit status.  The reference's analogue is
+    one SLURM array task per chunk of the image list (src/foho/guidance/run.py:178-185)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL needs dmabuf IPC on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def valu_record(args, image_steps_per_s):

@@ -62,3 +62,40 @@ def test_bench_line_n1_and_two_ranks_gloo():
     # keep optimising) and rank 1 works on another frame (seed = rank), so only the order of magnitude is comparable
     assert math.isfinite(m2["sum_total_loss"]) and 0.02 * m1["sum_total_loss"] < m2["sum_total_loss"] < 50.0 * m1["sum_total_loss"]
     assert "roofline" in o2 and "cpu_baseline" not in o2
+    assert o2["rccl_ranks"] == 2 and o2["collective_backend"] == "gloo" and o1["rccl_ranks"] == 1
+
+    # the PLAIN form the driver uses at N = 1, with N = 2: bench.py launches its own ranks (one per GPU; gloo lets the two
+    # share this box's GPU) and the line says two
+    r3 = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + flags, env=_env(FOHO_BENCH_BACKEND="gloo"), cwd=ROOT,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stdout[-4000:]
+    o3 = _line(r3.stdout)
+    assert o3["n_gpus"] == 2 and o3["rccl_ranks"] == 2 and o3["config"]["global_images"] == 2
+    assert abs(o3["value"] - 2 * 1e3 / o3["ms_per_step"]) <= 1e-6 * o3["value"]
+    assert o1["value"] <= 2.0 * o3["value"] and o3["value"] <= 4.0 * o1["value"], (o1["value"], o3["value"])
+
+
+def test_bench_refuses_a_rank_count_other_than_gpus():
+    """`--gpus N` under a launcher that started another number of ranks is an error, not a line with a different n_gpus
+    (checked before anything touches a GPU, so this runs anywhere)."""
+    env = _env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stdout and '{"metric"' not in r.stdout
+    env.update(WORLD_SIZE="4")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stdout
+
+
+def test_bench_plain_form_launches_one_rank_per_gpu():
+    """Without a GPU the launched ranks stop at "needs an MI355X" -- what is checked here is that `python bench.py --gpus 2`
+    becomes TWO ranks (each reports its own refusal) and that the launcher hands their failure on as its exit status."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the gpu test")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.count("bench.py needs an MI355X") == 2, r.stdout[-3000:]
