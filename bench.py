@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   cpu_baseline        the CPU oracle ("port" of the reference path) on this box's host cores, bounded sample;
   cpu_baseline_1t     the same with one thread, the reference's own thread policy (src/foho/main.py:65-68)
   batched             configs[2]'s per-GPU regime: 8 frames per GPU, 4 streams x 2 frames
+  closeup             the reference's real frames: crops around hand + object (meshes fill the frame), 1 and 32 images in flight
   job                 the 750-iteration per-image job through the product entry point's engine at 1 / 8 / 16 images in flight
   driver_on_files     foho.guidance.run.run() on scene folders in the reference's file formats, wall time per image
   topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
@@ -392,6 +393,7 @@ def main():
             for key, fn in (("batched", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("batched_f16_gbuffer", lambda: batched_record(E, torch, synthetic, render_fn, args, dev, cfg, gbuf_f16=True)),
                             ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev)),
+                            ("closeup", lambda: closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
                             ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
@@ -479,6 +481,46 @@ def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, step
     # ... and the vector-ALU issue slots the step needs (the batch regime's nearer roof)
     if not gbuf_f16:
         rec.update(valu_record(args, v))
+    return rec
+
+
+def closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg, steps=500):
+    """The reference's real input regime: its frames are 512 x 512 CROPS around hand + object (union box + 10 px, squared,
+    x 1.25; src/foho/preprocess/segment_hoi_sam2.py:108-124, 180-196 -> synthetic.hoi_crop), so the meshes fill the frame: a
+    ~25 degree field of view, six times the hit pixels and five times the hit tiles of the 60-degree scene SURVEY 8(d)
+    prescribes for the headline.  Same meshes, same joint step; one image (50-iteration graphs) and 32 in flight (4 streams x 8
+    images, listed k_resolve); per-kernel durations of the one-image step (hipEvents, as in the headline's `kernels`)."""
+    H = W = args.size
+    scenes = [synthetic.build_scene(render_fn, obj_kind=args.obj, H=H, W=W, seed=400 + j, crop="hoi") for j in range(32)]
+    rec = {"workload": f"{H}x{W} crop around hand + object (hoi_crop), fov {scenes[0]['fov']:.1f} deg, {args.obj} object, joint guidance step",
+           "unit": "guidance-steps/s"}
+    for n_img, n_streams, key in ((1, 1, "one_image"), (32, 4, "in_flight_32")):
+        group, run_steps = make_runner(E, torch, scenes[:n_img], n_streams, dev, cfg, 50)
+        run_steps(100)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(3):
+            run_steps.realign()
+            t0 = time.perf_counter()
+            run_steps(steps if n_img == 1 else 200)
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t0) / (steps if n_img == 1 else 200))
+        for g in group.batches:
+            g.raise_on_flags()
+        dt = float(np.median(ts))
+        rec[key] = {"value": n_img / dt, "ms_per_step": dt * 1e3, "images": n_img, "streams": n_streams}
+        if n_img == 1:
+            gb = group.batches[0]
+            cfg_frozen, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
+            acc = {}
+            for _ in range(50):
+                for k, v in gb.step_profiled(cfg_frozen, deferred=True).items():
+                    acc[k] = acc.get(k, 0.0) + v / 50
+            p2f = gb.region("p2f", torch.int32, (2, gb.B, H, W))[:, 0]
+            rec["hit_pixels"] = [int((p2f[r] >= 0).sum()) for r in range(2)]
+            rec["hit_tiles"] = [int((p2f[r] >= 0)[: H // 8 * 8, : W // 32 * 32].reshape(H // 8, 8, W // 32, 32).any(3).any(1).sum()) for r in range(2)]
+            rec["kernel_us"] = {k: round(v * 1e3, 2) for k, v in acc.items()}
+        del group
     return rec
 
 

@@ -44,7 +44,8 @@ class FohoStepCfg(ctypes.Structure):
                 ("use_intersection", c_i), ("w_int_near", c_f), ("w_int_far", c_f), ("int_gate", c_f),
                 ("int_gate_step_ok", c_i), ("sigma", c_f), ("gamma", c_f), ("blur_radius", c_f),
                 ("lr", c_f * 16), ("beta1", c_f), ("beta2", c_f), ("eps", c_f), ("weight_decay", c_f),
-                ("do_update", c_i), ("world_space_input", c_i), ("deferred_update", c_i), ("n_active_renders", c_i)]
+                ("do_update", c_i), ("world_space_input", c_i), ("deferred_update", c_i), ("n_active_renders", c_i),
+                ("listed_cap", c_i)]
 
 
 class FohoStepDesc(ctypes.Structure):
@@ -52,7 +53,7 @@ class FohoStepDesc(ctypes.Structure):
                 ("inc_fc", vp), ("nbr_off", vp), ("nbr_idx", vp), ("J_regressor", vp), ("tgt_normal", vp),
                 ("tgt_disp", vp), ("mask", vp), ("kps_2d", vp), ("params", vp), ("adam_m", vp), ("adam_v", vp),
                 ("adam_t", vp), ("losses", vp), ("grad_params", vp), ("grad_verts_in", vp), ("flags", vp),
-                ("workspace", vp), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", vp), ("workspace_bytes", ctypes.c_size_t), ("hand_order_valid", c_i)]
 
 
 # enums of include/foho_hip.h
@@ -66,6 +67,7 @@ LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_ob
 WS_REGIONS = ["world", "ndc", "vn", "p2f", "zbuf", "sdist", "prod", "knn_idx", "knn_d2", "gworld", "frac_count",
               "stats", "parity", "frag_count", "seg_count", "hand_order"]
 N_KERNELS = 10
+ABI_VERSION = 102     # include/foho_hip.h: foho_step_cfg.listed_cap, foho_step_desc.hand_order_valid, foho_abi_sizes
 
 
 def build(force=False):
@@ -86,6 +88,13 @@ def lib():
         L = ctypes.CDLL(SO_PATH)
         L.foho_last_error.restype = ctypes.c_char_p
         L.foho_version.restype = ctypes.c_int
+        sizes = (ctypes.c_int64 * 5)()
+        L.foho_abi_sizes.restype = ctypes.c_int
+        ver = L.foho_abi_sizes(sizes)
+        mine = [ctypes.sizeof(t) for t in (FohoImage, FohoDims, FohoRenderCfg, FohoStepCfg, FohoStepDesc)]
+        if list(sizes) != mine or ver < ABI_VERSION:
+            raise FohoError(f"{SO_PATH} is ABI version {ver} with struct sizes {list(sizes)}; this binding is version "
+                            f"{ABI_VERSION} with {mine}: rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
         L.foho_step_workspace_bytes.restype = ctypes.c_size_t
         L.foho_step_workspace_bytes.argtypes = [ctypes.POINTER(FohoDims)]
         L.foho_step_workspace_region.restype = ctypes.c_int64

@@ -415,6 +415,7 @@ class GuidanceBatch:
                 setattr(d, name, getattr(self, name).data_ptr())
             d.J_regressor = self.J.data_ptr()
             d.workspace_bytes = self.workspace.numel()
+            d.hand_order_valid = int(getattr(self, "_hand_order", None) is not None)   # the table is (re-)uploaded with every workspace
             self._desc = d
         return self._desc
 

@@ -208,8 +208,32 @@ def similarity_about_center(v, scale, Rm, t):
     return (scale * (v - c)) @ Rm.T + c + t
 
 
-def build_scene(render_fn, obj_kind="20k", H=512, W=512, fov=60.0, seed=0, two_hands=False):
+def hoi_crop(points, src_width=640.0, src_fov=60.0, margin_px=10.0, factor=1.25):
+    """The reference's input regime: its frames are CROPS around the hand and the object -- union of the two boxes, 10 px
+    of margin on every side, squared up around its centre, times 1.25, resampled to 512 x 512
+    (src/foho/preprocess/segment_hoi_sam2.py:108-124 `process_bbox`, :180-196) -- so the meshes fill most of the frame,
+    where a hand at half a metre through a 60-degree lens covers 3 % of it.  `points` (N,3) in the camera's space (looking
+    down -z) as a `src_width`-pixel, `src_fov`-degree source camera sees them -> (shift (3,), fov_degrees): the lateral
+    shift that puts the crop's centre on the optical axis (the depth maps of the crop come from a network that assumes a
+    centred principal point) and the field of view of the crop."""
+    p = np.asarray(points, np.float64)
+    px_per_tan = (src_width / 2.0) / math.tan(math.radians(src_fov) / 2.0)
+    zc = float(np.mean(-p[:, 2]))
+    shift = np.zeros(3)
+    for _ in range(4):      # the box's edges are set by points at different depths: a few rounds centre it to a fraction of a pixel
+        u, v = (p[:, 0] + shift[0]) / -p[:, 2], (p[:, 1] + shift[1]) / -p[:, 2]
+        shift -= np.array([(u.max() + u.min()) / 2.0 * zc, (v.max() + v.min()) / 2.0 * zc, 0.0])
+    u, v = (p[:, 0] + shift[0]) / -p[:, 2], (p[:, 1] + shift[1]) / -p[:, 2]
+    w = (u.max() - u.min()) * px_per_tan + 2.0 * margin_px
+    h = (v.max() - v.min()) * px_per_tan + 2.0 * margin_px
+    side = max(w, h) * factor
+    return shift, 2.0 * math.degrees(math.atan(side / 2.0 / px_per_tan))
+
+
+def build_scene(render_fn, obj_kind="20k", H=512, W=512, fov=60.0, seed=0, two_hands=False, crop=None):
     """Scene dict of numpy arrays for one image.
+
+    crop="hoi": the frame is the reference's crop around hand and object (`hoi_crop`; `fov` is then computed, not taken).
 
     render_fn(verts_world (V,3) f32, faces (F,3) i64, H, W, fov) -> (normal (H,W,3), disp (H,W), pix_to_face (H,W))
     renders the ground-truth pose to make the MoGe-style targets (reference pipelines.py:1247-1256).
@@ -236,6 +260,13 @@ def build_scene(render_fn, obj_kind="20k", H=512, W=512, fov=60.0, seed=0, two_h
     T[:3, 3] = obj_center
     ov_hy = ov / s_h2m  # object as Hunyuan emits it
     ov_moge = ov_hy @ T[:3, :3].T + T[:3, 3]
+    if crop == "hoi":
+        shift, fov = hoi_crop(np.concatenate([hv, ov_moge], 0))
+        hv = hv + shift
+        T[:3, 3] += shift
+        ov_moge = ov_hy @ T[:3, :3].T + T[:3, 3]
+    elif crop is not None:
+        raise ValueError(crop)
 
     Vh = hv.shape[0]
     gt_v = np.concatenate([hv, ov_moge], 0).astype(np.float32)

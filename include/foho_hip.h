@@ -54,6 +54,11 @@ typedef enum {
 
 const char* foho_last_error(void);
 int foho_version(void);
+/* Layout check for bindings that mirror the structs (ctypes, cgo, JNI): fills out[0..4] with sizeof(foho_image),
+ * sizeof(foho_dims), sizeof(foho_render_cfg), sizeof(foho_step_cfg), sizeof(foho_step_desc) of THIS build and returns
+ * foho_version().  A caller whose own sizes differ is talking to another version of the ABI (fields are only ever
+ * appended; entry points that gained parameters: foho_raster_bwd's blur_radius in 101). */
+int foho_abi_sizes(int64_t out[5]);
 
 /* ---- per-image constants (array of B of these lives in DEVICE memory) -------------------- */
 typedef struct {
@@ -124,6 +129,12 @@ typedef struct {
                                         draws gets no raster / vertex-normal workgroups, w_contact == 0 without the
                                         intersection gate -> no nearest-neighbour role (contact / mean_d2 report 0),
                                         w_edge == w_verts_obj == 0 -> no edge role, w_kps == 0 -> no keypoint role        */
+    int32_t listed_cap;              /* how the resolve pass finds its tiles.  0 = automatic: one workgroup per 32x8 tile of
+                                        the frame below eight images per launch, a compacted list of the tiles that need
+                                        work (k_tile_list) walked by 3/8 of the frame's tile count as workgroups from eight
+                                        on; < 0 = always the former; n > 0 = always the latter with n workgroups per
+                                        (render, image).  Same results either way.  (Was the FOHO_LISTED_CAP environment
+                                        variable up to version 101; the library reads no environment any more.)        */
 } foho_step_cfg;
 
 /* ---- buffers of one batched step -------------------------------------------------------------- */
@@ -153,10 +164,13 @@ typedef struct {
     float* grad_params;              /* (B,16)                                                       */
     float* grad_verts_in;            /* (Vtot,3)  dL/d verts_in (object rows are the autograd sink)  */
     int32_t* flags;                  /* (B)  bit0 NaN loss, bit1 frac list overflow, bit2 >K faces/pixel,
-                                        (bit3 unused since near-plane clipping is implemented),
+                                        (bit3 retired in 101: near-plane clipping is implemented),
                                         bit4 / bit5: capacity mode, see foho_object_update                      */
     void* workspace;
     size_t workspace_bytes;
+    int32_t hand_order_valid;        /* 1: the caller has written a permutation into FOHO_WS_HAND_ORDER (below); 0: the
+                                        region is ignored and lanes take hand vertices in index order -- a workspace that
+                                        is not zero-filled (plain hipMalloc) is safe with 0                          */
 } foho_step_desc;
 
 /* indices into losses[b][*] */
@@ -185,8 +199,8 @@ enum {
 /* named workspace regions, for parity tests that inspect intermediates.
  * FOHO_WS_KNN_IDX persists between steps: the nearest-neighbour role prunes with the distance to the vertex it names (any
  * content is valid, the true previous answer prunes best).
- * FOHO_WS_HAND_ORDER (B x Vh_max int32, host-written, optional): which hand vertex lane `slot` of the nearest-neighbour
- * role takes, stored as a DELTA on the slot -- an all-zero (freshly allocated) region is the identity.  A spatially
+ * FOHO_WS_HAND_ORDER (B x Vh_max int32, host-written, optional, read only when foho_step_desc.hand_order_valid): which hand
+ * vertex lane `slot` of the nearest-neighbour role takes, stored as a DELTA on the slot -- all-zero is the identity.  A spatially
  * coherent order (the Python host writes the Morton order of the input hand) lets the 64 lanes of a wave skip the same runs
  * of candidates; any PERMUTATION of [0, Vh) gives identical results.  Rewrite it after the workspace is re-allocated. */
 enum {
@@ -198,10 +212,8 @@ enum {
 size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
 int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
-/* One step (or the prefix of it that stage_mask names) on `stream`, asynchronously.  Environment, read at every call (i.e. when
- * a graph is captured): FOHO_LISTED_CAP -- how the resolve pass finds its tiles: unset = one workgroup per 32x8 tile of the frame
- * below eight images per launch, a compacted list of the tiles that need work from eight on; 0 = always the former, n > 0 =
- * always the latter with n workgroups per (render, image).  Same results either way. */
+/* One step (or the prefix of it that stage_mask names) on `stream`, asynchronously.  Everything that shapes the launches is in
+ * desc / cfg (cfg->listed_cap: how the resolve pass finds its tiles); the process environment is not consulted. */
 int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
 /* Applies the update a deferred_update step left pending (no-op per image when nothing is pending): one small launch;
  * cfg->deferred_update must carry the number of the LAST step run. */

@@ -1,5 +1,5 @@
 """Close-up frames (narrow field of view: hand and object fill the crop, like a cropped hand-object image) at 32 images in flight:
-phase C with k_resolve dense (FOHO_LISTED_CAP=0) and listed (default from eight images per launch on).  Usage: dev_closeup.py [fov ...]"""
+phase C with k_resolve dense (listed_cap = -1) and listed (default from eight images per launch on).  Usage: dev_closeup.py [fov ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -9,13 +9,10 @@ rf = E.hip_render_fn("cuda")
 ident = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0] * 2, dtype=torch.float32, device="cuda")
 for fov in [float(a) for a in sys.argv[1:]] or [60.0, 30.0, 22.0]:
     scenes = [synthetic.build_scene(rf, obj_kind="20k", H=512, W=512, fov=fov, seed=100 + j) for j in range(32)]
-    for mode in ("0", None):
-        if mode is None:
-            os.environ.pop("FOHO_LISTED_CAP", None)
-        else:
-            os.environ["FOHO_LISTED_CAP"] = mode
+    for mode in (-1, 0):
         group = E.GuidanceGroup(scenes, 4, device="cuda")
         cfg, nr = E.phase_cfg("C", denoise_i=19, do_update=True)
+        cfg.listed_cap = mode
         group.capture(cfg, steps_per_graph=50)
         ts = []
         for rep in range(5):

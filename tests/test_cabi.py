@@ -78,14 +78,19 @@ def test_host_only_queries_work_without_a_gpu(lib):
     assert lib.foho_topology_tables(None, 10, 10, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1
 
 
-def test_struct_layouts_match_the_header():
+def test_struct_layouts_match_the_header(lib):
     """ctypes mirrors must have the C sizes (4-byte fields, 8-byte pointers, natural alignment)."""
     from followmyhold_amd import _lib as L
     assert ctypes.sizeof(L.FohoImage) == 8 * 4 + 2 * 4 + 9 * 4 + 3 * 4 + 2 * 4 + 12 * 4
     assert ctypes.sizeof(L.FohoDims) == 15 * 4
     assert ctypes.sizeof(L.FohoRenderCfg) == 7 * 4
-    assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4 + 4
-    assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8
+    assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4 + 4 + 4
+    assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8 + 8          # hand_order_valid + tail padding
+    # ... and the library this binding loads was built from the same layout (the check _lib.lib() makes at load time)
+    sizes = (ctypes.c_int64 * 5)()
+    lib.foho_abi_sizes.restype = ctypes.c_int
+    assert lib.foho_abi_sizes(sizes) == lib.foho_version() == L.ABI_VERSION
+    assert list(sizes) == [ctypes.sizeof(t) for t in (L.FohoImage, L.FohoDims, L.FohoRenderCfg, L.FohoStepCfg, L.FohoStepDesc)]
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -432,19 +432,19 @@ def test_k100_buffer_is_rebuilt_where_the_all_fragment_product_would_differ():
 
 @gpu
 @pytest.mark.parametrize("cap", [1, 5, 64])
-def test_listed_resolve_equals_the_dense_launch(cap, monkeypatch):
+def test_listed_resolve_equals_the_dense_launch(cap):
     """Batches of eight images and more launch k_resolve over a LIST of the tiles that need work (k_tile_list) instead of over
     every tile of the frame, `cap` workgroups per (render, image), and k_resolve_ovf takes the entries beyond them.  Forced
-    here on a two-image batch through FOHO_LISTED_CAP with caps far below the number of active tiles (1, 5: nearly everything
+    here on a two-image batch through foho_step_cfg.listed_cap with caps far below the number of active tiles (1, 5: nearly everything
     goes through the overflow kernel) and above it (64): the G-buffer of the first step must be the dense launch's
-    (FOHO_LISTED_CAP=0) bit for bit, losses and parameters of three optimiser steps the same up to the order of the gradient atomics."""
+    (listed_cap = -1) bit for bit, losses and parameters of three optimiser steps the same up to the order of the gradient atomics."""
     from followmyhold_amd import engine as E
     scenes = [_np_scene(make_scene("ico2", 96, 160, seed=s)) for s in (3, 5)]
 
-    def run(env):
-        monkeypatch.setenv("FOHO_LISTED_CAP", env)
+    def run(listed_cap):
         gb = E.GuidanceBatch(scenes, grid_res=16)
         cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+        cfg.listed_cap = listed_cap
         out = []
         for _ in range(3):
             gb.step(cfg)
@@ -457,7 +457,7 @@ def test_listed_resolve_equals_the_dense_launch(cap, monkeypatch):
                             loss=[gb.loss_dict(b)["total"] for b in range(2)], params=gb.params.cpu().numpy().copy()))
         return out
 
-    dense, listed = run("0"), run(str(cap))
+    dense, listed = run(-1), run(cap)
     # first step: same parameters on both sides, so every plane is the same bit for bit
     d, l = dense[0], listed[0]
     assert np.array_equal(d["p2f"], l["p2f"])

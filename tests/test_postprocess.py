@@ -7,6 +7,12 @@ import pytest
 from followmyhold_amd import postprocess as PP, synthetic
 
 
+# The decimator is host C++ inside libfoho_hip.so (csrc/mesh_decimate.inc).  Every test of this module therefore runs twice:
+# in the CPU suite, and -- as the instance marked `gpu` -- on the MI355X box, so that the host code of the library that
+# ships is exercised there too (same assertions; no device work).
+where = pytest.mark.parametrize("where", ["cpu_suite", pytest.param("gpu_box", marks=pytest.mark.gpu)])
+
+
 def _edge_counts(f):
     e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
     _, c = np.unique(e, axis=0, return_counts=True)
@@ -45,7 +51,8 @@ def _box(n):
     return np.array(verts, np.float32), np.array(faces, np.int64)
 
 
-def test_decimation_of_a_sphere_stays_a_closed_oriented_sphere():
+@where
+def test_decimation_of_a_sphere_stays_a_closed_oriented_sphere(where):
     v, f = synthetic.icosphere(5, 1.0)                      # 20480 faces
     ov, of = PP.decimate(v, f, 2000)
     assert len(of) <= 2000 and len(of) >= 1990
@@ -62,7 +69,8 @@ def test_decimation_of_a_sphere_stays_a_closed_oriented_sphere():
     assert len(tf) >= 4 and (_edge_counts(tf) == 2).all()
 
 
-def test_decimation_keeps_planar_regions_and_sharp_edges_exact():
+@where
+def test_decimation_keeps_planar_regions_and_sharp_edges_exact(where):
     """Quadric error is zero for collapses inside a plane or along a crease: a finely tessellated box decimates to a
     coarse box with the same volume and corners."""
     v, f = _box(12)                                         # 1728 faces
@@ -75,7 +83,8 @@ def test_decimation_keeps_planar_regions_and_sharp_edges_exact():
     assert ov.min() > -1e-5 and ov.max() < 1 + 1e-5
 
 
-def test_decimation_preserves_an_open_boundary():
+@where
+def test_decimation_preserves_an_open_boundary(where):
     n = 24
     ys, xs = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
     z = 0.05 * np.sin(xs / n * 6.0) * np.cos(ys / n * 5.0)
@@ -92,7 +101,8 @@ def test_decimation_preserves_an_open_boundary():
     assert (np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])[:, 2] > 0).all()          # no flipped triangle
 
 
-def test_floater_and_degenerate_removal_and_the_reference_chain(tmp_path):
+@where
+def test_floater_and_degenerate_removal_and_the_reference_chain(where, tmp_path):
     v, f = synthetic.icosphere(4, 1.0)                      # 5120 faces
     sv, sf = synthetic.icosphere(0, 0.05)                   # 20-face floater = 0.39 % of the big component
     mv, mf = synthetic.icosphere(1, 0.2)                    # 80 faces = 1.6 %: stays
@@ -119,7 +129,8 @@ def test_floater_and_degenerate_removal_and_the_reference_chain(tmp_path):
         PP.decimate(verts, np.array([[0, 1, 10 ** 6]]), 10)
 
 
-def test_decimator_against_an_independent_bruteforce_qem():
+@where
+def test_decimator_against_an_independent_bruteforce_qem(where):
     """foho_mesh_decimate (lazy-deletion heap, time stamps) against oracle/decimate_ref.py, which recomputes the cost of
     EVERY edge before every collapse and takes the cheapest admissible one.  On a smooth closed mesh no candidate is ever
     rejected, the two orders of collapses coincide and the results are IDENTICAL; on a noisy open surface (rejections, the
