@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   job                 the 750-iteration per-image job through the product entry point's engine at 1 / 8 / 16 images in flight
   driver_on_files     foho.guidance.run.run() on scene folders in the reference's file formats, wall time per image
   topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
+  geo_decode          the ShapeVAE geometry decoder of latent2sdf (65^3 queries x 3072 tokens) on the matrix cores vs torch
 """
 import argparse
 import json
@@ -395,6 +396,7 @@ def main():
                             ("topology_changing", lambda: topology_record(E, torch, scenes[0], dev)),
                             ("closeup", lambda: closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
+                            ("geo_decode", lambda: geo_decode_record(torch, dev)),
                             ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
                             ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
                 try:
@@ -522,6 +524,60 @@ def closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg, steps=500
             rec["kernel_us"] = {k: round(v * 1e3, 2) for k, v in acc.items()}
         del group
     return rec
+
+
+def geo_decode_record(torch, dev, res=64, reps=5):
+    """SURVEY 8(f) rank 1, first half: the geometry decoder of latent2sdf (PL:292-313) at the Hunyuan3D-2 shape -- 3072 x 1024
+    latent tokens, 16 heads, hidden 4096, (res+1)^3 = 274 625 query points -- forward, fp16: `foho_geo_decode_fwd` (one call,
+    hand-written MFMA kernels) beside the torch module run the reference's way (35 chunks of 8000 queries through hipBLASLt /
+    SDPA).  Random-initialised stand-in of that shape (no Hunyuan weights on this box); bound: the fp16 matrix peak."""
+    import math
+    from followmyhold_amd import standins
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    W, NH, NL, F = 1024, 16, 3072, 4096
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=NL, embed_dim=64, width=W, heads=NH, layers=1, num_freqs=8)
+    dec = vae.geo_decoder.to(dev).eval()
+    n = (res + 1) ** 3
+    axes = torch.linspace(-1.1, 1.1, res + 1)
+    xyz = torch.stack(torch.meshgrid(axes, axes, axes, indexing="ij"), -1).reshape(-1, 3).to(dev)
+    lat = torch.randn(1, NL, W, device=dev).half()
+    flop_q = 2 * 64 * W + 2 * W * W + 4 * NL * W + 2 * W * W + 4 * W * F + 2 * W
+    flops = n * flop_q + NL * (2 * W * 2 * W)
+    hip = HipGeoDecoder.from_module(dec, device=dev)
+    q32 = xyz.half().float().unsqueeze(0)
+    out = hip(q32, lat)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        hip._prepared = None                       # K / V projection of the tokens is part of every decode
+        t0 = time.perf_counter()
+        out = hip(q32, lat)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t_hip = min(ts)
+    dech = vae.geo_decoder.half()
+    def torch_decode():
+        outs = []
+        with torch.no_grad():
+            for s0 in range(0, n, 8000):
+                outs.append(dech(xyz[s0:s0 + 8000].half().unsqueeze(0), lat))
+        return torch.cat(outs, 1)
+    ref = torch_decode()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref = torch_decode()
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t_torch = min(ts)
+    err = (out.float() - ref.float()).abs().max().item()
+    return {"queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
+            "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops / 1e12,
+            "tflops": flops / t_hip / 1e12, "roofline": {"bound": "mfma", "achieved": flops / t_hip / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                                          "frac": flops / t_hip / 1e12 / 2500.0},
+            "max_abs_diff_vs_torch_fp16": err, "logit_scale": ref.float().abs().max().item(), "backward": "not implemented (torch autograd)"}
 
 
 def obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg, steps=1000):

@@ -1,0 +1,611 @@
+// foho_geo.hip -- the ShapeVAE geometry decoder of `latent2sdf` on the MI355X matrix cores.
+//
+// Reference: third_party_patches/hy3dgen/shapegen/pipelines.py:292-313 -- every inner iteration of phases B and C decodes
+// the current clean-sample estimate into a 65^3 occupancy grid: 35 chunks x 8000 queries through `vae.geo_decoder`
+// (Fourier embedding -> query projection -> ONE cross-attention block over the 3072 x 1024 latent tokens, 16 heads of
+// 64 -> MLP 1024 -> 4096 -> 1024 -> LayerNorm -> logit).  33.7 MFLOP per query, 9.25 TFLOP per grid: the one place on the
+// path where the matrix cores decide the time.
+//
+// Design for gfx950:
+//   * fp16 storage, fp32 accumulation on v_mfma_f32_32x32x16_f16 (the reference runs the VAE in fp16, PL:522).
+//   * the 8000-query chunks are gone: one call decodes all queries, in row blocks sized so that the block's activations
+//     (14.5 KB per query) stay inside the 256 MB Infinity Cache between the kernels of the chain.
+//   * K and V of the latent tokens are projected once per call; V is kept TRANSPOSED and key-permuted so that both
+//     operands of P.V are 16-byte contiguous fragments (no LDS transpose, no cross-lane exchange of P).
+//   * attention: swapped QK^T (S^T = K Q^T) puts a query's scores in ONE lane column -> row max / row sum are in-lane
+//     v_max3 / adds plus one exchange between the two half-waves; softmax scale and log2(e) are folded into Q;
+//     the running max is only raised when a tile exceeds it by more than 2^6 (deferred rescale).
+//   * GEMMs: 128 x 128 x 64 tiles, 4 waves x (64 x 64), operands staged by LDS-DMA (global_load_lds_dwordx4) into a
+//     double-buffered, XOR-swizzled image (swizzle applied on the SOURCE address, the DMA's destination is lane-linear),
+//     conflict-free ds_read_b128 fragments; bias / GELU / softmax scale / residual fused into the epilogue, which goes
+//     through LDS so that global stores are whole 128-byte row segments.
+//   * XCD-aware block order everywhere (workgroup L runs on XCD L mod 8; K/V of two heads or the weight panel of a GEMM
+//     stay in that XCD's 4 MB L2).
+//
+// Translation unit of its own: compiled WITHOUT -ffp-contract=off / correctly rounded division (nothing here decides a
+// face index), linked into libfoho_hip.so next to foho_step.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <stdio.h>
+#include <algorithm>
+
+#include "../../include/foho_hip.h"
+
+namespace geo {
+
+typedef _Float16 h16;
+typedef h16 half8 __attribute__((ext_vector_type(8)));
+typedef h16 half4 __attribute__((ext_vector_type(4)));
+typedef h16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+thread_local char g_err[256] = "";
+static int fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+// 16-byte chunk `c` of row `row` of a [rows][64 halfs] LDS tile (128-byte rows) lives in slot c ^ swz(row): the 32 rows x
+// 2 chunks a 32x32x16 fragment read touches then fall on 16 distinct 16-byte bank groups within each of ds_read_b128's
+// lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (and their upper-half twins) -- conflict-free.
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]),  fp16 in / fp32 accumulate / fp16 out.
+// N % 128 == 0, K % 64 == 0, all leading dimensions multiples of 8 halfs (16-byte rows).
+// ------------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128, GK = 64;
+constexpr int EP_GELU = 1, EP_RESID = 2;
+constexpr int CPAD = 72;  // halfs per row of the epilogue's LDS image (64 + 8: keeps 16-byte alignment, spreads banks)
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+template <int EP>
+__global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
+                                                     const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
+                                                     h16* __restrict__ C, int ldc, int M, int N, int K, float scale) {
+    __shared__ uint4 lds[2][2][GM * GK * 2 / 16];  // [buffer][A | W][128 rows x 8 chunks] = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    // XCD-aware tile order: the blocks of one XCD (L mod 8) sweep N inside one row panel of A, eight panels (one per XCD) at a time
+    const int ntn = N / GN, ntm = (M + GM - 1) / GM;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mp = (j / ntn) * 8 + xcd, nt = j % ntn;
+    if (mp >= ntm) return;
+    const int m0 = mp * GM, n0 = nt * GN;
+    const int wr = w >> 1, wc = w & 1;  // this wave's 64 x 64 part of the tile
+
+    // staging: a wave moves pieces w*4 .. w*4+3 (8 rows x 128 B each) of both operands per K-tile
+    const int srow = lane >> 3, sslot = lane & 7;
+    const h16* asrc[4];
+    const h16* wsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int row = (w * 4 + p) * 8 + srow;
+        const int c = sslot ^ swz(row);
+        asrc[p] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        wsrc[p] = Wt + (size_t)(n0 + row) * ldw + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            glds16(asrc[p] + k0, &lds[buf][0][(w * 4 + p) * 64]);
+            glds16(wsrc[p] + k0, &lds[buf][1][(w * 4 + p) * 64]);
+        }
+    };
+
+    f32x16 acc[2][2];  // [n tile][m tile]: D rows = n, D columns = m (the lane holds 4 consecutive n for one m)
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const int nk = K / GK;
+    stage(0, 0);
+    for (int t = 0; t < nk; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile t has landed for every wave, and everybody is done with the other buffer
+        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * GK);
+        const uint4* la = lds[t & 1][0];
+        const uint4* lw = lds[t & 1][1];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            half8 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int ra = wr * 64 + i * 32 + l31, rw = wc * 64 + i * 32 + l31;
+                const uint4 ua = la[ra * 8 + ((2 * kk + hi) ^ swz(ra))];
+                const uint4 uw = lw[rw * 8 + ((2 * kk + hi) ^ swz(rw))];
+                fa[i] = *reinterpret_cast<const half8*>(&ua);
+                fw[i] = *reinterpret_cast<const half8*>(&uw);
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[jn], fa[i], acc[jn][i], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the staging buffers: they become the epilogue's transpose image
+
+    // ---- epilogue: bias / GELU / scale in fp32, round to fp16, through LDS to whole-row stores (+ residual)
+    h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int nl = jn * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns (within the wave's 64)
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + nl);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                half4 o;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float v = acc[jn][i][4 * g + q] + b4[q];
+                    if (EP & EP_GELU) v = gelu_erf(v);
+                    v *= scale;
+                    o[q] = (h16)v;
+                }
+                *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is wave-private: no barrier, only this wave's own writes
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int ml = q * 8 + (lane >> 3), ch = lane & 7;
+        const int gm = m0 + wr * 64 + ml, gn = n0 + wc * 64 + ch * 8;
+        half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
+        if (gm < M) {
+            if (EP & EP_RESID) {
+                const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] + (float)r[e]);
+            }
+            *reinterpret_cast<half8*>(C + (size_t)gm * ldc + gn) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross attention, head dimension 64: O[M, heads*64] = softmax(Q K^T) V per head, Q pre-scaled by log2(e)/sqrt(64).
+// K rows: Kp + l * ldk + head * 64 (the K half of the KV projection, as the GEMM left it); V: Vt[head][d][pos(l)],
+// transposed, with the keys of every 16-block stored in the order the P fragment holds them (pack_vt below).
+// Workgroup = 4 waves x 64 queries of ONE head; 64-key tiles double-buffered in LDS (register staging: the loads for
+// tile t+1 are issued before tile t is computed and written to LDS after it).
+// ------------------------------------------------------------------------------------------------
+constexpr int AQ = 256, AK = 64;
+constexpr float RESCALE_THR = 6.0f;  // log2 domain: P <= 2^6 while the running max lags behind
+
+__device__ __forceinline__ float other_half(float x) { return __shfl_xor(x, 32); }
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+__global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
+                                                     const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
+                                                     int heads) {
+    __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    int head, qblk;
+    if ((heads & 7) == 0) {  // an XCD (block id mod 8) keeps heads/8 heads: their K and V stay in its L2
+        const int hpx = heads >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        head = xcd * hpx + j % hpx;
+        qblk = j / hpx;
+    } else {
+        head = blockIdx.x % heads;
+        qblk = blockIdx.x / heads;
+    }
+    const int q0 = qblk * AQ + w * 64;
+
+    half8 qf[2][4];  // B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16 kk + 8 hi .. + 7]
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const int row = min(q0 + qb * 32 + l31, M - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) qf[qb][kk] = *reinterpret_cast<const half8*>(Q + (size_t)row * ldq + head * 64 + 16 * kk + 8 * hi);
+    }
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const h16* kg = Kp + (size_t)srow * ldk + head * 64 + sch * 8;
+    const h16* vg = Vt + ((size_t)head * 64 + srow) * L + sch * 8;
+    uint4 st[4];
+    auto gload = [&](int t) {
+        st[0] = *reinterpret_cast<const uint4*>(kg + (size_t)(t * AK) * ldk);
+        st[1] = *reinterpret_cast<const uint4*>(kg + (size_t)(t * AK + 32) * ldk);
+        st[2] = *reinterpret_cast<const uint4*>(vg + t * AK);
+        st[3] = *reinterpret_cast<const uint4*>(vg + (size_t)32 * L + t * AK);
+    };
+    const int sidx = srow * 8 + (sch ^ swz(srow));  // rows srow and srow + 32 share the swizzle
+    auto lwrite = [&](int buf) {
+        lds[buf][0][sidx] = st[0];
+        lds[buf][0][sidx + 256] = st[1];
+        lds[buf][1][sidx] = st[2];
+        lds[buf][1][sidx + 256] = st[3];
+    };
+
+    f32x16 o[2][2];  // [query block][d tile]: O^T, rows d, columns q
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[a][b][r] = 0.0f;
+    float mrun[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.0f, 0.0f};
+
+    const int nt = L / AK;
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int t = 0; t < nt; t++) {
+        if (t + 1 < nt) gload(t + 1);
+        const uint4* lk = lds[t & 1][0];
+        const uint4* lv = lds[t & 1][1];
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            // ---- S^T (32 keys x 32 queries per query block) = K Q^T
+            half8 kf[4];
+            const int krow = sub * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint4 u = lk[krow * 8 + ((2 * kk + hi) ^ swz(krow))];
+                kf[kk] = *reinterpret_cast<const half8*>(&u);
+            }
+            f32x16 s[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[qb][r] = 0.0f;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], s[qb], 0, 0, 0);
+            }
+            // ---- V^T fragments of this sub-tile: A operand, rows d, 16 keys per MFMA
+            half8 vf[2][2];
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) {
+                const int vrow = dt * 32 + l31;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const uint4 u = lv[vrow * 8 + ((4 * sub + 2 * k2 + hi) ^ swz(vrow))];
+                    vf[dt][k2] = *reinterpret_cast<const half8*>(&u);
+                }
+            }
+            // ---- online softmax in the log2 domain; a query's 32 scores sit in two lanes (l31, hi = 0 / 1), 16 registers each
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++) {
+                float tm = max3(s[qb][0], s[qb][1], s[qb][2]);
+                tm = max3(tm, s[qb][3], s[qb][4]);
+                tm = max3(tm, s[qb][5], s[qb][6]);
+                tm = max3(tm, s[qb][7], s[qb][8]);
+                tm = max3(tm, s[qb][9], s[qb][10]);
+                tm = max3(tm, s[qb][11], s[qb][12]);
+                tm = max3(tm, s[qb][13], s[qb][14]);
+                tm = fmaxf(tm, s[qb][15]);
+                tm = fmaxf(tm, other_half(tm));
+                if (__any(tm > mrun[qb] + RESCALE_THR)) {  // rare after the first tiles: raise the running max, rescale what is accumulated
+                    const float mn = fmaxf(mrun[qb], tm);
+                    const float alpha = exp2f(mrun[qb] - mn);
+                    mrun[qb] = mn;
+                    lsum[qb] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) o[qb][dt][r] *= alpha;
+                }
+                half8 pf[2];
+                float ls = 0.0f;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float p0 = exp2f(s[qb][8 * k2 + e] - mrun[qb]), p1 = exp2f(s[qb][8 * k2 + e + 1] - mrun[qb]);
+                        ls += p0 + p1;
+                        const f32x2 pp = {p0, p1};
+                        const half2v ph = __builtin_convertvector(pp, half2v);
+                        pf[k2][e] = ph[0];
+                        pf[k2][e + 1] = ph[1];
+                    }
+                lsum[qb] += ls;
+                // ---- O^T += V^T P^T
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) lwrite((t + 1) & 1);  // that buffer was last read in iteration t - 1, before the barrier every wave passed
+        __syncthreads();
+    }
+    // ---- normalise and store: the lane holds, for ONE query, d = 32 dt + 8 g + 4 hi + (0..3)
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const float lt = lsum[qb] + other_half(lsum[qb]);
+        const float inv = 1.0f / lt;
+        const int row = q0 + qb * 32 + l31;
+        if (row < M) {
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    half4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (h16)(o[qb][dt][4 * g + e] * inv);
+                    *reinterpret_cast<half4*>(O + (size_t)row * ldo + head * 64 + dt * 32 + 8 * g + 4 * hi) = v;
+                }
+        }
+    }
+}
+
+// V half of the KV projection (L rows, row stride ldkv, columns width + head*64 + d) -> Vt[head][d][pos(l)]: within every
+// block of 16 keys, key kq goes to position (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1) (keys 4-7 and 8-11 swap places):
+// the order in which a lane of the P^T fragment holds its 8 keys (C layout of the 32x32 MFMA: rows (r & 3) + 8 (r >> 2) + 4 hi).
+__global__ void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt) {
+    const int c = blockIdx.x * 256 + threadIdx.x;  // head * 64 + d
+    const int l = blockIdx.y;
+    if (c >= width) return;
+    const int kq = l & 15, pos = (l & ~15) | (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1);
+    Vt[(size_t)c * L + pos] = KV[(size_t)l * ldkv + width + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows of `width` <= 1024 halfs (one wave per row, fp32 statistics like torch's fp16 LayerNorm).
+// MODE 0: Y = LN(X) gamma + beta (fp16).  MODE 1: logits[row] = prior(query) + gain * (LN(X) gamma + beta) . w_out + b_out.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_geo_ln(const h16* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, h16* __restrict__ Y, int ldy, int M, int width,
+                                                float eps, const float* __restrict__ w_out, float b_out, const float* __restrict__ queries,
+                                                float radius, float sharpness, float gain, float* __restrict__ logits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[2][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < width) {
+            const half8 h = *reinterpret_cast<const half8*>(X + (size_t)row * ldx + col);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[c][e] = (float)h[e];
+                sum += v[c][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[c][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)width;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        if ((c * 64 + lane) * 8 < width)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float d = v[c][e] - mean;
+                sq += d * d;
+            }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq / (float)width + eps);
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < width) {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float y = (v[c][e] - mean) * rstd * gamma[col + e] + beta[col + e];
+                h[e] = (h16)y;
+                if (MODE == 1) dot += (float)h[e] * w_out[col + e];  // the reference's LayerNorm output is fp16 before the last Linear
+            }
+            if (MODE == 0) *reinterpret_cast<half8*>(Y + (size_t)row * ldy + col) = h;
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        if (lane == 0) {
+            float learned = (float)(h16)(dot + b_out);
+            float prior = 0.0f;
+            if (sharpness != 0.0f) {
+                const float x = queries[3 * (size_t)row], y = queries[3 * (size_t)row + 1], z = queries[3 * (size_t)row + 2];
+                prior = (radius - sqrtf(x * x + y * y + z * z)) * sharpness;
+            }
+            logits[row] = prior + gain * learned;
+        }
+    }
+}
+
+// Fourier embedding of the query points, [x, sin(x f_j), cos(x f_j)] flattened as (coordinate, frequency) like the
+// reference's FourierEmbedder, rounded to fp16 and zero-padded to 64 columns (the K of the query projection GEMM).
+__global__ __launch_bounds__(256) void k_geo_embed(const float* __restrict__ queries, int M, int n_freqs, const float* __restrict__ freqs,
+                                                   h16* __restrict__ E) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid >> 3, ch = gid & 7;
+    if (row >= M) return;
+    const float p[3] = {queries[3 * (size_t)row], queries[3 * (size_t)row + 1], queries[3 * (size_t)row + 2]};
+    const int nf3 = 3 * n_freqs;
+    half8 out;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int col = ch * 8 + e;
+        float v = 0.0f;
+        if (col < 3) v = p[col];
+        else if (col < 3 + nf3) {
+            const int i = col - 3;
+            v = sinf(p[i / n_freqs] * freqs[i % n_freqs]);
+        } else if (col < 3 + 2 * nf3) {
+            const int i = col - 3 - nf3;
+            v = cosf(p[i / n_freqs] * freqs[i % n_freqs]);
+        }
+        out[e] = (h16)v;
+    }
+    *reinterpret_cast<half8*>(E + (size_t)row * 64 + ch * 8) = out;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static bool launch_ok(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
+static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
+                int N, int K, float scale, hipStream_t s) {
+    if (M <= 0) return FOHO_OK;
+    if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
+    const int ntn = N / GN, ntm = (M + GM - 1) / GM;
+    const dim3 grid(8 * ((ntm + 7) / 8) * ntn), block(256);
+    switch (ep) {
+        case 0: hipLaunchKernelGGL(k_geo_gemm<0>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+        case EP_GELU: hipLaunchKernelGGL(k_geo_gemm<EP_GELU>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+        case EP_RESID: hipLaunchKernelGGL(k_geo_gemm<EP_RESID>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+        default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
+    }
+    return launch_ok("k_geo_gemm") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+static int check_weights(const foho_geo_weights* w) {
+    if (!w) return fail(FOHO_ERR_BAD_ARG, "foho_geo: null weights");
+    if (w->width <= 0 || w->width % 128 || w->width > 1024) return fail(FOHO_ERR_BAD_ARG, "foho_geo: width must be a multiple of 128, at most 1024");
+    if (w->heads <= 0 || w->width != w->heads * 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo: head dimension must be 64");
+    if (w->n_latents <= 0 || w->n_latents % 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo: n_latents must be a multiple of 64");
+    if (w->hidden <= 0 || w->hidden % 128) return fail(FOHO_ERR_BAD_ARG, "foho_geo: hidden must be a multiple of 128");
+    if (w->n_freqs < 0 || w->n_freqs > 10) return fail(FOHO_ERR_BAD_ARG, "foho_geo: 3 (2 n_freqs + 1) must fit 64 columns");
+    if (!w->w_qproj || !w->b_qproj || !w->w_q || !w->b_q || !w->w_kv || !w->b_kv || !w->w_proj || !w->b_proj || !w->w_fc1 || !w->b_fc1 ||
+        !w->w_fc2 || !w->b_fc2 || !w->w_out || !w->ln_q_g || !w->ln_q_b || !w->ln_kv_g || !w->ln_kv_b || !w->ln_2_g || !w->ln_2_b ||
+        !w->ln_post_g || !w->ln_post_b || !w->freqs)
+        return fail(FOHO_ERR_BAD_ARG, "foho_geo: null weight pointer");
+    return FOHO_OK;
+}
+
+struct Layout {
+    size_t kv, vt, e, a, b, c, h, total;
+};
+static Layout layout(const foho_geo_weights* w, int chunk) {
+    Layout l{};
+    size_t off = 0;
+    auto take = [&](size_t halfs) {
+        const size_t o = off;
+        off += (halfs * 2 + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t W = w->width, Lr = w->n_latents, rows = std::max<size_t>(chunk, Lr);  // the prepare step normalises the latents in buffer A
+    l.kv = take(Lr * 2 * W);
+    l.vt = take(W * Lr);
+    l.e = take((size_t)chunk * 64);
+    l.a = take(rows * W);
+    l.b = take((size_t)chunk * W);
+    l.c = take((size_t)chunk * W);
+    l.h = take((size_t)chunk * w->hidden);
+    l.total = off;
+    return l;
+}
+
+}  // namespace geo
+
+using namespace geo;
+
+extern "C" const char* foho_geo_last_error(void) { return g_err; }
+
+extern "C" size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows) {
+    if (check_weights(w) != FOHO_OK || chunk_rows <= 0) return 0;
+    return layout(w, chunk_rows).total;
+}
+
+extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chunk_rows, void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!latents || !ws || chunk_rows <= 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_prepare: null argument");
+    const Layout l = layout(w, chunk_rows);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_prepare: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    char* base = (char*)ws;
+    h16 *kv = (h16*)(base + l.kv), *vt = (h16*)(base + l.vt), *ln = (h16*)(base + l.a);
+    const int W = w->width, Lr = w->n_latents;
+    hipLaunchKernelGGL(k_geo_ln<0>, dim3((Lr + 3) / 4), dim3(256), 0, s, (const h16*)latents, W, w->ln_kv_g, w->ln_kv_b, ln, W, Lr, W, w->ln_eps,
+                       (const float*)nullptr, 0.0f, (const float*)nullptr, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+    if (!launch_ok("k_geo_ln(kv)")) return FOHO_ERR_LAUNCH;
+    if (int rc = gemm(0, ln, W, (const h16*)w->w_kv, W, w->b_kv, nullptr, 0, kv, 2 * W, Lr, 2 * W, W, 1.0f, s)) return rc;
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
+    return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
+                                   void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!queries || !logits || !ws || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_fwd: null argument");
+    const Layout l = layout(w, chunk_rows);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    char* base = (char*)ws;
+    const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
+    h16 *E = (h16*)(base + l.e), *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
+    const int W = w->width, Lr = w->n_latents, F = w->hidden;
+    const float qscale = 1.4426950408889634f * 0.125f;  // log2(e) / sqrt(64): the attention kernel exponentiates with exp2
+    const float* nof = nullptr;
+    for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
+        const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
+        const float* q = queries + 3 * r0;
+        hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), dim3(256), 0, s, q, M, w->n_freqs, w->freqs, E);
+        if (!launch_ok("k_geo_embed")) return FOHO_ERR_LAUNCH;
+        // x0 = query_proj(embed)                                                     -> A
+        if (int rc = gemm(0, E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, bA, W, M, W, 64, 1.0f, s)) return rc;
+        // q = c_q(ln_q(x0)) * log2(e) / 8                                             B -> C
+        hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_q_g, w->ln_q_b, bB, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f,
+                           0.0f, (float*)nullptr);
+        if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
+        if (int rc = gemm(0, bB, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, bC, W, M, W, W, qscale, s)) return rc;
+        // attention over the latent tokens                                           C -> B
+        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
+        if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
+        // x1 = x0 + c_proj(attn)                                                      B (+A) -> C
+        if (int rc = gemm(EP_RESID, bB, W, (const h16*)w->w_proj, W, w->b_proj, bA, W, bC, W, M, W, W, 1.0f, s)) return rc;
+        // x2 = x1 + fc2(gelu(fc1(ln_2(x1))))                                          C -> B -> H -> A
+        hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, bC, W, w->ln_2_g, w->ln_2_b, bB, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f,
+                           0.0f, (float*)nullptr);
+        if (!launch_ok("k_geo_ln(2)")) return FOHO_ERR_LAUNCH;
+        if (int rc = gemm(EP_GELU, bB, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, bH, F, M, F, W, 1.0f, s)) return rc;
+        if (int rc = gemm(EP_RESID, bH, F, (const h16*)w->w_fc2, F, w->b_fc2, bC, W, bA, W, M, W, F, 1.0f, s)) return rc;
+        // logits = output_proj(ln_post(x2)) (+ the stand-in's analytic prior)
+        hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, W, w->ln_eps, w->w_out,
+                           w->b_out, q, w->prior_radius, w->prior_sharpness, w->out_gain, logits + r0);
+        if (!launch_ok("k_geo_ln(post)")) return FOHO_ERR_LAUNCH;
+    }
+    return FOHO_OK;
+}
+
+// Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
+extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
+                             int32_t gelu, float scale, void* stream) {
+    if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
+    if (gelu && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
+    return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
+                (hipStream_t)stream);
+}
+
+extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
+                                  void* stream) {
+    if (!Q || !KV || !Vt_scratch || !O || heads <= 0 || n_latents <= 0 || n_latents % 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo_attention: bad argument");
+    const int W = heads * 64;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
+    if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
+    if (M <= 0) return FOHO_OK;
+    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
+                       n_latents, (h16*)O, W, M, heads);
+    return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}

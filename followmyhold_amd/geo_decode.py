@@ -1,0 +1,156 @@
+"""The ShapeVAE geometry decoder of `latent2sdf` on the MI355X matrix cores (`foho_geo_decode_fwd`, csrc/foho_geo.hip).
+
+Reference: third_party_patches/hy3dgen/shapegen/pipelines.py:298-308 -- 35 chunks of 8000 grid points through
+`vae.geo_decoder(queries, latents)` per decode of a 65^3 grid (hy3dgen's CrossAttentionDecoder: Fourier embedding,
+query projection, one cross-attention block over the latent tokens, MLP, LayerNorm, one logit per point).  Here one call
+decodes all points.  FORWARD ONLY in this version: `pipeline.latent2sdf` uses it where the reference decodes without
+gradients (the per-step clean-sample decode PL:1614-1662, 385^3 points on the last step) and keeps the torch modules
+where autograd has to reach the latent (PL:1391-1393, 1507-1509).
+
+    dec = HipGeoDecoder.from_module(vae.geo_decoder)         # weights packed once (fp16 matrices, fp32 vectors)
+    logits = dec(queries (1, N, 3), latents (1, L, width))    # (1, N, 1), dtype of the latents -- the module's signature
+
+There is no CPU path: the constructor raises when the module's shape is outside what the kernels take (head dimension
+64, width % 128 == 0 and <= 1024, n_latents % 64 == 0, hidden % 128 == 0).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+class FohoGeoWeights(ctypes.Structure):
+    _fields_ = [("width", L.c_i), ("heads", L.c_i), ("n_latents", L.c_i), ("hidden", L.c_i), ("n_freqs", L.c_i), ("reserved", L.c_i),
+                ("freqs", L.vp), ("w_qproj", L.vp), ("b_qproj", L.vp), ("ln_q_g", L.vp), ("ln_q_b", L.vp), ("ln_kv_g", L.vp),
+                ("ln_kv_b", L.vp), ("w_q", L.vp), ("b_q", L.vp), ("w_kv", L.vp), ("b_kv", L.vp), ("w_proj", L.vp), ("b_proj", L.vp),
+                ("ln_2_g", L.vp), ("ln_2_b", L.vp), ("w_fc1", L.vp), ("b_fc1", L.vp), ("w_fc2", L.vp), ("b_fc2", L.vp),
+                ("ln_post_g", L.vp), ("ln_post_b", L.vp), ("w_out", L.vp), ("b_out", L.c_f), ("ln_eps", L.c_f),
+                ("prior_radius", L.c_f), ("prior_sharpness", L.c_f), ("out_gain", L.c_f)]
+
+
+def _bias(lin, n, device):
+    return (lin.bias.detach() if lin.bias is not None else torch.zeros(n)).to(device=device, dtype=torch.float32).contiguous()
+
+
+def _parts(m):
+    """The pieces of a geometry decoder module by role: the stand-in (`standins._GeoDecoder`) or hy3dgen's
+    CrossAttentionDecoder (query_proj, cross_attn_decoder.{ln_1, ln_2, ln_3, attn.{c_q, c_kv, c_proj}, mlp.{c_fc, c_proj}},
+    ln_post, output_proj; c_kv's output interleaves K and V per head)."""
+    if hasattr(m, "block"):                                   # standins._GeoDecoder: kv rows are [K of all heads | V of all heads]
+        b = m.block
+        return dict(freqs=m.freqs, query_proj=m.query_proj, ln_q=b.ln_q, ln_kv=b.ln_kv, ln_2=b.ln_2, q=b.q, kv=b.kv, proj=b.proj, fc1=b.fc1,
+                    fc2=b.fc2, ln_post=m.ln_post, out=m.out, heads=b.heads, kv_interleaved=False,
+                    prior=(float(m.radius), float(m.sharpness), float(m.gain)))
+    blk = m.cross_attn_decoder
+    att = blk.attn
+    for name in ("q_norm", "k_norm"):
+        nrm = getattr(att.attention, name, None)
+        if nrm is not None and not isinstance(nrm, torch.nn.Identity):
+            raise L.FohoError("HipGeoDecoder: qk_norm decoders are not supported by this version of foho_geo_decode_fwd")
+    return dict(freqs=m.fourier_embedder.frequencies, query_proj=m.query_proj, ln_q=blk.ln_1, ln_kv=blk.ln_2, ln_2=blk.ln_3, q=att.c_q,
+                kv=att.c_kv, proj=att.c_proj, fc1=blk.mlp.c_fc, fc2=blk.mlp.c_proj, ln_post=m.ln_post, out=m.output_proj,
+                heads=att.attention.heads, kv_interleaved=True, prior=(0.0, 0.0, 1.0))
+
+
+class HipGeoDecoder:
+    CHUNK = 16384        # rows per block of the chain: its activations (14.5 KB per row at width 1024) stay in the Infinity Cache
+
+    def __init__(self, parts, device="cuda", chunk_rows=None):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        dev, h = self.device, torch.float16
+        p = parts
+        width = p["q"].weight.shape[0]
+        heads = int(p["heads"])
+        hidden = p["fc1"].weight.shape[0]
+        n_freqs = int(p["freqs"].numel())
+        emb = 3 * (2 * n_freqs + 1)
+        if p["query_proj"].weight.shape[1] != emb or emb > 64:
+            raise L.FohoError(f"HipGeoDecoder: query projection of {p['query_proj'].weight.shape[1]} inputs, embedding of {emb} (at most 64)")
+        t = {}
+        wq = torch.zeros(width, 64, dtype=h, device=dev)
+        wq[:, :emb] = p["query_proj"].weight.detach().to(dev, h)
+        t["w_qproj"], t["b_qproj"] = wq, _bias(p["query_proj"], width, dev)
+        for name, ln in (("ln_q", p["ln_q"]), ("ln_kv", p["ln_kv"]), ("ln_2", p["ln_2"]), ("ln_post", p["ln_post"])):
+            t[name + "_g"] = ln.weight.detach().to(dev, torch.float32).contiguous()
+            t[name + "_b"] = ln.bias.detach().to(dev, torch.float32).contiguous()
+        wkv, bkv = p["kv"].weight.detach().to(dev, torch.float32), _bias(p["kv"], 2 * width, dev)
+        if p["kv_interleaved"]:                          # rows [h][k | v][d] -> [k | v][h][d]
+            wkv = wkv.view(heads, 2, width // heads, width).permute(1, 0, 2, 3).reshape(2 * width, width)
+            bkv = bkv.view(heads, 2, width // heads).permute(1, 0, 2).reshape(2 * width)
+        t["w_kv"], t["b_kv"] = wkv.to(h).contiguous(), bkv.contiguous()
+        for name, lin in (("q", p["q"]), ("proj", p["proj"]), ("fc1", p["fc1"]), ("fc2", p["fc2"])):
+            t["w_" + name] = lin.weight.detach().to(dev, h).contiguous()
+            t["b_" + name] = _bias(lin, lin.weight.shape[0], dev)
+        t["w_out"] = p["out"].weight.detach().reshape(-1).to(dev, torch.float32).contiguous()
+        t["freqs"] = p["freqs"].detach().to(dev, torch.float32).contiguous()
+        self.t = t
+        w = FohoGeoWeights()
+        w.width, w.heads, w.hidden, w.n_freqs, w.n_latents = width, heads, hidden, n_freqs, 64
+        for name, _ in FohoGeoWeights._fields_:
+            if name in t:
+                setattr(w, name, t[name].data_ptr())
+        w.b_out = float(p["out"].bias.detach().reshape(-1)[0]) if p["out"].bias is not None else 0.0
+        w.ln_eps = float(p["ln_post"].eps)
+        w.prior_radius, w.prior_sharpness, w.out_gain = p["prior"]
+        self.w = w
+        self.chunk = int(chunk_rows or self.CHUNK)
+        self.workspace = None
+        self._prepared = None
+        self.lib.foho_geo_workspace_bytes.restype = ctypes.c_size_t
+        self.lib.foho_geo_workspace_bytes.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
+        self.lib.foho_geo_last_error.restype = ctypes.c_char_p
+        if self.lib.foho_geo_workspace_bytes(ctypes.byref(w), self.chunk) == 0:
+            raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
+
+    @classmethod
+    def from_module(cls, module, device="cuda", chunk_rows=None):
+        return cls(_parts(module), device=device, chunk_rows=chunk_rows)
+
+    def _check(self, status, what):
+        if status != 0:
+            raise L.FohoError(f"{what} failed ({status}): {self.lib.foho_geo_last_error().decode()}")
+
+    def prepare(self, latents):
+        """LayerNorm + K/V projection of the latent tokens (L, width), once per set of tokens."""
+        lat = latents.reshape(-1, latents.shape[-1]).to(self.device, torch.float16).contiguous()
+        if lat.shape[1] != self.w.width:
+            raise L.FohoError(f"HipGeoDecoder: latent tokens of width {lat.shape[1]}, decoder of width {self.w.width}")
+        if lat.shape[0] != self.w.n_latents or self.workspace is None:
+            self.w.n_latents = lat.shape[0]
+            n = int(self.lib.foho_geo_workspace_bytes(ctypes.byref(self.w), self.chunk))
+            if n == 0:
+                raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
+            self.workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_prepare(ctypes.byref(self.w), L.vp(lat.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
+                                              ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_prepare")
+        self._lat = lat        # kept alive until the stream has consumed it
+
+    def decode(self, queries):
+        """queries (N, 3) -> logits (N,) float32, against the tokens of the last prepare()."""
+        q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
+        out = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_decode_fwd(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(out.data_ptr()),
+                                                 ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()), ctypes.c_size_t(self.workspace.numel()),
+                                                 L.vp(stream)), "foho_geo_decode_fwd")
+        return out
+
+    def __call__(self, queries, latents):
+        """The module's signature: queries (1, N, 3), latents (1, L, width) -> (1, N, 1) in the latents' dtype."""
+        if latents.dim() == 3 and latents.shape[0] != 1:
+            raise L.FohoError("HipGeoDecoder: one set of latent tokens per call")
+        key = (latents.data_ptr(), latents._version, tuple(latents.shape))
+        if self._prepared != key:
+            self.prepare(latents)
+            self._prepared = key
+        return self.decode(queries).to(latents.dtype).reshape(1, -1, 1)
+
+
+def install(vae, device="cuda", chunk_rows=None):
+    """Attach a HipGeoDecoder built from `vae.geo_decoder` as `vae.hip_geo`: `pipeline.latent2sdf` then decodes with it
+    wherever no gradient is required.  Raises when the decoder's shape is outside what the kernels take."""
+    vae.hip_geo = HipGeoDecoder.from_module(vae.geo_decoder, device=device, chunk_rows=chunk_rows)
+    return vae.hip_geo

@@ -40,6 +40,11 @@ def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     8000 grid points, negate the logits so that the field is negative inside.  -> (1, G, G, G) float32."""
     pred = 1 / vae.scale_factor * pred
     pred = vae(pred)
+    hip = getattr(vae, "hip_geo", None)          # geo_decode.install(vae): the decoder on the matrix cores, forward only
+    if hip is not None and not (torch.is_grad_enabled() and pred.requires_grad):
+        # the reference's no-gradient decodes (PL:1614-1662): all grid points in one call, no 8000-query chunks
+        grid_logits = hip(xyz_samples.to(device).half().float().unsqueeze(0), pred)      # fp16 query points like PL:303
+        return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
     logits = []
     for start in range(0, xyz_samples.shape[0], num_chunks):
         queries = xyz_samples[start:start + num_chunks].to(device).half()      # fp16 whatever the VAE's dtype (PL:303)

@@ -34,6 +34,7 @@
  *   foho_icp_run_batch       the same for all start transforms of icp() at once (ICP:91-175)
  *   foho_icp_run_surface     the same with on_surface=True: closest point on the target triangles (ICP:106-107)
  *   foho_mesh_decimate       hy3dgen FaceReducer = pymeshlab quadric edge collapse (RUN:163), host code
+ *   foho_geo_decode_fwd      the chunked `vae.geo_decoder(queries, latents)` loop of latent2sdf (PL:298-308)
  */
 #ifndef FOHO_HIP_H
 #define FOHO_HIP_H
@@ -359,6 +360,64 @@ int foho_object_update(const foho_step_desc* desc, const int32_t* counts, const 
  * Vertices and faces keep their relative order; the same input gives the same output. */
 int foho_mesh_decimate(const float* verts, int32_t V, const int64_t* faces, int32_t F, int32_t target_faces,
                        float* out_verts, int64_t* out_faces, int32_t* out_counts);
+
+/* ---- the ShapeVAE geometry decoder of latent2sdf on the matrix cores ----------------------
+ * Replaces the loop `for start in range(0, N, 8000): logits.append(vae.geo_decoder(queries, latents))` of latent2sdf
+ * (PL:298-308; hy3dgen CrossAttentionDecoder: FourierEmbedder -> query_proj -> ResidualCrossAttentionBlock over the
+ * latent tokens -> ln_post -> output_proj), which the reference runs 550 times per image (PL:1391-1393, 1507-1509) plus
+ * once per denoising step without gradients (PL:1624-1642, 385^3 queries on the last one).  Forward only in this version.
+ * fp16 storage / fp32 accumulation (the reference runs the VAE in fp16, PL:522); all queries in ONE call.
+ * Weights: DEVICE pointers, prepared once by the caller.  fp16 matrices in torch.nn.Linear layout (out_features rows of
+ * in_features), fp32 biases / LayerNorm parameters.  Constraints (FOHO_ERR_BAD_ARG otherwise): head dimension 64
+ * (width = 64 heads), width % 128 == 0 and <= 1024, n_latents % 64 == 0, hidden % 128 == 0, n_freqs <= 10. */
+typedef struct {
+    int32_t width, heads, n_latents, hidden, n_freqs, reserved;
+    const float* freqs;              /* (n_freqs) DEVICE: the embedder's frequencies (2^j pi, or 2^j with include_pi = False) */
+    const void* w_qproj;             /* (width, 64) fp16: query_proj, columns 3 (2 n_freqs + 1) .. 63 zero      */
+    const float* b_qproj;            /* (width)                                                                 */
+    const float *ln_q_g, *ln_q_b;    /* LayerNorm of the queries (ln_1), (width) each                           */
+    const float *ln_kv_g, *ln_kv_b;  /* LayerNorm of the latent tokens (ln_2 of the cross-attention block)      */
+    const void* w_q;                 /* (width, width) fp16: c_q                                                */
+    const float* b_q;                /* (width)  (zeros when the model has qkv_bias = False)                    */
+    const void* w_kv;                /* (2 width, width) fp16: c_kv with rows ordered [K of head 0 .. K of head h-1 | V of head 0 ..]
+                                        (hy3dgen interleaves K and V per head; the caller permutes the rows once)  */
+    const float* b_kv;               /* (2 width)                                                               */
+    const void* w_proj;              /* (width, width) fp16: c_proj                                             */
+    const float* b_proj;
+    const float *ln_2_g, *ln_2_b;    /* LayerNorm before the MLP (ln_3 in hy3dgen)                              */
+    const void* w_fc1;               /* (hidden, width) fp16; GELU (erf form) behind it                         */
+    const float* b_fc1;
+    const void* w_fc2;               /* (width, hidden) fp16                                                    */
+    const float* b_fc2;
+    const float *ln_post_g, *ln_post_b;
+    const float* w_out;              /* (width) fp32: output_proj (one occupancy logit)                         */
+    float b_out;
+    float ln_eps;                    /* 1e-5 (torch default) unless the model says otherwise                    */
+    float prior_radius, prior_sharpness, out_gain;  /* logits = sharpness (radius - |x|) + gain * learned.  A trained decoder:
+                                        0, 0, 1.  (The random-initialised stand-in of the tests adds an analytic sphere.) */
+} foho_geo_weights;
+
+/* workspace for row blocks of `chunk_rows` queries: K / V of the latent tokens + the block's activations (14.5 KB per
+ * query at width 1024 / hidden 4096; 16384 rows keep a block inside the 256 MB Infinity Cache).  0 on bad arguments. */
+size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
+/* once per set of latent tokens: LayerNorm + K/V projection of `latents` (n_latents, width) fp16 into the workspace
+ * (V transposed and key-permuted for the attention kernel).  The same chunk_rows as the decode calls that follow. */
+int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chunk_rows, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* logits[n] = geo_decoder(queries[n], latents) for n < n_queries: queries (N,3) fp32 (already rounded the way the caller's
+ * pipeline rounds them: the reference casts them to fp16 first, PL:303), logits (N) fp32.  Uses the K / V that
+ * foho_geo_prepare left in the workspace.  9 launches per row block, asynchronous, no host synchronisation. */
+int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
+ * with epilogue = GELU when `gelu`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
+ * foho_geo_attention: O (M, 64 heads) = softmax(Q K^T) V per head with Q (M, 64 heads) pre-scaled by log2(e) / 8, KV
+ * (n_latents, 128 heads) = [K | V] as the projection leaves them, Vt_scratch room for 64 heads x n_latents fp16. */
+int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
+                  int32_t gelu, float scale, void* stream);
+int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
+                       void* stream);
+const char* foho_geo_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,165 @@
+"""The geometry decoder of latent2sdf on the matrix cores (foho_geo_decode_fwd, csrc/foho_geo.hip) against the torch module
+of the same shape (standins._GeoDecoder, float32 arithmetic on the same fp16-representable weights): the GEMM with each
+epilogue, the attention kernel, and the whole chain at a reduced and at the full Hunyuan3D-2 shape (3072 x 1024 latent
+tokens, 16 heads, hidden 4096, 65^3 queries).  fp16 storage / fp32 accumulation: tolerance 2e-3 of the output's scale."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+gpu = pytest.mark.gpu
+
+
+def _lib():
+    from followmyhold_amd import _lib as L
+    lib = L.lib()
+    lib.foho_geo_last_error.restype = ctypes.c_char_p
+    return L, lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_geo_workspace_query_and_argument_checks_run_without_a_gpu():
+    from followmyhold_amd.geo_decode import FohoGeoWeights
+    L, lib = _lib()
+    lib.foho_geo_workspace_bytes.restype = ctypes.c_size_t
+    lib.foho_geo_workspace_bytes.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
+    w = FohoGeoWeights()
+    w.width, w.heads, w.n_latents, w.hidden, w.n_freqs = 1024, 16, 3072, 4096, 8
+    for name, typ in FohoGeoWeights._fields_:
+        if typ is L.vp:
+            setattr(w, name, 1)       # non-null: the size query only looks at the shape
+    n = lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384)
+    per_row = 2 * (64 + 3 * 1024 + 4096)
+    assert 16384 * per_row <= n <= 16384 * per_row + 3072 * 1024 * 2 * 3 + 8192
+    w.heads = 8                        # head dimension 128: refused
+    assert lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384) == 0 and b"head dimension" in lib.foho_geo_last_error()
+    w.heads, w.n_latents = 16, 100
+    assert lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384) == 0 and b"n_latents" in lib.foho_geo_last_error()
+    lib.foho_geo_decode_fwd.restype = ctypes.c_int
+    assert lib.foho_geo_decode_fwd(None, None, ctypes.c_int64(0), None, 0, None, ctypes.c_size_t(0), None) == -1
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K,mode", [(300, 256, 64, "plain"), (1000, 1024, 1024, "scale"), (777, 512, 256, "gelu"), (4097, 256, 1024, "resid")])
+def test_gemm_epilogues_against_torch(M, N, K, mode):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).half().cuda() if mode == "resid" else None
+    C = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+    scale = 0.18 if mode == "scale" else 1.0
+    lib.foho_geo_gemm.restype = ctypes.c_int
+    rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), _p(R) if R is not None else None, _p(C), M, N, K, int(mode == "gelu"), ctypes.c_float(scale),
+                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.foho_geo_last_error()
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().T + b
+    if mode == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    ref = ref * scale
+    if R is not None:
+        ref = ref.half().float() + R.float()
+    assert torch.isfinite(C.float()).all()
+    err = (C.float() - ref).abs().max().item()
+    assert err <= 2e-3 * max(ref.abs().max().item(), 1.0), (err, ref.abs().max().item())
+
+
+@gpu
+@pytest.mark.parametrize("M,Lk,heads", [(256, 64, 2), (1000, 256, 4), (700, 3072, 16)])
+def test_attention_against_torch(M, Lk, heads):
+    L, lib = _lib()
+    W = heads * 64
+    g = torch.Generator().manual_seed(Lk)
+    q = torch.randn(M, W, generator=g)
+    kv = torch.randn(Lk, 2 * W, generator=g)
+    kv[5, :64] *= 4.0                                   # one key that dominates some rows: the deferred rescale must fire late, too
+    kv[Lk - 3, 64 * (heads - 1):64 * heads] *= 4.0
+    qs = (q * (math.log2(math.e) / 8.0)).half().cuda()
+    kvh = kv.half().cuda()
+    O = torch.full((M, W), float("nan"), dtype=torch.float16, device="cuda")
+    vt = torch.empty(W * Lk, dtype=torch.float16, device="cuda")
+    lib.foho_geo_attention.restype = ctypes.c_int
+    rc = lib.foho_geo_attention(_p(qs), _p(kvh), _p(vt), _p(O), M, Lk, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.foho_geo_last_error()
+    torch.cuda.synchronize()
+    qf = (qs.float() * (8.0 / math.log2(math.e))).view(M, heads, 64).transpose(0, 1)          # the values the kernel saw
+    kf = kvh.float()[:, :W].view(Lk, heads, 64).transpose(0, 1)
+    vf = kvh.float()[:, W:].view(Lk, heads, 64).transpose(0, 1)
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf).transpose(0, 1).reshape(M, W)
+    assert torch.isfinite(O.float()).all()
+    err = (O.float() - ref).abs().max().item()
+    assert err <= 2e-3 * max(ref.abs().max().item(), 1.0), (err, ref.abs().max().item())
+
+
+def _decoder(width, heads, n_lat, hidden_ratio=4, seed=0):
+    from followmyhold_amd import standins
+    torch.manual_seed(seed)
+    vae = standins.StandInShapeVAE(num_latents=n_lat, embed_dim=16, width=width, heads=heads, layers=1, num_freqs=8)
+    dec = vae.geo_decoder
+    with torch.no_grad():          # weights the fp16 kernels can represent exactly; LayerNorm parameters off their defaults
+        for p in dec.parameters():
+            p.copy_(p.half().float())
+        for ln in (dec.block.ln_q, dec.block.ln_kv, dec.block.ln_2, dec.ln_post):
+            ln.weight.add_(0.1 * torch.randn_like(ln.weight))
+            ln.bias.add_(0.1 * torch.randn_like(ln.bias))
+    return dec.cuda().eval()
+
+
+@gpu
+@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384)])
+def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk):
+    """Fourier embedding -> query projection -> cross attention -> MLP -> LayerNorm -> logit, all queries in one call (row
+    blocks of `chunk`, the last one ragged), against the float32 torch module on the same fp16-rounded inputs."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(width, heads, n_lat)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, n_lat, width, generator=g).half().cuda()
+    q = (torch.rand(1, n_q, 3, generator=g) * 2.2 - 1.1).half().cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=chunk)
+    out = hip(q.float(), lat)
+    torch.cuda.synchronize()
+    assert out.shape == (1, n_q, 1) and out.dtype == torch.float16
+    with torch.no_grad():
+        ref = dec(q, lat.float())
+        learned = (ref - (dec.radius - q.float().norm(dim=-1, keepdim=True)) * dec.sharpness) / dec.gain
+    err = (out.float() - ref).abs().max().item()
+    # the tolerance refers to the LEARNED part (the analytic prior is exact on both sides)
+    assert learned.abs().max().item() > 0.1
+    assert err <= 2e-3 * max(learned.abs().max().item(), 1.0) * dec.gain + 1e-3 * ref.abs().max().item(), (err, learned.abs().max().item())
+    # a second call on the same tokens reuses K / V; new tokens are projected again
+    out2 = hip(q.float(), lat)
+    assert torch.equal(out, out2)
+    lat2 = (lat.float() * 1.5).half()
+    out3 = hip(q.float(), lat2)
+    with torch.no_grad():
+        ref3 = dec(q, lat2.float())
+    assert (out3.float() - ref3).abs().max().item() <= 2e-3 * max(learned.abs().max().item(), 1.0) * dec.gain + 1e-3 * ref3.abs().max().item()
+
+
+@gpu
+def test_latent2sdf_uses_the_hip_decoder_without_gradients_only():
+    """pipeline.latent2sdf: with geo_decode.install(vae) the no-gradient decodes (PL:1614-1662) run on the HIP decoder -- same
+    grid to fp16 accuracy --, a decode that must carry gradients to the latent stays on the torch modules."""
+    from followmyhold_amd import geo_decode, pipeline, standins
+    from followmyhold_amd.facade import generate_dense_grid_points
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=128, embed_dim=8, width=128, heads=2, layers=1, num_freqs=8).cuda().eval()
+    xyz, gsz, _ = generate_dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 4, "ij")       # 17^3 points
+    xyz = torch.as_tensor(xyz, dtype=torch.float32)
+    lat = torch.randn(1, 128, 8, device="cuda")
+    with torch.no_grad():
+        ref = pipeline.latent2sdf(lat, xyz, gsz, vae, "cuda")
+        geo_decode.install(vae)
+        got = pipeline.latent2sdf(lat, xyz, gsz, vae, "cuda")
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 5e-3 * ref.abs().max().item()
+    assert not torch.equal(got, ref)                                    # it did take the other path
+    lat.requires_grad_(True)
+    sdf = pipeline.latent2sdf(lat, xyz, gsz, vae, "cuda")
+    assert sdf.requires_grad and torch.equal(sdf.detach(), ref)
