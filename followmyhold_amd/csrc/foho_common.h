@@ -276,9 +276,16 @@ struct Frag {
 // PRETESTED = true: the caller has established the three face-level tests -- depth not all negative, pixel centre inside
 // the blur-inflated box, area beyond K_EPS -- itself (the scatter rasteriser's set-up wave does, per face, and its pixel
 // boxes are exactly the centres that pass the box test): same result, ~25 instructions per fragment less.
+// full_t > 0 (the scatter rasteriser only): a fragment INSIDE the face whose squared distance to each of the three edge
+// LINES exceeds full_t -- e_i^2 > full_t |edge_i|^2, e_i the edge function = |edge_i| x distance to the line -- is farther
+// than that from every edge SEGMENT too, so with full_t = 20 sigma its 1 - sigmoid(dist / sigma) is exactly 0 (the float
+// sigmoid is 1 from 16.7 on): the pixel is fully covered, the caller needs neither the distance nor its three correctly
+// rounded divisions, and out.sdist = -INFINITY says so.  The classification is the one the full evaluation makes: the
+// rounding of e_i (<= 2.4e-7 |p - a| |edge_i|, i.e. <= 3e-4 relative at the threshold for edges up to 1 NDC -- longer
+// ones never take the shortcut) and of seg_d2 (1e-3) are far inside the margin between 16.7 and 20.
 template <bool PRETESTED = false>
 __device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf, float yf, float blur_radius,
-                                          float sqrt_blur, Frag& out) {
+                                          float sqrt_blur, Frag& out, float full_t = 0.0f) {
     const float x0 = fv[0], y0 = fv[1], z0 = fv[2];
     const float x1 = fv[3], y1 = fv[4], z1 = fv[5];
     const float x2 = fv[6], y2 = fv[7], z2 = fv[8];
@@ -295,9 +302,10 @@ __device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf
     }
 
     const float area = edge_fn(x2, y2, x0, y0, x1, y1) + K_EPS;
-    const float a0 = edge_fn(xf, yf, x1, y1, x2, y2) / area;
-    const float a1 = edge_fn(xf, yf, x2, y2, x0, y0) / area;
-    const float a2 = edge_fn(xf, yf, x0, y0, x1, y1) / area;
+    const float e0 = edge_fn(xf, yf, x1, y1, x2, y2), e1 = edge_fn(xf, yf, x2, y2, x0, y0), e2 = edge_fn(xf, yf, x0, y0, x1, y1);
+    const float a0 = e0 / area;
+    const float a1 = e1 / area;
+    const float a2 = e2 / area;
     const float t0 = a0 * z1 * z2;
     const float t1 = z0 * a1 * z2;
     const float t2 = z0 * z1 * a2;
@@ -310,6 +318,20 @@ __device__ __forceinline__ bool eval_frag(const float* __restrict__ fv, float xf
     c2 = c2 / s;
     const float pz = c0 * z0 + c1 * z1 + c2 * z2;
     if (pz < 0.0f) return false;
+    if (full_t > 0.0f) {
+        // e0 belongs to edge (v1, v2), e1 to (v2, v0), e2 to (v0, v1)
+        const float l0 = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1), l1 = (x0 - x2) * (x0 - x2) + (y0 - y2) * (y0 - y2),
+                    l2 = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+        if ((w0 > 0.0f) && (w1 > 0.0f) && (w2 > 0.0f) && fmaxf(fmaxf(l0, l1), l2) <= 1.0f && e0 * e0 > full_t * l0 && e1 * e1 > full_t * l1 &&
+            e2 * e2 > full_t * l2) {
+            out.z = pz + 0.0f;
+            out.sdist = -INFINITY;
+            out.c0 = c0;
+            out.c1 = c1;
+            out.c2 = c2;
+            return true;
+        }
+    }
     const float d01 = seg_d2(xf, yf, x0, y0, x1, y1);
     const float d02 = seg_d2(xf, yf, x0, y0, x2, y2);
     const float d12 = seg_d2(xf, yf, x1, y1, x2, y2);

@@ -66,7 +66,19 @@ constexpr int GM = 128, GN = 128, GK = 64;
 constexpr int EP_GELU = 1, EP_RESID = 2;
 constexpr int CPAD = 72;  // halfs per row of the epilogue's LDS image (64 + 8: keeps 16-byte alignment, spreads banks)
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// GELU in torch's default (erf) form.  erf by Abramowitz-Stegun 7.1.26 -- one v_exp_f32, one v_rcp_f32, five fmas; absolute
+// error <= 1.5e-7 + the 1-ulp primitives, three orders below the fp16 rounding of the result (erff() costs ~3x as much
+// and was a third of the fc1 GEMM's time in the first version of this kernel).
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);   // erf(|v| / sqrt 2)
+    return 0.5f * v + 0.5f * fabsf(v) * e;                                                   // v erf(v / sqrt 2) = |v| erf(|v| / sqrt 2)
+}
 
 template <int EP>
 __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
@@ -185,8 +197,14 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
 constexpr int AQ = 256, AK = 64;
 constexpr float RESCALE_THR = 6.0f;  // log2 domain: P <= 2^6 while the running max lags behind
 
-__device__ __forceinline__ float other_half(float x) { return __shfl_xor(x, 32); }
+// value of the same register in the other half-wave (lane ^ 32): v_permlane32_swap exchanges vdst[32..63] with src[0..31]
+__device__ __forceinline__ float other_half(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32: arguments are <= 6, underflow to 0 is what is wanted
 
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
@@ -231,13 +249,18 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     };
 
     f32x16 o[2][2];  // [query block][d tile]: O^T, rows d, columns q
+    f32x16 negm[2];  // -(running max) of the lane's query in all 16 registers: the accumulator S^T starts from, so the MFMA
+                     // chain delivers s - m and the softmax needs no subtraction
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) negm[a][r] = 0.0f;
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[a][b][r] = 0.0f;
-    float mrun[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.0f, 0.0f};
+    }
+    float lsum[2] = {0.0f, 0.0f};
 
     const int nt = L / AK;
     gload(0);
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         const uint4* lv = lds[t & 1][1];
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
-            // ---- S^T (32 keys x 32 queries per query block) = K Q^T
+            // ---- S^T - m (32 keys x 32 queries per query block) = K Q^T - m
             half8 kf[4];
             const int krow = sub * 32 + l31;
 #pragma unroll
@@ -260,10 +283,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
             f32x16 s[2];
 #pragma unroll
             for (int qb = 0; qb < 2; qb++) {
+                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; r++) s[qb][r] = 0.0f;
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], s[qb], 0, 0, 0);
+                for (int kk = 1; kk < 4; kk++) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], s[qb], 0, 0, 0);
             }
             // ---- V^T fragments of this sub-tile: A operand, rows d, 16 keys per MFMA
             half8 vf[2][2];
@@ -277,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                 }
             }
             // ---- online softmax in the log2 domain; a query's 32 scores sit in two lanes (l31, hi = 0 / 1), 16 registers each
+            const bool first = (t == 0) && (sub == 0);
 #pragma unroll
             for (int qb = 0; qb < 2; qb++) {
                 float tm = max3(s[qb][0], s[qb][1], s[qb][2]);
@@ -288,11 +311,17 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                 tm = max3(tm, s[qb][13], s[qb][14]);
                 tm = fmaxf(tm, s[qb][15]);
                 tm = fmaxf(tm, other_half(tm));
-                if (__any(tm > mrun[qb] + RESCALE_THR)) {  // rare after the first tiles: raise the running max, rescale what is accumulated
-                    const float mn = fmaxf(mrun[qb], tm);
-                    const float alpha = exp2f(mrun[qb] - mn);
-                    mrun[qb] = mn;
+                if (first || __any(tm > RESCALE_THR)) {
+                    // raise the running max (the first sub-tile SETS it: there it may also fall below the initial 0) and rescale
+                    // what is accumulated -- rare after the first tiles: the max only moves when a score exceeds it by 2^6
+                    const float up = first ? tm : fmaxf(tm, 0.0f);
+                    const float alpha = ex2(-up);
                     lsum[qb] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        s[qb][r] -= up;
+                        negm[qb][r] -= up;
+                    }
 #pragma unroll
                     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                 for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const float p0 = exp2f(s[qb][8 * k2 + e] - mrun[qb]), p1 = exp2f(s[qb][8 * k2 + e + 1] - mrun[qb]);
+                        const float p0 = ex2(s[qb][8 * k2 + e]), p1 = ex2(s[qb][8 * k2 + e + 1]);
                         ls += p0 + p1;
                         const f32x2 pp = {p0, p1};
                         const half2v ph = __builtin_convertvector(pp, half2v);
