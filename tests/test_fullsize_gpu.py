@@ -355,8 +355,9 @@ def _teacher_forced_joint_steps(E, sc, n_steps, max_flipped, max_conditioned=0):
                 _, gs = S.gradients_with_shifted_sigmoid("C", sct, p_k, ulps, grid_res=64)
                 cond_g = max(cond_g, rel(np.concatenate([gs[kk].numpy().reshape(-1) for kk in E.PARAM_NAMES]), gref))
                 cond_gv = max(cond_gv, rel(gs["obj_verts"].numpy(), grads["obj_verts"].numpy()))
-            assert cond_gv < 2e-2 and cond_g < 2e-2, (k, cond_g, cond_gv)
-            assert e_g <= max(1e-4, cond_g) and e_gv <= max(2e-4, cond_gv), (k, e_g, cond_g, e_gv, cond_gv)
+            # (a coherent shift can also push an alpha of 1 - 2^-24 onto the BCE clamp and move the gradient by orders of
+            # magnitude -- as a bound that is still valid, only useless, hence the hard cap beside it)
+            assert e_g <= min(max(1e-4, cond_g), 5e-3) and e_gv <= min(max(2e-4, cond_gv), 5e-3), (k, e_g, cond_g, e_gv, cond_gv)
             conditioned += 1
             e_g, e_gv = min(e_g, 1e-4), min(e_gv, 2e-4)
         worst["grad"] = max(worst["grad"], e_g)
