@@ -15,9 +15,10 @@
 //   * attention: swapped QK^T (S^T = K Q^T) puts a query's scores in ONE lane column -> row max / row sum are in-lane
 //     v_max3 / adds plus one exchange between the two half-waves; softmax scale and log2(e) are folded into Q;
 //     the running max is only raised when a tile exceeds it by more than 2^6 (deferred rescale).
-//   * GEMMs: 128 x 128 x 64 tiles, 4 waves x (64 x 64), operands staged by LDS-DMA (global_load_lds_dwordx4) into a
-//     double-buffered, XOR-swizzled image (swizzle applied on the SOURCE address, the DMA's destination is lane-linear),
-//     conflict-free ds_read_b128 fragments; bias / GELU / softmax scale / residual fused into the epilogue, which goes
+//   * GEMMs: 128 x 128 x 64 tiles, 4 waves x (64 x 64), operands staged by LDS-DMA (global_load_lds_dwordx4; tile t+1 in
+//     flight while tile t is multiplied) into a double-buffered, XOR-swizzled image (swizzle applied on the SOURCE
+//     address, the DMA's destination is lane-linear), conflict-free ds_read_b128 fragments requested one k-step ahead of
+//     the MFMAs that use them (inline asm with hand-counted lgkmcnt: see the kernel); bias / GELU / softmax scale / residual fused into the epilogue, which goes
 //     through LDS so that global stores are whole 128-byte row segments.
 //   * XCD-aware block order everywhere (workgroup L runs on XCD L mod 8; K/V of two heads or the weight panel of a GEMM
 //     stay in that XCD's 4 MB L2).
@@ -80,6 +81,12 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v + 0.5f * fabsf(v) * e;                                                   // v erf(v / sqrt 2) = |v| erf(|v| / sqrt 2)
 }
 
+// LDS byte address of a __shared__ object (for the inline-asm reads below)
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+#define GEO_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
 template <int EP>
 __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                      const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
@@ -94,7 +101,13 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
     const int m0 = mp * GM, n0 = nt * GN;
     const int wr = w >> 1, wc = w & 1;  // this wave's 64 x 64 part of the tile
 
-    // staging: a wave moves pieces w*4 .. w*4+3 (8 rows x 128 B each) of both operands per K-tile
+    // Staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows of a tile per instruction, destination lane-linear,
+    // so the XOR swizzle sits on the SOURCE address): no VGPR -> LDS store pass -- register staging had this kernel bound by
+    // the LDS (ds_write_b128 costs 13 cycles per wave-instruction: 832 of them + 512 of fragment reads per K-tile and CU
+    // against 1024 cycles of MFMA).  The fragment reads are INLINE ASM: hipcc cannot tell the DMA's destination buffer
+    // from the one being read and waits vmcnt(0) in front of every compiler-visible ds_read, which serialises the
+    // prefetch with the MFMAs (measured: the first version of this kernel); reads it cannot see get no such wait, and
+    // this code counts lgkmcnt itself.  A wave moves pieces w*4 .. w*4+3 of both operands per K-tile.
     const int srow = lane >> 3, sslot = lane & 7;
     const h16* asrc[4];
     const h16* wsrc[4];
@@ -105,13 +118,6 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
         asrc[p] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
         wsrc[p] = Wt + (size_t)(n0 + row) * ldw + c * 8;
     }
-    auto stage = [&](int buf, int k0) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            glds16(asrc[p] + k0, &lds[buf][0][(w * 4 + p) * 64]);
-            glds16(wsrc[p] + k0, &lds[buf][1][(w * 4 + p) * 64]);
-        }
-    };
 
     f32x16 acc[2][2];  // [n tile][m tile]: D rows = n, D columns = m (the lane holds 4 consecutive n for one m)
 #pragma unroll
@@ -121,29 +127,63 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
+    // fragment byte addresses inside buffer 0: row r, chunk c -> r * 128 + (c ^ swz(r)) * 16; the second tile of a wave
+    // (rows + 32, same swizzle) is an immediate offset of 4096, the W operand one of 16384
+    const int ra = wr * 64 + l31, rw = wc * 64 + l31;
+    const unsigned base = lds_addr(&lds[0][0][0]);
+    unsigned aa[4], aw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        aa[kk] = base + ra * 128 + (((2 * kk + hi) ^ swz(ra)) << 4);
+        aw[kk] = base + rw * 128 + (((2 * kk + hi) ^ swz(rw)) << 4);
+    }
+
     const int nk = K / GK;
-    stage(0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        glds16(asrc[p], &lds[0][0][(w * 4 + p) * 64]);
+        glds16(wsrc[p], &lds[0][1][(w * 4 + p) * 64]);
+    }
     for (int t = 0; t < nk; t++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile t has landed for every wave, and everybody is done with the other buffer
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * GK);
-        const uint4* la = lds[t & 1][0];
-        const uint4* lw = lds[t & 1][1];
+        __syncthreads();  // tile t has landed for every wave, and everybody is done reading the other buffer
+        if (t + 1 < nk) {
+            const int nb = (t + 1) & 1, k0 = (t + 1) * GK;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                glds16(asrc[p] + k0, &lds[nb][0][(w * 4 + p) * 64]);
+                glds16(wsrc[p] + k0, &lds[nb][1][(w * 4 + p) * 64]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(t & 1) << 15;  // 32 KB per buffer
+        half8 fa[2][2], fw[2][2];  // [parity of kk][tile]: the fragments of step kk + 1 are requested before step kk's MFMAs issue
+        {
+            const unsigned pa = aa[0] + bo, pw = aw[0] + bo;
+            GEO_DSR(fa[0][0], pa, 0);
+            GEO_DSR(fa[0][1], pa, 4096);
+            GEO_DSR(fw[0][0], pw, 16384);
+            GEO_DSR(fw[0][1], pw, 16384 + 4096);
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            half8 fa[2], fw[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int ra = wr * 64 + i * 32 + l31, rw = wc * 64 + i * 32 + l31;
-                const uint4 ua = la[ra * 8 + ((2 * kk + hi) ^ swz(ra))];
-                const uint4 uw = lw[rw * 8 + ((2 * kk + hi) ^ swz(rw))];
-                fa[i] = *reinterpret_cast<const half8*>(&ua);
-                fw[i] = *reinterpret_cast<const half8*>(&uw);
+            if (kk < 3) {
+                const unsigned pa = aa[kk + 1] + bo, pw = aw[kk + 1] + bo;
+                GEO_DSR(fa[(kk + 1) & 1][0], pa, 0);
+                GEO_DSR(fa[(kk + 1) & 1][1], pa, 4096);
+                GEO_DSR(fw[(kk + 1) & 1][0], pw, 16384);
+                GEO_DSR(fw[(kk + 1) & 1][1], pw, 16384 + 4096);
+                // LDS returns in order: at most the four reads just issued may still be out
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
             }
 #pragma unroll
             for (int jn = 0; jn < 2; jn++)
 #pragma unroll
-                for (int i = 0; i < 2; i++) acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[jn], fa[i], acc[jn][i], 0, 0, 0);
+                for (int i = 0; i < 2; i++)
+                    acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][jn], fa[kk & 1][i], acc[jn][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();  // every wave is done with the staging buffers: they become the epilogue's transpose image
@@ -203,6 +243,10 @@ __device__ __forceinline__ float other_half(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
+// three-input maximum: v_max3_f32.  Plain fmaxf() -- NOT inline asm: hipcc pads the MFMA -> VALU read hazard only for
+// instructions it can see, and an asm v_max3 on fresh accumulators read them before the matrix pipe had written them
+// (results stayed accurate but differed from run to run).  The translation unit is built with -fno-honor-nans, which is
+// what keeps the compiler from putting a canonicalising v_max_f32 x, x in front of every operand.
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32: arguments are <= 6, underflow to 0 is what is wanted
 
@@ -233,20 +277,22 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     const int srow = tid >> 3, sch = tid & 7;
     const h16* kg = Kp + (size_t)srow * ldk + head * 64 + sch * 8;
     const h16* vg = Vt + ((size_t)head * 64 + srow) * L + sch * 8;
-    uint4 st[4];
-    auto gload = [&](int t) {
-        st[0] = *reinterpret_cast<const uint4*>(kg + (size_t)(t * AK) * ldk);
-        st[1] = *reinterpret_cast<const uint4*>(kg + (size_t)(t * AK + 32) * ldk);
-        st[2] = *reinterpret_cast<const uint4*>(vg + t * AK);
-        st[3] = *reinterpret_cast<const uint4*>(vg + (size_t)32 * L + t * AK);
-    };
     const int sidx = srow * 8 + (sch ^ swz(srow));  // rows srow and srow + 32 share the swizzle
-    auto lwrite = [&](int buf) {
-        lds[buf][0][sidx] = st[0];
-        lds[buf][0][sidx + 256] = st[1];
-        lds[buf][1][sidx] = st[2];
-        lds[buf][1][sidx + 256] = st[3];
-    };
+    uint4 st0, st1, st2, st3;
+#define ATT_GLOAD(t)                                                                    \
+    do {                                                                                \
+        st0 = *reinterpret_cast<const uint4*>(kg + (size_t)((t) * AK) * ldk);           \
+        st1 = *reinterpret_cast<const uint4*>(kg + (size_t)((t) * AK + 32) * ldk);      \
+        st2 = *reinterpret_cast<const uint4*>(vg + (t) * AK);                           \
+        st3 = *reinterpret_cast<const uint4*>(vg + (size_t)32 * L + (t) * AK);          \
+    } while (0)
+#define ATT_LWRITE(buf)                  \
+    do {                                 \
+        lds[buf][0][sidx] = st0;         \
+        lds[buf][0][sidx + 256] = st1;   \
+        lds[buf][1][sidx] = st2;         \
+        lds[buf][1][sidx + 256] = st3;   \
+    } while (0)
 
     f32x16 o[2][2];  // [query block][d tile]: O^T, rows d, columns q
     f32x16 negm[2];  // -(running max) of the lane's query in all 16 registers: the accumulator S^T starts from, so the MFMA
@@ -263,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     float lsum[2] = {0.0f, 0.0f};
 
     const int nt = L / AK;
-    gload(0);
-    lwrite(0);
+    ATT_GLOAD(0);
+    ATT_LWRITE(0);
     __syncthreads();
     for (int t = 0; t < nt; t++) {
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) ATT_GLOAD(t + 1);
         const uint4* lk = lds[t & 1][0];
         const uint4* lv = lds[t & 1][1];
 #pragma unroll
@@ -302,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
             const bool first = (t == 0) && (sub == 0);
 #pragma unroll
             for (int qb = 0; qb < 2; qb++) {
+                // max of the lane's 16 scores (already relative to the running max).  The other half-wave holds the query's
+                // other 16: it is only consulted when somebody's maximum has to move (one ballot decides)
                 float tm = max3(s[qb][0], s[qb][1], s[qb][2]);
                 tm = max3(tm, s[qb][3], s[qb][4]);
                 tm = max3(tm, s[qb][5], s[qb][6]);
@@ -310,10 +358,10 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                 tm = max3(tm, s[qb][11], s[qb][12]);
                 tm = max3(tm, s[qb][13], s[qb][14]);
                 tm = fmaxf(tm, s[qb][15]);
-                tm = fmaxf(tm, other_half(tm));
                 if (first || __any(tm > RESCALE_THR)) {
                     // raise the running max (the first sub-tile SETS it: there it may also fall below the initial 0) and rescale
                     // what is accumulated -- rare after the first tiles: the max only moves when a score exceeds it by 2^6
+                    tm = fmaxf(tm, other_half(tm));
                     const float up = first ? tm : fmaxf(tm, 0.0f);
                     const float alpha = ex2(-up);
                     lsum[qb] *= alpha;
@@ -348,9 +396,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                     for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
             }
         }
-        if (t + 1 < nt) lwrite((t + 1) & 1);  // that buffer was last read in iteration t - 1, before the barrier every wave passed
+        if (t + 1 < nt) ATT_LWRITE((t + 1) & 1);  // that buffer was last read in iteration t - 1, before the barrier every wave passed
         __syncthreads();
     }
+#undef ATT_GLOAD
+#undef ATT_LWRITE
     // ---- normalise and store: the lane holds, for ONE query, d = 32 dt + 8 g + 4 hi + (0..3)
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {

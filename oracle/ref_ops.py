@@ -273,36 +273,6 @@ def render_normals(verts_world, faces, cam, sel, sigma=1e-8, gamma=1e-8):
     return rgba.reshape(H, W, 4), zbuf.reshape(H, W)
 
 
-# Conditioning probe for parity tests (never set by the product, which does not import this package): the silhouette's
-# sigmoid outputs moved by SIGMOID_ULP float32 ulps, forward AND in the derivative s (1 - s) autograd builds from them.
-# torch-CPU (Sleef), the HIP device library and the CUDA build the reference runs on disagree by one ulp on ~10 % of
-# their expf results; where 1 - s is a few 1e-5 (fragments at the rim of the blur radius) one ulp of s is 0.3 % of the
-# fragment's gradient.  The tests use the shifted gradients to MEASURE how far the reference's own gradient moves under
-# such a disagreement and hold the HIP path to that, instead of to a blanket tolerance.
-SIGMOID_ULP = 0
-
-
-class _ShiftedSigmoid(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, ulps):
-        s = torch.sigmoid(x)
-        target = torch.full_like(s, float("inf") if ulps > 0 else float("-inf"))
-        for _ in range(abs(int(ulps))):
-            s = torch.nextafter(s, target)
-        s = s.clamp(0.0, 1.0)
-        ctx.save_for_backward(s)
-        return s
-
-    @staticmethod
-    def backward(ctx, g):
-        (s,) = ctx.saved_tensors
-        return g * s * (1.0 - s), None
-
-
-def _sil_sigmoid(x):
-    return torch.sigmoid(x) if SIGMOID_ULP == 0 else _ShiftedSigmoid.apply(x, SIGMOID_ULP)
-
-
 def render_silhouette(verts_world, faces, cam, sel, sigma=1e-8):
     """sil_renderer(mesh)[..., 3] of RUN:113-116: alpha = 1 - prod_k(1 - sigmoid(-d_k/sigma))."""
     H, W = cam.H, cam.W
@@ -315,7 +285,7 @@ def render_silhouette(verts_world, faces, cam, sel, sigma=1e-8):
     pix, fidx = pairs[:, 0], pairs[:, 1]
     _, _, sdist, _ = eval_fragments(ndc, faces, pix, fidx, H, W, sub=pairs[:, 2] if pairs.shape[1] > 2 else None)
     sig = torch.tensor(sigma, dtype=torch.float32).to(dt)
-    one_minus = 1.0 - _sil_sigmoid(-sdist / sig)
+    one_minus = 1.0 - torch.sigmoid(-sdist / sig)
     # dense (n_hit_pixels, Kmax) layout; pairs arrive grouped by pixel and sorted by z
     upix, inv, cnt = torch.unique_consecutive(pix, return_inverse=True, return_counts=True)
     start = torch.cumsum(cnt, 0) - cnt
@@ -325,16 +295,54 @@ def render_silhouette(verts_world, faces, cam, sel, sigma=1e-8):
     return alpha.index_put((upix,), a).reshape(H, W)
 
 
+# Conditioning probe for parity tests (never set by the product, which does not import this package).  The min-max
+# normalisation couples every pixel to two global extrema, and autograd sends d loss / d min -- a SUM over all 3 H W
+# normalised values, of mixed sign -- back to the one pixel that attains the extremum (its face's three vertices).  In
+# float32 that sum carries ~1e-3 of relative error whose value depends on the reduction order (torch-CPU, CUDA and any
+# other implementation differ); on crop frames late in the loop, when |grad obj_verts| has fallen to a few units, those three
+# vertices are what is left of the comparison.  WIDE_SUMS = True keeps the forward pass bit-identical and evaluates the two
+# backward sums through the extrema in float64 (_MinMaxNormaliseWide): the HIP path accumulates them in double precision
+# and must agree with THIS to the tolerance; the float32 figure beside it is the reference's own summation error.
+WIDE_SUMS = False
+
+
+class _MinMaxNormaliseWide(torch.autograd.Function):
+    """(x - x.min()) / (x.max() - x.min() + 1e-6): forward exactly as the float32 expression computes it (bit-identical
+    values, so every exact tie downstream -- |render - target| == 0 where the render IS the target -- stays a tie); backward
+    with the two sums through the extrema in float64, distributed evenly over ties like torch's min() / max()."""
+
+    @staticmethod
+    def forward(ctx, x):
+        mn, mx = x.min(), x.max()
+        ctx.save_for_backward(x, mn, mx)
+        return (x - mn) / (mx - mn + 1e-6)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mn, mx = ctx.saved_tensors
+        xd, gd, mnd, mxd = x.double(), g.double(), mn.double(), mx.double()
+        D = (mx - mn + 1e-6).double()          # the float32 denominator the forward divided by
+        g_mn = (gd * (xd - mnd - D)).sum() / (D * D)
+        g_mx = -(gd * (xd - mnd)).sum() / (D * D)
+        is_mn, is_mx = x == mn, x == mx
+        out = gd / D + is_mn * (g_mn / is_mn.sum()) + is_mx * (g_mx / is_mx.sum())
+        return out.to(x.dtype)
+
+
+def _minmax_normalise(x):
+    return _MinMaxNormaliseWide.apply(x) if WIDE_SUMS else (x - x.min()) / (x.max() - x.min() + 1e-6)
+
+
 def render_normal_and_disparity(rgba, zbuf):
     """PL:272-289 on the (H,W,4) colour image and (H,W) zbuf of one mesh."""
     alpha = rgba[..., 3]
     mask = alpha > 0.0
     n = rgba[..., :3]
-    nn = (n - n.min()) / (n.max() - n.min() + 1e-6)
+    nn = _minmax_normalise(n)
     nn = torch.where(mask[..., None], nn, torch.zeros_like(nn))
     depth = torch.where(zbuf < 0, torch.full_like(zbuf, 10.0), zbuf)
     disp = 1 / (depth + 1e-6)
-    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-6)
+    disp = _minmax_normalise(disp)
     return nn, disp
 
 

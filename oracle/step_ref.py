@@ -264,15 +264,15 @@ def loss_without_silhouette(phase, scene, params, denoise_i=19, num_inference_st
     return rest.detach(), grads
 
 
-def gradients_with_shifted_sigmoid(phase, scene, params, ulps, denoise_i=19, num_inference_steps=20, grid_res=64):
-    """Gradients of one iteration of `phase` at `params` (no update) with every silhouette sigmoid moved by `ulps` float32
-    ulps (ref_ops.SIGMOID_ULP): how far the reference's OWN gradient moves when its expf rounds the other way -- the
-    conditioning of the comparison, measured.  -> (total, grads)."""
+def gradients_with_wide_sums(phase, scene, params, denoise_i=19, num_inference_steps=20, grid_res=64):
+    """Gradients of one iteration of `phase` at `params` (no update) with the backward sums of the renders' min-max
+    normalisation evaluated in float64 (ref_ops.WIDE_SUMS): forward bit-identical, the two sums through the global extrema
+    exact instead of carrying float32 summation error.  -> (total, grads)."""
     p = leafify(params, PARAM_KEYS)
     ov = scene["obj_verts"].detach().clone().requires_grad_(phase != "A")
     edges = R.unique_edges(scene["obj_faces"])
-    old = R.SIGMOID_ULP
-    R.SIGMOID_ULP = int(ulps)
+    old = R.WIDE_SUMS
+    R.WIDE_SUMS = True
     try:
         if phase == "A":
             total, _, _ = phase_a_loss(scene, p)
@@ -285,7 +285,7 @@ def gradients_with_shifted_sigmoid(phase, scene, params, ulps, denoise_i=19, num
             keys = PARAM_KEYS
         total.backward()
     finally:
-        R.SIGMOID_ULP = old
+        R.WIDE_SUMS = old
     grads = {k: p[k].grad.detach().clone() for k in keys}
     if phase != "A":
         grads["obj_verts"] = ov.grad.detach().clone()

@@ -5,7 +5,7 @@ import numpy as np, torch
 from followmyhold_amd import _lib as L
 L.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")
 from followmyhold_amd import engine as E, synthetic
-sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512, seed=0)
+sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind="20k", H=512, W=512, seed=0, crop=os.environ.get("CROP"))
 NB = int(os.environ.get("NB", "16"))
 gb = E.GuidanceBatch([sc] * NB); cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=False)
 for _ in range(5): gb.step(cfg)

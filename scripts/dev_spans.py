@@ -6,7 +6,7 @@ import numpy as np, torch
 from followmyhold_amd import _lib as L
 L.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")
 from followmyhold_amd import engine as E, synthetic
-sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind=sys.argv[1] if len(sys.argv) > 1 else "20k", H=512, W=512, seed=0)
+sc = synthetic.build_scene(E.hip_render_fn("cuda"), obj_kind=sys.argv[1] if len(sys.argv) > 1 else "20k", H=512, W=512, seed=0, crop=os.environ.get("CROP"))
 phase = sys.argv[2] if len(sys.argv) > 2 else "C"
 cfgu, nr = E.phase_cfg(phase, denoise_i=19, do_update=True)
 gb = E.GuidanceBatch([sc], n_renders=nr)

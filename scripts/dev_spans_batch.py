@@ -8,7 +8,7 @@ L.SO_PATH = os.path.join(ROOT, "followmyhold_amd", "libfoho_hip_stamps.so")
 from followmyhold_amd import engine as E, synthetic
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rf = E.hip_render_fn("cuda")
-scs = [synthetic.build_scene(rf, obj_kind="20k", H=512, W=512, seed=s) for s in range(NB)]
+scs = [synthetic.build_scene(rf, obj_kind="20k", H=512, W=512, seed=s, crop=os.environ.get("CROP")) for s in range(NB)]
 cfgu, nr = E.phase_cfg("C", denoise_i=19, do_update=True)
 gb = E.GuidanceBatch(scs)
 cd = lambda a, b: (a + b - 1) // b

@@ -312,7 +312,7 @@ def _teacher_forced_joint_steps(E, sc, n_steps, max_flipped, max_conditioned=0):
     ids of both renders bit-exact, flags clear; loss 1e-5, parameter gradients 1e-4, vertex gradients 2e-4, updated
     parameters 5e-6 -- on a step that holds a silhouette pixel on the BCE clamp (_clamp_flips) that pixel's own BCE value is
     replaced by the oracle's and everything is compared (_check_clamp_flip_step); a step whose gradients exceed the
-    tolerance must stay within the reference's own sensitivity to one ulp of its sigmoids (max_conditioned such steps)."""
+    tolerance against the float32 oracle must meet it against the oracle with exact normalisation sums (max_conditioned such steps)."""
     sct = _t(sc)
     st = S.JointStepper(sct, S.make_params(), denoise_i=19, grid_res=64)
     gb = E.GuidanceBatch([sc])
@@ -345,21 +345,20 @@ def _teacher_forced_joint_steps(E, sc, n_steps, max_flipped, max_conditioned=0):
         gref = np.concatenate([grads[kk].numpy().reshape(-1) for kk in E.PARAM_NAMES])
         e_g, e_gv = rel(g, gref), rel(gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy())
         if e_g > 1e-4 or e_gv > 2e-4:
-            # Ill-conditioned step of the reference's own arithmetic: a fragment at the rim of the blur radius has
-            # 1 - sigmoid ~ 1e-5, so ONE ulp of the fp32 sigmoid is 0.3 % of its gradient, and the libraries disagree by
-            # an ulp on every tenth expf (crop frames late in the loop: |grad obj_verts| has fallen from 1e5 to ~5 and a
-            # handful of such fragments is what is left of it).  MEASURE it: the oracle's gradient with its silhouette
-            # sigmoids moved one ulp either way bounds what a correct implementation may differ by.
-            cond_g = cond_gv = 0.0
-            for ulps in (1, -1):
-                _, gs = S.gradients_with_shifted_sigmoid("C", sct, p_k, ulps, grid_res=64)
-                cond_g = max(cond_g, rel(np.concatenate([gs[kk].numpy().reshape(-1) for kk in E.PARAM_NAMES]), gref))
-                cond_gv = max(cond_gv, rel(gs["obj_verts"].numpy(), grads["obj_verts"].numpy()))
-            # (a coherent shift can also push an alpha of 1 - 2^-24 onto the BCE clamp and move the gradient by orders of
-            # magnitude -- as a bound that is still valid, only useless, hence the hard cap beside it)
-            assert e_g <= min(max(1e-4, cond_g), 5e-3) and e_gv <= min(max(2e-4, cond_gv), 5e-3), (k, e_g, cond_g, e_gv, cond_gv)
+            # The gradient through the extrema of the min-max normalisation (PL:279, 285) is a sum over all 3 H W normalised
+            # values that lands on ONE face; in the reference's float32 autograd it carries ~1e-3 of summation error (order
+            # dependent: oracle/ref_ops.py WIDE_SUMS), and on crop frames late in the loop -- |grad obj_verts| down from 1e5
+            # to a few units -- that face's three vertices dominate the difference.  The HIP path accumulates those sums
+            # in double precision: it is held, at the SAME tolerance, to the oracle evaluated with exact sums, and the
+            # float32 oracle's own distance to that is asserted to be what explains the excess.
+            _, gw = S.gradients_with_wide_sums("C", sct, p_k, grid_res=64)
+            gwp = np.concatenate([gw[kk].numpy().reshape(-1) for kk in E.PARAM_NAMES])
+            e_g_w, e_gv_w = rel(g, gwp), rel(gb.grad_obj_verts(0).cpu().numpy(), gw["obj_verts"].numpy())
+            own_g, own_gv = rel(gref, gwp), rel(grads["obj_verts"].numpy(), gw["obj_verts"].numpy())
+            assert e_g_w <= 1e-4 and e_gv_w <= 2e-4, (k, e_g, e_g_w, own_g, e_gv, e_gv_w, own_gv)
+            assert e_g <= 1e-4 + 2.0 * own_g and e_gv <= 2e-4 + 2.0 * own_gv, (k, e_g, own_g, e_gv, own_gv)
             conditioned += 1
-            e_g, e_gv = min(e_g, 1e-4), min(e_gv, 2e-4)
+            e_g, e_gv = e_g_w, e_gv_w
         worst["grad"] = max(worst["grad"], e_g)
         worst["gv"] = max(worst["gv"], e_gv)
         after = gb.params[0].cpu().numpy()
