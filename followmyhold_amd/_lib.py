@@ -53,7 +53,8 @@ class FohoStepDesc(ctypes.Structure):
                 ("inc_fc", vp), ("nbr_off", vp), ("nbr_idx", vp), ("J_regressor", vp), ("tgt_normal", vp),
                 ("tgt_disp", vp), ("mask", vp), ("kps_2d", vp), ("params", vp), ("adam_m", vp), ("adam_v", vp),
                 ("adam_t", vp), ("losses", vp), ("grad_params", vp), ("grad_verts_in", vp), ("flags", vp),
-                ("workspace", vp), ("workspace_bytes", ctypes.c_size_t), ("hand_order_valid", c_i)]
+                ("workspace", vp), ("workspace_bytes", ctypes.c_size_t), ("hand_order_valid", c_i),
+                ("hand_faces_per_block", c_i)]
 
 
 # enums of include/foho_hip.h

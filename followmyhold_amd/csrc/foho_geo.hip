@@ -228,6 +228,149 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same GEMM on 256 x 256 x 64 tiles, 8 waves x (128 x 64): per K-tile a wave still issues 8 LDS-DMA pieces, but 64 MFMAs
+// instead of 16 -- on the 128-wide tile the DMA issue (60-180 cycles per piece beside MFMAs) cost as much as the matrix work
+// it fed -- and 6 fragment reads per 8 MFMAs instead of 4 per 4.  128 KB of LDS, one workgroup per CU (two waves per SIMD).
+// N % 256 == 0.  The epilogue's transpose image takes the wave's 128 rows in two halves.
+// ------------------------------------------------------------------------------------------------
+constexpr int HM = 256, HN = 256;
+
+template <int EP>
+__global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
+                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
+                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale) {
+    __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int ntn = N / HN, ntm = (M + HM - 1) / HM;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mp = (j / ntn) * 8 + xcd, nt = j % ntn;
+    if (mp >= ntm) return;
+    const int m0 = mp * HM, n0 = nt * HN;
+    const int wr = w >> 2, wc = w & 3;  // this wave's 128 (M) x 64 (N) part of the tile
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    const h16* asrc[4];
+    const h16* wsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int row = (w * 4 + p) * 8 + srow;
+        const int c = sslot ^ swz(row);
+        asrc[p] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        wsrc[p] = Wt + (size_t)(n0 + row) * ldw + c * 8;
+    }
+
+    f32x16 acc[2][4];  // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const int ra = wr * 128 + l31, rw = wc * 64 + l31;
+    const unsigned base = lds_addr(&lds[0][0][0]);
+    unsigned aa[4], aw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        aa[kk] = base + ra * 128 + (((2 * kk + hi) ^ swz(ra)) << 4);
+        aw[kk] = base + rw * 128 + (((2 * kk + hi) ^ swz(rw)) << 4);
+    }
+
+    const int nk = K / GK;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        glds16(asrc[p], &lds[0][0][(w * 4 + p) * 64]);
+        glds16(wsrc[p], &lds[0][1][(w * 4 + p) * 64]);
+    }
+#define GEO_RD6(set, kq)                                          \
+    do {                                                          \
+        const unsigned pa_ = aa[kq] + bo, pw_ = aw[kq] + bo;      \
+        GEO_DSR(fa[set][0], pa_, 0);                              \
+        GEO_DSR(fa[set][1], pa_, 4096);                           \
+        GEO_DSR(fa[set][2], pa_, 8192);                           \
+        GEO_DSR(fa[set][3], pa_, 12288);                          \
+        GEO_DSR(fw[set][0], pw_, 32768);                          \
+        GEO_DSR(fw[set][1], pw_, 32768 + 4096);                   \
+    } while (0)
+    for (int t = 0; t < nk; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nk) {
+            const int nb = (t + 1) & 1, k0 = (t + 1) * GK;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                glds16(asrc[p] + k0, &lds[nb][0][(w * 4 + p) * 64]);
+                glds16(wsrc[p] + k0, &lds[nb][1][(w * 4 + p) * 64]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(t & 1) << 16;  // 64 KB per buffer
+        half8 fa[2][4], fw[2][2];
+        GEO_RD6(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            if (kk < 3) {
+                GEO_RD6((kk + 1) & 1, kk + 1);
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fa[kk & 1][2]), "+v"(fa[kk & 1][3]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fa[kk & 1][2]), "+v"(fa[kk & 1][3]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][jn], fa[kk & 1][i], acc[jn][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef GEO_RD6
+    __syncthreads();
+
+    h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int nl = jn * 32 + 8 * g + 4 * hi;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + nl);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    half4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float v = acc[jn][2 * half + i][4 * g + q] + b4[q];
+                        if (EP & EP_GELU) v = gelu_erf(v);
+                        v *= scale;
+                        o[q] = (h16)v;
+                    }
+                    *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int ml = q * 8 + (lane >> 3), ch = lane & 7;
+            const int gm = m0 + wr * 128 + half * 64 + ml, gn = n0 + wc * 64 + ch * 8;
+            half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
+            if (gm < M) {
+                if (EP & EP_RESID) {
+                    const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] + (float)r[e]);
+                }
+                *reinterpret_cast<half8*>(C + (size_t)gm * ldc + gn) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second half overwrites the image
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cross attention, head dimension 64: O[M, heads*64] = softmax(Q K^T) V per head, Q pre-scaled by log2(e)/sqrt(64).
 // K rows: Kp + l * ldk + head * 64 (the K half of the KV projection, as the GEMM left it); V: Vt[head][d][pos(l)],
 // transposed, with the keys of every 16-block stored in the order the P fragment holds them (pack_vt below).
@@ -543,10 +686,22 @@ static bool launch_ok(const char* what) {
     return true;
 }
 
+static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
                 int N, int K, float scale, hipStream_t s) {
     if (M <= 0) return FOHO_OK;
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
+    if (N % HN == 0 && K >= 256 && M >= 2048 && !g_force128) {  // the big GEMMs of the chain: 256 x 256 tiles
+        const int ntn = N / HN, ntm = (M + HM - 1) / HM;
+        const dim3 grid(8 * ((ntm + 7) / 8) * ntn), block(512);
+        switch (ep) {
+            case 0: hipLaunchKernelGGL(k_geo_gemm256<0>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+            case EP_GELU: hipLaunchKernelGGL(k_geo_gemm256<EP_GELU>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+            case EP_RESID: hipLaunchKernelGGL(k_geo_gemm256<EP_RESID>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+            default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
+        }
+        return launch_ok("k_geo_gemm256") ? FOHO_OK : FOHO_ERR_LAUNCH;
+    }
     const int ntn = N / GN, ntm = (M + GM - 1) / GM;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn), block(256);
     switch (ep) {
@@ -671,7 +826,10 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
 extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
                              int32_t gelu, float scale, void* stream) {
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
-    if (gelu && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
+    if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
+    g_force128 = (gelu & 2) != 0;
+    struct Reset { ~Reset() { g_force128 = false; } } reset;
+    gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
                 (hipStream_t)stream);
 }

@@ -214,11 +214,13 @@ static inline int raster_faces_per_block(int F, int B = 1) {
     return r;
 }
 // raster workgroups per image (hand blocks, then object blocks): also the number of fragment-list segments per render
-static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& nRh, int& nRo) {
+constexpr int RF_H_MIN = 2;  // fewest hand faces per raster workgroup a caller may ask for: sizes the fragment-list segments
+static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& nRh, int& nRo, int hand_faces = 0) {
     const int Fh_max = d.Fh_max > 0 ? d.Fh_max : d.Fmax, Fo_max = d.Fo_max > 0 ? d.Fo_max : d.Fmax;
     // hand faces are the big ones (tens of pixels each, the palm's up to hundreds): half of that per workgroup (a quarter overfills the chip at one image: a second round of workgroups), so that
     // the workgroup with the largest faces does not set the length of the launch
     rf_h = std::max(2, raster_faces_per_block(Fh_max, d.B) / 2);
+    if (hand_faces > 0) rf_h = std::max(RF_H_MIN, std::min(hand_faces, RF));  // foho_step_desc.hand_faces_per_block
     rf_o = raster_faces_per_block(Fo_max, d.B);
 #ifdef FOHO_STAMPS  // development build: faces per raster workgroup from the environment (sweeps)
     if (const char* e = getenv("FOHO_DEBUG_RFH")) rf_h = std::max(1, std::min(atoi(e), RF));
@@ -249,7 +251,7 @@ static WS make_ws(const foho_dims& d) {
     w.frac_count = take(R * B * 4);
     {
         int rf_h, rf_o, nRh, nRo;
-        raster_blocks(d, rf_h, rf_o, nRh, nRo);
+        raster_blocks(d, rf_h, rf_o, nRh, nRo, RF_H_MIN);  // room for the most workgroups any hand_faces_per_block gives
         w.nseg = nRh + nRo;
     }
     w.seg_count = take(R * B * (size_t)w.nseg * 4);  // entries in every raster workgroup's segment of the fragment list

@@ -245,7 +245,7 @@ class GuidanceBatch:
             for k in range(12):
                 im.T_h2m[k] = float(M[k])
             images.append(im)
-            self.meta.append(dict(v_off=v_off, Vh=Vh, Vo=Vo, f_off=f_off, Fh=Fh, Fo=Fo, n_edges=0))
+            self.meta.append(dict(v_off=v_off, Vh=Vh, Vo=Vo, f_off=f_off, Fh=Fh, Fo=Fo, n_edges=0, fov=float(s["fov"])))
             v_off += Vh + Vo
             f_off += Fh + Fo
         self.Vtot, self.Ftot = v_off, f_off
@@ -416,6 +416,9 @@ class GuidanceBatch:
             d.J_regressor = self.J.data_ptr()
             d.workspace_bytes = self.workspace.numel()
             d.hand_order_valid = int(getattr(self, "_hand_order", None) is not None)   # the table is (re-)uploaded with every workspace
+            # crops (the reference's frames: fov ~ 25 degrees, big hand faces): 2 hand faces per raster workgroup at one image
+            fovs = [float(m["fov"]) for m in self.meta if "fov" in m]
+            d.hand_faces_per_block = 2 if (self.B == 1 and fovs and max(fovs) < 40.0) else 0
             self._desc = d
         return self._desc
 
@@ -493,7 +496,7 @@ class GuidanceBatch:
             hfaces.append(np.asarray(s["hand_faces"], np.int64) + lo)
             faces64[b, :nf] = of
             counts[b, :2] = (nv, nf)
-            m.update(Vo=nv, Fo=nf, n_edges=3 * nf // 2)
+            m.update(Vo=nv, Fo=nf, n_edges=3 * nf // 2, fov=float(s["fov"]))
             im.k00, im.k11 = fov_focal(float(s["fov"]))
             R = np.asarray(s.get("cam_R", np.diag([-1.0, 1.0, -1.0])), np.float32).reshape(-1)
             T = np.asarray(s.get("cam_T", np.zeros(3)), np.float32)

@@ -9,8 +9,8 @@ batch size, guid_config.py:9).  Rasterisation, nearest neighbours and the SDF pi
 torch.autograd.Functions; the glue the reference itself writes in torch (shader blend, normalisation) stays in
 torch ops on the device.  For throughput use followmyhold_amd.engine.GuidanceBatch (the fused step) instead.
 
-Not differentiable here (round 1): the K=100 silhouette alpha (its gradient is zero except within ~0.1 px of an
-edge with sigma = 1e-8; the fused step implements it).
+The K=100 silhouette alpha is differentiable (foho_raster_sil_bwd: through every fragment of the pixels with fractional
+coverage); its sigma comes from the shader's blend_params.
 """
 import math
 from typing import List, Optional, Sequence
@@ -151,18 +151,23 @@ class _RasterFn(torch.autograd.Function):
         out = ops.raster_fwd(verts_ndc, faces, H, W, blur, sigma, want_sil)
         ov = int(out["overflow"].item())
         if (ov & 4) and want_sil:
-            raise ops.L.FohoError("a pixel is covered by more than 100 faces: K=100 silhouette semantics not reproduced")
-        ctx.blur = float(blur)
-        ctx.save_for_backward(verts_ndc.detach(), faces, out["pix_to_face"])
-        ctx.mark_non_differentiable(out["pix_to_face"])
+            # a pixel with 100 fractional-coverage fragments or more has its K = 100 buffer re-built on the device
+            # (kbuffer_fix); this is what is left when even that is beyond its capacities (> 1024 fragments on a pixel, > 32
+            # such pixels)
+            raise ops.L.FohoError("K = 100 silhouette not reproduced: a pixel holds more than 1024 fragments, or more than 32 pixels "
+                                  "hold 100 fractional-coverage fragments")
+        ctx.blur, ctx.sigma = float(blur), float(sigma)
         prod = out["sil_prod"] if want_sil else torch.zeros(0, device=verts_ndc.device)
-        ctx.mark_non_differentiable(prod)
+        ctx.save_for_backward(verts_ndc.detach(), faces, out["pix_to_face"], prod)
+        ctx.mark_non_differentiable(out["pix_to_face"])
         return out["pix_to_face"], out["zbuf"], out["bary"], out["dists"], prod
 
     @staticmethod
     def backward(ctx, g_p2f, g_z, g_b, g_d, g_prod):
-        v, f, p2f = ctx.saved_tensors
+        v, f, p2f, prod = ctx.saved_tensors
         g = ops.raster_bwd(v, f, p2f, g_z, g_b, g_d, blur_radius=ctx.blur)
+        if prod.numel() and g_prod is not None:      # SoftSilhouetteShader's alpha = 1 - prod (RUN:106-116, PL:1341, 1423, 1569)
+            g = g + ops.raster_sil_bwd(v, f, prod, g_prod, ctx.blur, ctx.sigma)
         return g, None, None, None, None, None, None
 
 
@@ -182,7 +187,12 @@ class MeshRasterizer:
         H, W = rs.image_size
         ndc = self.transform(meshes, **kwargs)
         want_sil = rs.faces_per_pixel > 1
-        p2f, z, b, d, prod = _RasterFn.apply(ndc, meshes.faces_packed(), H, W, rs.blur_radius, 1e-8, want_sil)
+        # sigma of the silhouette product: the renderer hands over its shader's blend_params.sigma; a bare rasteriser call
+        # takes the sigma its blur radius was derived from (blur_radius = log(1 / 1e-4 - 1) sigma, RUN:97)
+        sigma = kwargs.get("sigma")
+        if sigma is None:
+            sigma = rs.blur_radius / math.log(1.0 / 1e-4 - 1.0) if rs.blur_radius > 0 else 1e-8
+        p2f, z, b, d, prod = _RasterFn.apply(ndc, meshes.faces_packed(), H, W, rs.blur_radius, float(sigma), want_sil)
         return Fragments(p2f[None, ..., None], z[None, ..., None], b[None, :, :, None, :], d[None, ..., None],
                          prod[None] if want_sil else None)
 
@@ -256,6 +266,9 @@ class MeshRenderer:
         return self
 
     def __call__(self, meshes_world, **kwargs):
+        bp = kwargs.get("blend_params", getattr(self.shader, "blend_params", None))
+        if bp is not None and "sigma" not in kwargs:
+            kwargs = dict(kwargs, sigma=bp.sigma)
         return self.shader(self.rasterizer(meshes_world, **kwargs), meshes_world, **kwargs)
 
 

@@ -67,6 +67,18 @@ def raster_bwd(verts_ndc, faces, pix_to_face, grad_zbuf=None, grad_bary=None, gr
     return g
 
 
+def raster_sil_bwd(verts_ndc, faces, sil_prod, grad_prod, blur_radius, sigma):
+    """Backward of the silhouette product of raster_fwd -> grad w.r.t. verts_ndc (V,3)."""
+    lib = L.lib()
+    v, f = _f32(verts_ndc), faces.detach().to(torch.int32).contiguous()
+    H, W = sil_prod.shape[-2:]
+    g = torch.zeros_like(v)
+    pr, gp = _f32(sil_prod), _f32(grad_prod)
+    L.check(lib.foho_raster_sil_bwd(P(v.data_ptr()), P(f.data_ptr()), v.shape[0], f.shape[0], H, W, P(pr.data_ptr()), P(gp.data_ptr()),
+                                    P(g.data_ptr()), ctypes.c_float(blur_radius), ctypes.c_float(sigma), _stream(v)), "foho_raster_sil_bwd")
+    return g
+
+
 # ------------------------------------------------------------------------------------------------ knn / sdf
 def knn1(p1, p2):
     """pytorch3d.ops.knn_points(K=1): (squared distances (N1,), indices (N1,) int64)."""

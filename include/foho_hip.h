@@ -172,6 +172,12 @@ typedef struct {
     int32_t hand_order_valid;        /* 1: the caller has written a permutation into FOHO_WS_HAND_ORDER (below); 0: the
                                         region is ignored and lanes take hand vertices in index order -- a workspace that
                                         is not zero-filled (plain hipMalloc) is safe with 0                          */
+    int32_t hand_faces_per_block;    /* hand faces per workgroup of the scatter rasteriser: 0 = automatic (4 at one image per
+                                        launch, more in batches); 2 .. 64 = the caller's choice.  The library cannot see how
+                                        large the hand is on screen (images[] lives in device memory): on the reference's
+                                        crops (meshes fill the frame, fov ~ 25 degrees) a hand face covers 7 x the pixels it
+                                        does through a 60 degree lens, and 2 per workgroup is 7 % faster at one image per
+                                        launch (4 is 3 % faster on the wide frames).  Same results either way.       */
 } foho_step_desc;
 
 /* indices into losses[b][*] */
@@ -246,6 +252,14 @@ size_t foho_raster_workspace_bytes(int32_t V, int32_t F, int32_t H, int32_t W);
 int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
                     const float* grad_dists, float* grad_verts_ndc, float blur_radius, void* stream);
+/* backward of sil_prod (version 102): grad_verts_ndc (V,3) += d(sil_prod)/d verts_ndc . grad_prod, i.e. the gradient of
+ * SoftSilhouetteShader's alpha = 1 - sil_prod through every fragment of the pixels with 0 < sil_prod < 1 (the only ones that
+ * carry one: d prod / d sdist_k = prod sigmoid(-sdist_k / sigma) / sigma).  sil_prod: foho_raster_fwd's output; blur_radius and
+ * sigma: that call's.  The product over ALL fragments is differentiated -- identical to the K = 100 product unless a pixel
+ * holds 100 fractional-coverage fragments or more. */
+int foho_raster_sil_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+                        const float* sil_prod, const float* grad_prod, float* grad_verts_ndc, float blur_radius, float sigma,
+                        void* stream);
 /* K=1 nearest neighbour: d2 (N1), idx (N1) int64; ties -> lowest index */
 int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
 
@@ -410,7 +424,8 @@ int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chu
 int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
                         void* workspace, size_t workspace_bytes, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
- * with epilogue = GELU when `gelu`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
+ * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
+ * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.
  * foho_geo_attention: O (M, 64 heads) = softmax(Q K^T) V per head with Q (M, 64 heads) pre-scaled by log2(e) / 8, KV
  * (n_latents, 128 heads) = [K | V] as the projection leaves them, Vt_scratch room for 64 heads x n_latents fp16. */
 int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,

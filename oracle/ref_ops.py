@@ -295,54 +295,16 @@ def render_silhouette(verts_world, faces, cam, sel, sigma=1e-8):
     return alpha.index_put((upix,), a).reshape(H, W)
 
 
-# Conditioning probe for parity tests (never set by the product, which does not import this package).  The min-max
-# normalisation couples every pixel to two global extrema, and autograd sends d loss / d min -- a SUM over all 3 H W
-# normalised values, of mixed sign -- back to the one pixel that attains the extremum (its face's three vertices).  In
-# float32 that sum carries ~1e-3 of relative error whose value depends on the reduction order (torch-CPU, CUDA and any
-# other implementation differ); on crop frames late in the loop, when |grad obj_verts| has fallen to a few units, those three
-# vertices are what is left of the comparison.  WIDE_SUMS = True keeps the forward pass bit-identical and evaluates the two
-# backward sums through the extrema in float64 (_MinMaxNormaliseWide): the HIP path accumulates them in double precision
-# and must agree with THIS to the tolerance; the float32 figure beside it is the reference's own summation error.
-WIDE_SUMS = False
-
-
-class _MinMaxNormaliseWide(torch.autograd.Function):
-    """(x - x.min()) / (x.max() - x.min() + 1e-6): forward exactly as the float32 expression computes it (bit-identical
-    values, so every exact tie downstream -- |render - target| == 0 where the render IS the target -- stays a tie); backward
-    with the two sums through the extrema in float64, distributed evenly over ties like torch's min() / max()."""
-
-    @staticmethod
-    def forward(ctx, x):
-        mn, mx = x.min(), x.max()
-        ctx.save_for_backward(x, mn, mx)
-        return (x - mn) / (mx - mn + 1e-6)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, mn, mx = ctx.saved_tensors
-        xd, gd, mnd, mxd = x.double(), g.double(), mn.double(), mx.double()
-        D = (mx - mn + 1e-6).double()          # the float32 denominator the forward divided by
-        g_mn = (gd * (xd - mnd - D)).sum() / (D * D)
-        g_mx = -(gd * (xd - mnd)).sum() / (D * D)
-        is_mn, is_mx = x == mn, x == mx
-        out = gd / D + is_mn * (g_mn / is_mn.sum()) + is_mx * (g_mx / is_mx.sum())
-        return out.to(x.dtype)
-
-
-def _minmax_normalise(x):
-    return _MinMaxNormaliseWide.apply(x) if WIDE_SUMS else (x - x.min()) / (x.max() - x.min() + 1e-6)
-
-
 def render_normal_and_disparity(rgba, zbuf):
     """PL:272-289 on the (H,W,4) colour image and (H,W) zbuf of one mesh."""
     alpha = rgba[..., 3]
     mask = alpha > 0.0
     n = rgba[..., :3]
-    nn = _minmax_normalise(n)
+    nn = (n - n.min()) / (n.max() - n.min() + 1e-6)
     nn = torch.where(mask[..., None], nn, torch.zeros_like(nn))
     depth = torch.where(zbuf < 0, torch.full_like(zbuf, 10.0), zbuf)
     disp = 1 / (depth + 1e-6)
-    disp = _minmax_normalise(disp)
+    disp = (disp - disp.min()) / (disp.max() - disp.min() + 1e-6)
     return nn, disp
 
 

@@ -262,31 +262,3 @@ def loss_without_silhouette(phase, scene, params, denoise_i=19, num_inference_st
     if phase != "A":
         grads["obj_verts"] = ov.grad.detach().clone()
     return rest.detach(), grads
-
-
-def gradients_with_wide_sums(phase, scene, params, denoise_i=19, num_inference_steps=20, grid_res=64):
-    """Gradients of one iteration of `phase` at `params` (no update) with the backward sums of the renders' min-max
-    normalisation evaluated in float64 (ref_ops.WIDE_SUMS): forward bit-identical, the two sums through the global extrema
-    exact instead of carrying float32 summation error.  -> (total, grads)."""
-    p = leafify(params, PARAM_KEYS)
-    ov = scene["obj_verts"].detach().clone().requires_grad_(phase != "A")
-    edges = R.unique_edges(scene["obj_faces"])
-    old = R.WIDE_SUMS
-    R.WIDE_SUMS = True
-    try:
-        if phase == "A":
-            total, _, _ = phase_a_loss(scene, p)
-            keys = ["scale_hand", "trans_hand", "rot_hand"]
-        elif phase == "B":
-            total, _, _ = phase_b_loss(scene, p, ov, edges)
-            keys = ["scale_obj", "trans_obj", "rot_obj"]
-        else:
-            total, _, _ = phase_c_loss(scene, p, ov, edges, denoise_i, num_inference_steps, grid_res=grid_res)
-            keys = PARAM_KEYS
-        total.backward()
-    finally:
-        R.WIDE_SUMS = old
-    grads = {k: p[k].grad.detach().clone() for k in keys}
-    if phase != "A":
-        grads["obj_verts"] = ov.grad.detach().clone()
-    return total.detach(), grads

@@ -85,7 +85,7 @@ def test_struct_layouts_match_the_header(lib):
     assert ctypes.sizeof(L.FohoDims) == 15 * 4
     assert ctypes.sizeof(L.FohoRenderCfg) == 7 * 4
     assert ctypes.sizeof(L.FohoStepCfg) == 2 * 28 + 7 * 4 + 4 + 3 * 4 + 4 + 3 * 4 + 16 * 4 + 4 * 4 + 4 + 4 + 4 + 4 + 4
-    assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8 + 8          # hand_order_valid + tail padding
+    assert ctypes.sizeof(L.FohoStepDesc) == 64 + 21 * 8 + 8 + 8          # hand_order_valid + hand_faces_per_block
     # ... and the library this binding loads was built from the same layout (the check _lib.lib() makes at load time)
     sizes = (ctypes.c_int64 * 5)()
     lib.foho_abi_sizes.restype = ctypes.c_int
