@@ -43,12 +43,15 @@ MIN_TIMED_S = 0.25     # the timed region of --steps iterations is repeated unti
 # committed rocprofv3 summaries, by workload (object kind, image size, images per GPU): PMC traffic and kernel trace are only
 # attached to a record of the SAME workload (images per LAUNCH: the b8 files are one 8-image batch on one stream) --
 # another object / size / batch gets null, never a borrowed number
-PMC_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_pmc_fetch_write_b1.csv"),
-                              os.path.join("profiles", "r02_rocprofv3_pmc_fetch_write_b1.csv")],
-            ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_pmc_fetch_write_b8.csv")]}
-KSTATS_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_kernel_stats_bench_b1.csv"),
-                                 os.path.join("profiles", "r02_rocprofv3_kernel_stats_bench_b1.csv")],
-               ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_kernel_stats_bench_b8_1stream.csv")]}
+def _prof(name):
+    """Committed rocprofv3 summaries of a workload, newest round first."""
+    return [os.path.join("profiles", f"{r}_{name}") for r in ("r04", "r03", "r02")]
+
+
+PMC_CSVS = {("20k", 512, 1): _prof("rocprofv3_pmc_fetch_write_b1.csv"), ("20k", 512, 8): _prof("rocprofv3_pmc_fetch_write_b8.csv")}
+KSTATS_CSVS = {("20k", 512, 1): _prof("rocprofv3_kernel_stats_bench_b1.csv"), ("20k", 512, 8): _prof("rocprofv3_kernel_stats_bench_b8_1stream.csv")}
+SQ_CSVS = {("20k", 512, 1): _prof("rocprofv3_sq_counters_b1.csv"), ("20k", 512, 8): _prof("rocprofv3_sq_counters_b8_1stream.csv")}
+VALU_PEAK_CYCLES_PER_S = 1024 * 2.4e9     # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock: busy SIMD cycles the chip can offer per second
 
 
 def algorithmic_bytes(H, W, Vh, Vo, Fh, Fo):
@@ -107,8 +110,37 @@ def pmc_table(workload):
     return {}, None
 
 
-EA_CSVS = {("20k", 512, 1): [os.path.join("profiles", "r03_rocprofv3_ea_requests_b1.csv")],
-           ("20k", 512, 8): [os.path.join("profiles", "r03_rocprofv3_ea_requests_b8.csv")]}
+EA_CSVS = {("20k", 512, 1): _prof("rocprofv3_ea_requests_b1.csv"), ("20k", 512, 8): _prof("rocprofv3_ea_requests_b8.csv")}
+
+
+def sq_table(workload):
+    """({kernel: {counter: mean per launch}}, file) from the committed SQ-counter passes of THIS workload."""
+    import csv
+    for rel in SQ_CSVS.get(workload, []):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        out = {}
+        for r in csv.DictReader(open(path)):
+            out.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_launch"])
+        return out, rel
+    return {}, None
+
+
+def valu_roofline(sq, kernel_ms, images):
+    """The vector-ALU side of the roofline, per kernel: busy SIMD cycles of one launch (SQ_ACTIVE_INST_VALU counts quad-cycles
+    in which a VALU instruction issues, x 4) over the SIMD cycles the chip offers during the launch's LIVE duration (1024
+    SIMDs at the 2.4 GHz peak clock), and the wave-instruction counts behind them.  The counters come from the committed
+    profile of the same workload (a profiled launch runs the same instructions), the durations from this run."""
+    out = {}
+    for k, ms in kernel_ms.items():
+        c = sq.get(k)
+        if not c or "SQ_ACTIVE_INST_VALU" not in c or ms <= 0:
+            continue
+        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"]
+        out[k] = {"valu_wave_instructions": round(c.get("SQ_INSTS_VALU", 0.0)), "valu_busy_simd_cycles": round(busy),
+                  "valu_frac": busy / (ms * 1e-3 * VALU_PEAK_CYCLES_PER_S), "wait_frac": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None}
+    return out
 
 
 def ea_table(workload):
@@ -370,6 +402,19 @@ def main():
                            "traffic_by_request_size": ea.get(dom), "traffic_by_request_size_source": ea_src,
                            "kernel_ms": acc[dom], "kernel_ms_median": med[dom], "algorithmic_bytes_per_launch": kb * ipb,
                            "dominant_by_trace": prof_dom, "trace_source": prof_src}
+        sq, sq_src = sq_table(workload)
+        vr = valu_roofline(sq, acc, ipb)
+        if vr:
+            tot_busy = sum(v["valu_busy_simd_cycles"] for v in vr.values())
+            out["roofline_valu"] = {"bound": "valu-issue", "kernel": dom, "frac": vr.get(dom, {}).get("valu_frac"), "kernels": vr,
+                                    "step_valu_wave_instructions": sum(v["valu_wave_instructions"] for v in vr.values()),
+                                    "step_valu_frac": tot_busy / ipb * value / world / VALU_PEAK_CYCLES_PER_S, "source": sq_src,
+                                    "peak": "1024 SIMDs x 2.4 GHz busy cycles/s (SQ_ACTIVE_INST_VALU x 4 per launch / live duration)"}
+            hb, vf = out["roofline"]["frac"], vr.get(dom, {}).get("valu_frac") or 0.0
+            # what binds: neither roof is near at one image per launch -- the kernels wait (wait_frac) on chains of dependent
+            # round trips; the record says so instead of letting "bound": "hbm" stand alone
+            out["roofline"]["binding"] = (f"latency: {dom} uses {hb:.3f} of the HBM roof and {vf:.3f} of the VALU-issue roof, "
+                                          f"its waves wait {vr.get(dom, {}).get('wait_frac') or 0:.2f} of their life (SQ_WAIT_ANY)")
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
         out["kernel_ms_median"] = {k: round(v, 5) for k, v in med.items()}
         out["hit_pixels"] = hits
@@ -436,22 +481,17 @@ def valu_record(args, image_steps_per_s):
     (SQ_ACTIVE_INST_VALU x 4 = busy SIMD cycles, committed under profiles/) against 1024 SIMDs at the 2.4 GHz peak clock."""
     if (args.obj, args.size) != ("20k", 512):
         return {}
-    rel = "profiles/r03_rocprofv3_sq_counters_b8_1stream.csv"
-    try:
-        import csv
-        busy = insts = 0.0
-        for r in csv.DictReader(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel))):
-            if r["kernel"] in STEP_KERNELS:
-                if r["counter"] == "SQ_ACTIVE_INST_VALU":
-                    busy += 4.0 * float(r["mean_per_launch"])
-                elif r["counter"] == "SQ_INSTS_VALU":
-                    insts += float(r["mean_per_launch"])
-    except OSError:
-        return {}
+    sq, rel = sq_table((args.obj, args.size, 8))
+    busy = sum(4.0 * sq[k].get("SQ_ACTIVE_INST_VALU", 0.0) for k in STEP_KERNELS if k in sq)
+    insts = sum(sq[k].get("SQ_INSTS_VALU", 0.0) for k in STEP_KERNELS if k in sq)
     if busy <= 0:
         return {}
-    return {"valu_instructions_per_image_step": round(insts / 8.0), "valu_issue_frac": busy / 8.0 * image_steps_per_s / (1024 * 2.4e9),
-            "valu_source": rel + " (SQ_ACTIVE_INST_VALU x 4 busy SIMD cycles per 8-image step)"}
+    per_kernel = {k: round(sq[k].get("SQ_INSTS_VALU", 0.0) / 8.0) for k in STEP_KERNELS if k in sq}
+    return {"valu_instructions_per_image_step": round(insts / 8.0), "valu_issue_frac": busy / 8.0 * image_steps_per_s / VALU_PEAK_CYCLES_PER_S,
+            "valu_instructions_per_image_step_by_kernel": per_kernel,
+            "roofline_valu": {"bound": "valu-issue", "frac": busy / 8.0 * image_steps_per_s / VALU_PEAK_CYCLES_PER_S,
+                              "peak": "1024 SIMDs x 2.4 GHz busy cycles/s"},
+            "valu_source": f"{rel} (SQ_ACTIVE_INST_VALU x 4 busy SIMD cycles per 8-image step)"}
 
 
 def batched_record(E, torch, synthetic, render_fn, args, dev, cfg, n_img=8, steps=200, gbuf_f16=False):
