@@ -393,6 +393,7 @@ __device__ __forceinline__ float other_half(float x) {
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32: arguments are <= 6, underflow to 0 is what is wanted
 
+template <bool NEGM>
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
                                                      int heads) {
@@ -443,13 +444,14 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
 #pragma unroll
     for (int a = 0; a < 2; a++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) negm[a][r] = 0.0f;
+        for (int r = 0; r < 16; r++) negm[a][r] = 0.0f;   // (NEGM = false: stays zero and folds into the MFMA's constant operand)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[a][b][r] = 0.0f;
     }
     float lsum[2] = {0.0f, 0.0f};
+    float mrun[2] = {0.0f, 0.0f};  // NEGM = false: the running max as a scalar per query, subtracted in the exponent
 
     const int nt = L / AK;
     ATT_GLOAD(0);
@@ -459,25 +461,19 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         if (t + 1 < nt) ATT_GLOAD(t + 1);
         const uint4* lk = lds[t & 1][0];
         const uint4* lv = lds[t & 1][1];
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            // ---- S^T - m (32 keys x 32 queries per query block) = K Q^T - m
-            half8 kf[4];
+        // A tile is four UNITS (32 keys x 32 queries): (sub-tile, query block) = (0,0) (0,1) (1,0) (1,1).  Per unit: QK (4 MFMAs)
+        // -> softmax (VALU) -> PV (4 MFMAs).  They are issued SKEWED -- the QK of unit u+1 goes out before the softmax of unit u,
+        // whose PV follows it -- so that every softmax has independent matrix work in flight beside it (an in-order wave
+        // cannot overlap its own VALU with MFMAs that come later in program order).
+        auto kfrag = [&](int sub, half8* kf) {
             const int krow = sub * 32 + l31;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const uint4 u = lk[krow * 8 + ((2 * kk + hi) ^ swz(krow))];
                 kf[kk] = *reinterpret_cast<const half8*>(&u);
             }
-            f32x16 s[2];
-#pragma unroll
-            for (int qb = 0; qb < 2; qb++) {
-                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
-#pragma unroll
-                for (int kk = 1; kk < 4; kk++) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], s[qb], 0, 0, 0);
-            }
-            // ---- V^T fragments of this sub-tile: A operand, rows d, 16 keys per MFMA
-            half8 vf[2][2];
+        };
+        auto vfrag = [&](int sub, half8 (*vf)[2]) {
 #pragma unroll
             for (int dt = 0; dt < 2; dt++) {
                 const int vrow = dt * 32 + l31;
@@ -487,57 +483,88 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                     vf[dt][k2] = *reinterpret_cast<const half8*>(&u);
                 }
             }
-            // ---- online softmax in the log2 domain; a query's 32 scores sit in two lanes (l31, hi = 0 / 1), 16 registers each
-            const bool first = (t == 0) && (sub == 0);
+        };
+        auto qk = [&](const half8* kf, int qb) {
+            f32x16 r;
+            if (NEGM) {
+                r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
+            } else {
+                f32x16 z;
 #pragma unroll
-            for (int qb = 0; qb < 2; qb++) {
-                // max of the lane's 16 scores (already relative to the running max).  The other half-wave holds the query's
-                // other 16: it is only consulted when somebody's maximum has to move (one ballot decides)
-                float tm = max3(s[qb][0], s[qb][1], s[qb][2]);
-                tm = max3(tm, s[qb][3], s[qb][4]);
-                tm = max3(tm, s[qb][5], s[qb][6]);
-                tm = max3(tm, s[qb][7], s[qb][8]);
-                tm = max3(tm, s[qb][9], s[qb][10]);
-                tm = max3(tm, s[qb][11], s[qb][12]);
-                tm = max3(tm, s[qb][13], s[qb][14]);
-                tm = fmaxf(tm, s[qb][15]);
-                if (first || __any(tm > RESCALE_THR)) {
-                    // raise the running max (the first sub-tile SETS it: there it may also fall below the initial 0) and rescale
-                    // what is accumulated -- rare after the first tiles: the max only moves when a score exceeds it by 2^6
-                    tm = fmaxf(tm, other_half(tm));
-                    const float up = first ? tm : fmaxf(tm, 0.0f);
-                    const float alpha = ex2(-up);
-                    lsum[qb] *= alpha;
+                for (int e = 0; e < 16; e++) z[e] = 0.0f;
+                r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 1; kk < 4; kk++) r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], r, 0, 0, 0);
+            return r;
+        };
+        // online softmax of one unit in the log2 domain (a query's 32 scores sit in two lanes, 16 registers each), then O^T += V^T P^T
+        auto sm_pv = [&](f32x16& sc, int qb, const half8 (*vf)[2], bool first) {
+            float tm = max3(sc[0], sc[1], sc[2]);
+            tm = max3(tm, sc[3], sc[4]);
+            tm = max3(tm, sc[5], sc[6]);
+            tm = max3(tm, sc[7], sc[8]);
+            tm = max3(tm, sc[9], sc[10]);
+            tm = max3(tm, sc[11], sc[12]);
+            tm = max3(tm, sc[13], sc[14]);
+            tm = fmaxf(tm, sc[15]);
+            if (!NEGM) tm -= mrun[qb];
+            // the other half-wave holds the query's other 16 scores: it is only consulted when somebody's maximum has to move
+            if (first || __any(tm > RESCALE_THR)) {
+                // raise the running max (the first unit SETS it: there it may also fall below the initial 0) and rescale what is
+                // accumulated -- rare after the first tiles: the max only moves when a score exceeds it by 2^6
+                tm = fmaxf(tm, other_half(tm));
+                const float up = first ? tm : fmaxf(tm, 0.0f);
+                const float alpha = ex2(-up);
+                lsum[qb] *= alpha;
+                if (NEGM) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        s[qb][r] -= up;
+                        sc[r] -= up;
                         negm[qb][r] -= up;
                     }
-#pragma unroll
-                    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) o[qb][dt][r] *= alpha;
+                } else {
+                    mrun[qb] += up;
                 }
-                half8 pf[2];
-                float ls = 0.0f;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; k2++)
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const float p0 = ex2(s[qb][8 * k2 + e]), p1 = ex2(s[qb][8 * k2 + e + 1]);
-                        ls += p0 + p1;
-                        const f32x2 pp = {p0, p1};
-                        const half2v ph = __builtin_convertvector(pp, half2v);
-                        pf[k2][e] = ph[0];
-                        pf[k2][e + 1] = ph[1];
-                    }
-                lsum[qb] += ls;
-                // ---- O^T += V^T P^T
 #pragma unroll
                 for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-                    for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
+                    for (int r = 0; r < 16; r++) o[qb][dt][r] *= alpha;
             }
+            half8 pf[2];
+            float ls = 0.0f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float p0 = ex2(NEGM ? sc[8 * k2 + e] : sc[8 * k2 + e] - mrun[qb]);
+                    const float p1 = ex2(NEGM ? sc[8 * k2 + e + 1] : sc[8 * k2 + e + 1] - mrun[qb]);
+                    ls += p0 + p1;
+                    const f32x2 pp = {p0, p1};
+                    const half2v ph = __builtin_convertvector(pp, half2v);
+                    pf[k2][e] = ph[0];
+                    pf[k2][e + 1] = ph[1];
+                }
+            lsum[qb] += ls;
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
+        };
+        {
+            half8 kf0[4], kf1[4], vf0[2][2], vf1[2][2];
+            kfrag(0, kf0);
+            f32x16 sA = qk(kf0, 0);      // unit 0
+            f32x16 sB = qk(kf0, 1);      // unit 1's scores are under way while unit 0 is exponentiated
+            vfrag(0, vf0);
+            kfrag(1, kf1);
+            sm_pv(sA, 0, vf0, t == 0);
+            sA = qk(kf1, 0);             // unit 2
+            sm_pv(sB, 1, vf0, t == 0);
+            sB = qk(kf1, 1);             // unit 3
+            vfrag(1, vf1);
+            sm_pv(sA, 0, vf1, false);
+            sm_pv(sB, 1, vf1, false);
         }
         if (t + 1 < nt) ATT_LWRITE((t + 1) & 1);  // that buffer was last read in iteration t - 1, before the barrier every wave passed
         __syncthreads();
@@ -686,6 +713,7 @@ static bool launch_ok(const char* what) {
     return true;
 }
 
+static int g_attn_variant = 0;   // development: foho_geo_debug_variant()
 static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
                 int N, int K, float scale, hipStream_t s) {
@@ -804,7 +832,10 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
         if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
         if (int rc = gemm(0, bB, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, bC, W, M, W, W, qscale, s)) return rc;
         // attention over the latent tokens                                           C -> B
-        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
+        if (g_attn_variant == 0)
+            hipLaunchKernelGGL(k_geo_attn<true>, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
+        else
+            hipLaunchKernelGGL(k_geo_attn<false>, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
         if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
         // x1 = x0 + c_proj(attn)                                                      B (+A) -> C
         if (int rc = gemm(EP_RESID, bB, W, (const h16*)w->w_proj, W, w->b_proj, bA, W, bC, W, M, W, W, 1.0f, s)) return rc;
@@ -821,6 +852,8 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
     }
     return FOHO_OK;
 }
+
+extern "C" void foho_geo_debug_variant(int attn) { g_attn_variant = attn; }   // development only (not in the header)
 
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
 extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
@@ -842,7 +875,11 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
-    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
-                       n_latents, (h16*)O, W, M, heads);
+    if (g_attn_variant == 0)
+        hipLaunchKernelGGL(k_geo_attn<true>, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W,
+                           (const h16*)Vt_scratch, n_latents, (h16*)O, W, M, heads);
+    else
+        hipLaunchKernelGGL(k_geo_attn<false>, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W,
+                           (const h16*)Vt_scratch, n_latents, (h16*)O, W, M, heads);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
