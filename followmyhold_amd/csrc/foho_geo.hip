@@ -393,7 +393,6 @@ __device__ __forceinline__ float other_half(float x) {
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32: arguments are <= 6, underflow to 0 is what is wanted
 
-template <bool NEGM>
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
                                                      int heads) {
@@ -444,14 +443,13 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
 #pragma unroll
     for (int a = 0; a < 2; a++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) negm[a][r] = 0.0f;   // (NEGM = false: stays zero and folds into the MFMA's constant operand)
+        for (int r = 0; r < 16; r++) negm[a][r] = 0.0f;
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) o[a][b][r] = 0.0f;
     }
     float lsum[2] = {0.0f, 0.0f};
-    float mrun[2] = {0.0f, 0.0f};  // NEGM = false: the running max as a scalar per query, subtracted in the exponent
 
     const int nt = L / AK;
     ATT_GLOAD(0);
@@ -485,15 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
             }
         };
         auto qk = [&](const half8* kf, int qb) {
-            f32x16 r;
-            if (NEGM) {
-                r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
-            } else {
-                f32x16 z;
-#pragma unroll
-                for (int e = 0; e < 16; e++) z[e] = 0.0f;
-                r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], z, 0, 0, 0);
-            }
+            f32x16 r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
 #pragma unroll
             for (int kk = 1; kk < 4; kk++) r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], r, 0, 0, 0);
             return r;
@@ -508,7 +498,6 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
             tm = max3(tm, sc[11], sc[12]);
             tm = max3(tm, sc[13], sc[14]);
             tm = fmaxf(tm, sc[15]);
-            if (!NEGM) tm -= mrun[qb];
             // the other half-wave holds the query's other 16 scores: it is only consulted when somebody's maximum has to move
             if (first || __any(tm > RESCALE_THR)) {
                 // raise the running max (the first unit SETS it: there it may also fall below the initial 0) and rescale what is
@@ -517,14 +506,10 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                 const float up = first ? tm : fmaxf(tm, 0.0f);
                 const float alpha = ex2(-up);
                 lsum[qb] *= alpha;
-                if (NEGM) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        sc[r] -= up;
-                        negm[qb][r] -= up;
-                    }
-                } else {
-                    mrun[qb] += up;
+                for (int r = 0; r < 16; r++) {
+                    sc[r] -= up;
+                    negm[qb][r] -= up;
                 }
 #pragma unroll
                 for (int dt = 0; dt < 2; dt++)
@@ -537,8 +522,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
             for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const float p0 = ex2(NEGM ? sc[8 * k2 + e] : sc[8 * k2 + e] - mrun[qb]);
-                    const float p1 = ex2(NEGM ? sc[8 * k2 + e + 1] : sc[8 * k2 + e + 1] - mrun[qb]);
+                    const float p0 = ex2(sc[8 * k2 + e]), p1 = ex2(sc[8 * k2 + e + 1]);
                     ls += p0 + p1;
                     const f32x2 pp = {p0, p1};
                     const half2v ph = __builtin_convertvector(pp, half2v);
@@ -713,7 +697,6 @@ static bool launch_ok(const char* what) {
     return true;
 }
 
-static int g_attn_variant = 0;   // development: foho_geo_debug_variant()
 static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
                 int N, int K, float scale, hipStream_t s) {
@@ -832,10 +815,7 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
         if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
         if (int rc = gemm(0, bB, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, bC, W, M, W, W, qscale, s)) return rc;
         // attention over the latent tokens                                           C -> B
-        if (g_attn_variant == 0)
-            hipLaunchKernelGGL(k_geo_attn<true>, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
-        else
-            hipLaunchKernelGGL(k_geo_attn<false>, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
+        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
         if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
         // x1 = x0 + c_proj(attn)                                                      B (+A) -> C
         if (int rc = gemm(EP_RESID, bB, W, (const h16*)w->w_proj, W, w->b_proj, bA, W, bC, W, M, W, W, 1.0f, s)) return rc;
@@ -852,8 +832,6 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
     }
     return FOHO_OK;
 }
-
-extern "C" void foho_geo_debug_variant(int attn) { g_attn_variant = attn; }   // development only (not in the header)
 
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
 extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
@@ -875,11 +853,7 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
-    if (g_attn_variant == 0)
-        hipLaunchKernelGGL(k_geo_attn<true>, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W,
-                           (const h16*)Vt_scratch, n_latents, (h16*)O, W, M, heads);
-    else
-        hipLaunchKernelGGL(k_geo_attn<false>, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W,
-                           (const h16*)Vt_scratch, n_latents, (h16*)O, W, M, heads);
+    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
+                       n_latents, (h16*)O, W, M, heads);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }

@@ -28,8 +28,6 @@ if "--parts" in sys.argv:
         torch.cuda.synchronize(); dtt = (time.perf_counter() - t0) / 20
         print(f"gemm M={M} N={N} K={K} gelu={gelu}: {dt * 1e6:.1f} us = {2 * M * N * K / dt / 1e12:.0f} TFLOP/s (torch linear {dtt * 1e6:.1f} us = {2 * M * N * K / dtt / 1e12:.0f})", flush=True)
     Lk, H = 3072, 16
-    if os.environ.get("GEO_ATTN_VARIANT"):
-        lib.foho_geo_debug_variant(int(os.environ["GEO_ATTN_VARIANT"]))
     q = torch.randn(M, 1024, device=dev).half(); kv = torch.randn(Lk, 2048, device=dev).half()
     O = torch.empty(M, 1024, dtype=torch.float16, device=dev); vt = torch.empty(1024 * Lk, dtype=torch.float16, device=dev)
     for _ in range(3):
