@@ -543,6 +543,8 @@ class GuidanceBatch:
             up("tgt_disp", self.tgt_disp, per_image(lambda s: s["moge_disp"]))
         up("mask", self.mask, per_image(lambda s: np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1)))
         up("kps", self.kps_2d, per_image(lambda s: s["kps_2d"]))
+        # the joint regressor is shared by the batch (foho_step_desc.J_regressor): the new image set's, not the first set's
+        up("J", self.J, put(np.asarray(scenes[0]["J_regressor"], np.float32)))
         up("params", self.params, put(np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1))))
         vh_max = max(int(self.dims.Vh_max), 1)
 
@@ -726,17 +728,15 @@ class GuidanceBatch:
         return dict(zip(L.LOSS_NAMES, l))
 
     def raise_on_flags(self, strict_k=True):
-        """bit1: fractional-fragment list overflow, bit2: a pixel holds at least 100 fractional-coverage fragments, the only
-        situation in which the silhouette over all fragments could differ from the reference's 100 nearest ones; bit3: a
-        face straddling the near plane z = znear / 2 was culled where pytorch3d's clip_faces would have split it.
+        """bit1: fractional-fragment list overflow; bit2: the K = 100 buffer of a pixel with 100 fractional-coverage fragments
+        or more could not be re-built on the device (more than 1024 fragments on the pixel, or more than 32 such pixels in a
+        render): the silhouette over all fragments may then differ from the reference's 100 nearest ones; bits 4-6: capacity
+        mode (foho_object_update).  (Bit 3 is retired: faces across the near plane are clipped like pytorch3d clips them.)
         Fails loudly instead of deviating; strict_k=False downgrades bit2 to a warning (a collapsing object -- thousands
         of sub-pixel faces on one pixel -- is outside any regime where the K=100 cut-off is meaningful)."""
         f = self.flags.detach().cpu().numpy()
         if (f & 2).any():
             raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
-        if (f & 8).any():
-            raise L.FohoError("a face crosses the near plane z = znear / 2 (images "
-                              f"{np.flatnonzero(f & 8).tolist()}): near-plane clipping is not implemented")
         if (f & 16).any():
             raise L.FohoError(f"object capacity exceeded (images {np.flatnonzero(f & 16).tolist()}): enlarge obj_capacity")
         if (f & 64).any():
@@ -745,7 +745,7 @@ class GuidanceBatch:
             raise L.FohoError(f"object mesh is not a closed 2-manifold (images {np.flatnonzero(f & 32).tolist()}): the on-device "
                               "edge tables assume it; use the exact-size path (GuidanceBatch.objective)")
         if (f & 4).any():
-            msg = "a pixel holds 100+ fractional-coverage fragments: K=100 silhouette semantics not reproduced"
+            msg = "K = 100 silhouette not reproduced: more than 1024 fragments on a pixel, or more than 32 pixels with 100+ fractional-coverage fragments"
             if strict_k:
                 raise L.FohoError(msg)
             import warnings

@@ -66,6 +66,11 @@ def _cat_recursive(*parts, dtype):
     return {k: _cat_recursive(*[p[k] for p in parts], dtype=dtype) for k in parts[0].keys()}
 
 
+class BatchLeftFastPath(RuntimeError):
+    """An image of a `call_batch` batch needs the per-image handling of `__call__` (empty / non-manifold / over-capacity
+    iso-surface, NaN loss)."""
+
+
 class GuidedShapePipeline:
     """Drop-in for `Hunyuan3DDiTFlowMatchingPipeline_main`: same constructor (PL:563-585), same `__call__` signature and
     return value (PL:1044-1072, 1679)."""
@@ -134,6 +139,149 @@ class GuidedShapePipeline:
         images = torch.cat(images, dim=0).to(self.device, dtype=self.dtype)
         masks = torch.cat(masks, dim=0).to(self.device, dtype=self.dtype) if masks[0] is not None else None
         return images, masks
+
+    # ------------------------------------------------------------------ B images through one pass of the schedule
+    @torch.no_grad()
+    def call_batch(self, images, paths, generators=None, guidance_scale=7.5, num_chunks=8000, config=None, renderer=None,
+                   J_regressor=None, guidance_octree_resolution=64, final_octree_resolution=384, obj_capacity=None):
+        """`__call__` for B images at once ("within a GPU, batch the rank's images through each kernel
+        launch").  The reference runs its images one after the other (RUN:208-259, batch_size = 1, guid_config.py:9); here
+        one pass of the 20-step schedule serves all of them: the DiT and the ShapeVAE transformer run on B latents, the
+        optimisation-in-the-loop iterations run as ONE capacity-mode GuidanceBatch of B slots -- per iteration one hipGraph
+        replay of iso-surfacing, object installation, fused step and iso-surface backward for all B (engine.SdfObjective) --
+        and one AdamW over the (B, L, D) noise prediction (element-wise: B independent optimisers).
+
+        images: list of B images (as `__call__` takes one); paths: list of B dicts with `__call__`'s eight path arguments;
+        generators: list of B torch.Generators (default: every image seeded with 2, RUN:120, 144).  All images must share
+        H x W.  -> list of B (object Meshes, hand Meshes) in the MoGe world.
+
+        Raises BatchLeftFastPath when an image needs what only the one-image path offers -- an empty / non-manifold /
+        over-capacity iso-surface (PL:1394-1397, 1511-1513) or a NaN loss (PL:1442-1444, 1590-1592), whose handling is per
+        image in the reference: the caller re-runs the batch's images through `__call__`."""
+        B = len(images)
+        device, dtype = self.device, self.dtype
+        cfg0 = config() if config is not None else E.OptimizationConfig()
+        self.stats = stats = {"inner_iterations": 0, "images": B}
+        do_cfg = guidance_scale >= 0 and not (getattr(self.model, "guidance_embed", False) is True)
+        img, msk = self.prepare_image(list(images))
+        cond = self.encode_cond(image=img, mask=msk, do_classifier_free_guidance=do_cfg, dual_guidance=False)
+        guid_res = int(guidance_octree_resolution)
+        bmin, bmax = np.full(3, -1.10), np.full(3, 1.10)
+
+        def grid(res):
+            xyz_np, gsz, _ = generate_dense_grid_points(bmin, bmax, octree_depth=5, octree_resolution=res, indexing="ij")
+            return torch.as_tensor(xyz_np, dtype=torch.float32, device=device), gsz
+
+        xyz_samples, grid_size = grid(guid_res)
+        n_steps = cfg0.num_inference_steps
+        timesteps, n_steps_obj = retrieve_timesteps(self.scheduler, n_steps, device, sigmas=np.linspace(0, 1, n_steps))
+        guidance = None
+        if getattr(self.model, "guidance_embed", False) is True:
+            guidance = torch.tensor([guidance_scale] * B, device=device, dtype=dtype)
+        self.model.eval()
+        self.vae.eval()
+        if generators is None:
+            generators = [torch.Generator().manual_seed(2) for _ in range(B)]
+        latents = torch.cat([self.prepare_latents(1, dtype, device, g) for g in generators], 0).clone()
+
+        fov = float(renderer.rasterizer.cameras.fov) if renderer is not None else None
+        jr = inputs.load_j_regressor() if J_regressor is None else np.asarray(J_regressor, np.float32)
+        scenes = []
+        for p_ in paths:
+            q = dict(cropped_hand_mask_path=p_["hand_mask_path"], cropped_obj_mask_path=p_["obj_mask_path"], moge_mesh_path=p_["moge_mesh_path"],
+                     moge_fov_path=os.path.join(os.path.dirname(p_["moge_mesh_path"]), "fov.json"), T_h2m_path=p_["h2m_rt_path"],
+                     aligned_mano_mesh_path=p_["aligned_mano_mesh_path"], hamer_for_guid_path=p_["hamer_for_guid_path"])
+            scenes.append(inputs.load_scene_from_files(q, jr, E.hip_render_fn(device), fov=fov, with_object=False))
+        cap = tuple(obj_capacity) if obj_capacity else (8 * guid_res * guid_res, 16 * guid_res * guid_res)
+        gb = E.GuidanceBatch(scenes, device=device, grid_res=guid_res, n_renders=2, obj_capacity=cap)
+        fobj = E.SdfObjective(gb, xyz_samples, guid_res)
+        T_h2m = [torch.as_tensor(sc["T_h2m"], dtype=torch.float32, device=device) for sc in scenes]
+        hand_moge = [torch.as_tensor(sc["hand_verts"], dtype=torch.float32, device=device) for sc in scenes]
+        hand_faces = [torch.as_tensor(sc["hand_faces"], dtype=torch.int64, device=device) for sc in scenes]
+
+        def sdf_of(x1, xyz, gsz):
+            """latent2sdf (PL:292-313) for B latents: the VAE transformer on all of them, the geometry decoder per image."""
+            pred = self.vae(1 / self.vae.scale_factor * x1)
+            out = []
+            for b in range(x1.shape[0]):
+                logits = [self.vae.geo_decoder(xyz[s0:s0 + num_chunks].half().unsqueeze(0), pred[b:b + 1]) for s0 in range(0, xyz.shape[0], num_chunks)]
+                out.append(-torch.cat(logits, dim=1).view(-1).float())
+            return torch.stack(out, 0)
+
+        def latent_phase(phase, iters, i, t, noise_pred, lr):
+            cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
+            gb.set_n_renders(n_renders)
+            gb.reset_optimizer()
+            noise_pred = noise_pred.clone().detach().requires_grad_(True)
+            opt = torch.optim.AdamW([{"params": [noise_pred], "lr": lr}], eps=1e-4)
+            for k in range(int(iters)):
+                opt.zero_grad()
+                x1 = self.scheduler.step_final(noise_pred, t, latents)
+                sdf = sdf_of(x1, xyz_samples, grid_size)
+                loss = fobj(sdf, cfg)                                   # (B,): one replay for all images
+                bad = [b for b, (_, _, fl) in enumerate(fobj.status()) if fl & (16 | 32 | 64)]
+                if bad or bool(torch.isnan(loss).any()):
+                    raise BatchLeftFastPath(f"phase {phase}, denoising step {i}, iteration {k}: images {bad or 'with a NaN loss'}")
+                loss.sum().backward()
+                opt.step()
+                stats["inner_iterations"] += 1
+            gb.raise_on_flags(strict_k=False)
+            return noise_pred.detach().clone()
+
+        results = [None] * B
+        for i, t in enumerate(timesteps):
+            latent_in = torch.cat([latents] * 2) if do_cfg else latents
+            timestep = t.expand(latent_in.shape[0]).to(latents.dtype) / self.scheduler.config.num_train_timesteps
+            noise_pred = self.model(latent_in, timestep, cond, guidance=guidance)
+            if do_cfg:
+                scale_i = cfg0.obj_guidance_scale * (1 - i / n_steps_obj) if i >= cfg0.guidance_start_step + 1 else cfg0.obj_guidance_scale
+                c, u = noise_pred.chunk(2)
+                noise_pred = u + scale_i * (c - u)
+            if i >= cfg0.handopt_start_step:
+                with torch.enable_grad():
+                    if i == cfg0.handopt_start_step:                     # phase A: hands only (PL:1296-1358)
+                        cfg, n_renders = E.phase_cfg("A", cfg0, denoise_i=i, do_update=True)
+                        gb.set_n_renders(n_renders)
+                        gb.reset_optimizer()
+                        n = int(cfg0.optimization_steps_hand)
+                        spg = max([d for d in range(1, 51) if n % d == 0]) if n > 0 else 1
+                        graph = gb.capture(cfg, steps_per_graph=spg)
+                        gb.reset_optimizer()
+                        for _ in range(n // spg):
+                            graph.replay()
+                        stats["inner_iterations"] += n
+                        torch.cuda.synchronize(device)
+                        gb.raise_on_flags(strict_k=False)
+                    elif i == cfg0.handopt_start_step + 1:               # phase B (PL:1361-1453)
+                        noise_pred = latent_phase("B", cfg0.optimization_steps_scale, i, t, noise_pred, cfg0.noise_obj_lr1)
+                    else:                                                # phase C (PL:1455-1601)
+                        noise_pred = latent_phase("C", cfg0.optimization_steps_joint, i, t, noise_pred, cfg0.noise_obj_lr2)
+                noise_pred = noise_pred.detach().clone()
+            latents = self.scheduler.step(noise_pred, t, latents).prev_sample
+            # the clean-sample estimate as a mesh in the MoGe world (PL:1612-1661): the last one is the result; earlier ones
+            # only matter as the fall-back of a later empty decode, so they are taken on the guidance grid
+            res = final_octree_resolution if i == n_steps - 1 else guid_res
+            xyz_d, gsz_d = grid(res) if res != guid_res else (xyz_samples, grid_size)
+            sdf = sdf_of(self.scheduler.step_final(noise_pred, t, latents), xyz_d, gsz_d)
+            for b in range(B):
+                verts, faces, _ = ops.flexicubes(xyz_d, sdf[b], res)
+                if verts.shape[0] == 0:
+                    print("Invalid mesh detected, aborting step!")
+                    continue
+                p = gb.params[b]
+                obj_world = similarity_about_center(verts @ T_h2m[b][:3, :3].T + T_h2m[b][:3, 3], p[8], p[12:16], p[9:12])
+                tex = torch.zeros_like(obj_world)
+                tex[:, 2] = 1.0
+                obj = Meshes(verts=[obj_world], faces=[faces], textures=TexturesVertex(verts_features=[tex]))
+                hand = results[b][1] if results[b] is not None else None
+                if i >= cfg0.handopt_start_step:
+                    hv = similarity_about_center(hand_moge[b], p[0], p[4:8], p[1:4])
+                    tex_h = torch.zeros_like(hv)
+                    tex_h[:, 1] = 1.0
+                    hand = Meshes(verts=[hv], faces=[hand_faces[b]], textures=TexturesVertex(verts_features=[tex_h]))
+                results[b] = (obj, hand)
+        self.guidance_batch = gb
+        return results
 
     # ------------------------------------------------------------------ PL:1044-1679
     @torch.no_grad()

@@ -379,3 +379,38 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     st, want = MPG.object_stats(ov, of), ref["obj_stats"]
     assert np.abs(st[:9] - want[:9]).max() < (1e-3 if n_joint == 1 else 2.5e-2)      # centroid and bounding box (metres)
     assert np.allclose(st[9:], want[9:], rtol=2e-2 if n_joint == 1 else 0.15)        # radius mean / std, area, volume
+
+
+@gpu
+def test_call_batch_equals_two_single_image_calls(tmp_path):
+    """GuidedShapePipeline.call_batch: two images through ONE pass of the schedule (DiT / VAE on two latents, one two-slot
+    capacity-mode GuidanceBatch, one AdamW over both noise predictions) against two `__call__` runs -- the reference's way,
+    one image after the other (RUN:208-259) -- at tame learning rates (1/500: at the reference's own rates two executions
+    of ONE image already separate)."""
+    from PIL import Image
+    scs = [_scene_for_pipeline(), _scene_for_pipeline(radius=0.7)]
+    scs[1]["kps_2d"] = scs[1]["kps_2d"] + 1.5
+    paths = [_write(tmp_path / f"img{b}", sc, index=str(7 + b)) for b, sc in enumerate(scs)]
+    cfg = _short_config()
+    for name in ("phase1_hand_lrs", "phase2_hand_lrs", "obj_lrs", "obj_2half_lrs"):
+        setattr(cfg, name, {k: v / 500.0 for k, v in getattr(cfg, name).items()})
+    cfg.noise_obj_lr1, cfg.noise_obj_lr2 = cfg.noise_obj_lr1 / 500.0, cfg.noise_obj_lr2 / 500.0
+    pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1)
+    imgs = [Image.open(p["cropped_obj_img_path"]) for p in paths]
+    kw = dict(config=cfg, renderer=_renderer(scs[0]["fov"]), J_regressor=scs[0]["J_regressor"], guidance_octree_resolution=24,
+              final_octree_resolution=40)
+    singles, params = [], []
+    for b in range(2):
+        singles.append(pipe(image=[imgs[b]], mc_algo="mc", generator=torch.Generator().manual_seed(2), sil_renderer=None, **kw, **paths[b]))
+        params.append(pipe.guidance_batch.params[0].clone())
+    both = pipe.call_batch(imgs, paths, **kw)
+    assert pipe.stats["inner_iterations"] == 10 + 3 + 2 * 2 and len(both) == 2
+    for b in range(2):
+        assert torch.allclose(pipe.guidance_batch.params[b], params[b], atol=2e-5), (b, pipe.guidance_batch.params[b], params[b])
+        (o1, h1), (o2, h2) = singles[b], both[b]
+        assert torch.allclose(h1.verts_packed(), h2.verts_packed(), atol=5e-5)
+        assert o1.faces_packed().shape == o2.faces_packed().shape and torch.allclose(o1.verts_packed(), o2.verts_packed(), atol=2e-4)
+    assert not torch.allclose(both[0][0].verts_packed().mean(0), both[1][0].verts_packed().mean(0), atol=1e-3)     # two different images
+    # an iso-surface beyond the capacity is the one-image path's business: the batch says so instead of approximating
+    with pytest.raises(PLN.BatchLeftFastPath):
+        pipe.call_batch(imgs, paths, obj_capacity=(64, 128), **kw)
