@@ -175,6 +175,12 @@ def run_hunyuan_w_guid(cropped_obj_img_path, fovx, hamer_for_guid_path, aligned_
     if out is not None and gb is not None:
         _tally(sharding.local_metrics(gb, n_steps=int(pipeline.stats["inner_iterations"]), wall_ms=0.0).cpu().numpy())
     obj_mesh, hand_mesh = out       # a None return (NaN in phase B, PL:1442-1444) raises here like in the reference
+    return _postprocess_and_save(obj_mesh, hand_mesh, cropped_obj_img_path, save_path_obj, save_path_hand)
+
+
+def _postprocess_and_save(obj_mesh, hand_mesh, cropped_obj_img_path, save_path_obj, save_path_hand):
+    """RUN:158-175: floaters, degenerate faces, decimation to 40k faces, export of the two PLY files."""
+    from followmyhold_amd import meshio
     try:    # RUN:159-166: floaters, degenerate faces, decimation to 40k faces, export
         from followmyhold_amd import postprocess as pp
         obj_mesh = pp.TriMesh(obj_mesh.verts_packed().cpu().numpy(), obj_mesh.faces_packed().cpu().numpy())
@@ -440,6 +446,8 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                     aligned_mano_dir=aligned_mano_dir, guidance_out_dir=guidance_out_dir)
         if _mesh_level_batched():
             _run_batched(assigned_imgs, dirs, config, device)
+        elif _pipeline_batch_size() > 1 and len(assigned_imgs) > 1 and _build_pipeline(device) is not None:
+            _run_pipeline_batched(assigned_imgs, dirs, config, device, _pipeline_batch_size())
         else:
             _run_one_by_one(assigned_imgs, dirs, config)
         print("Finished processing all images")
@@ -453,6 +461,85 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
         if error is not None:
             raise error
     return out
+
+
+def _pipeline_batch_size() -> int:
+    """Images per pass of the schedule when the networks are in the loop (GuidedShapePipeline.call_batch): FOHO_PIPELINE_BATCH,
+    default 4; 1 = the reference's one image at a time (guid_config.py:9)."""
+    return max(1, int(os.environ.get("FOHO_PIPELINE_BATCH", "4")))
+
+
+def _run_pipeline_batched(assigned_imgs, dirs, config, device, batch) -> None:
+    """RUN:208-259 with the networks in the loop, `batch` images per pass of the 20-step schedule: DiT and ShapeVAE on `batch`
+    latents, one capacity-mode GuidanceBatch of `batch` slots (GuidedShapePipeline.call_batch).  Skip rules, messages,
+    post-processing and the per-image error isolation are the one-image loop's; a group that leaves the batch's fast path
+    (BatchLeftFastPath: empty / non-manifold / over-capacity iso-surface, NaN loss) or fails as a whole is redone one
+    image at a time through run_hunyuan_w_guid."""
+    import torch
+    from followmyhold_amd.pipeline import BatchLeftFastPath
+    pipeline = _build_pipeline(device)
+
+    def one(name, p, fovx):
+        try:
+            print(f"Processing {p['index']}")
+            obj_mesh, hand_mesh = run_hunyuan_w_guid(
+                cropped_obj_img_path=p["cropped_obj_img_path"], fovx=fovx, hamer_for_guid_path=p["hamer_for_guid_path"],
+                aligned_mano_mesh_path=p["aligned_mano_mesh_path"], cropped_obj_mask_path=p["cropped_obj_mask_path"],
+                cropped_hand_mask_path=p["cropped_hand_mask_path"], moge_mesh_path=p["moge_mesh_path"], T_h2m_path=p["T_h2m_path"],
+                hunyuan_hoi_mesh_path=p["hunyuan_hoi_mesh_path"], save_path_obj=p["save_path_obj"], save_path_hand=p["save_path_hand"],
+                config=config)
+            print(f"Error in reconstruction for {p['index']}" if obj_mesh is None or hand_mesh is None else f"Reconstructed object {p['index']}")
+        except Exception as e:  # noqa: BLE001 -- RUN:257-259
+            print(f"Error in processing {name} : {e}")
+            _tally_named(n_failed=1)
+
+    def flush(group):
+        if len(group) == 1:
+            return one(*group[0])
+        try:
+            for _, p, _ in group:
+                print(f"Processing {p['index']}")
+            paths = [dict(cropped_obj_img_path=p["cropped_obj_img_path"], hamer_for_guid_path=p["hamer_for_guid_path"],
+                          aligned_mano_mesh_path=p["aligned_mano_mesh_path"], obj_mask_path=p["cropped_obj_mask_path"],
+                          hand_mask_path=p["cropped_hand_mask_path"], moge_mesh_path=p["moge_mesh_path"], h2m_rt_path=p["T_h2m_path"],
+                          hunyuan_hoi_mesh_path=p["hunyuan_hoi_mesh_path"]) for _, p, _ in group]
+            images = [_load_object_image(p["cropped_obj_img_path"])[0] for _, p, _ in group]
+            out = pipeline.call_batch(images, paths, generators=[torch.Generator().manual_seed(2) for _ in group], config=config,
+                                      fovs=[f for _, _, f in group])
+        except BatchLeftFastPath as e:
+            print(f"Batch of {[p['index'] for _, p, _ in group]} left the batched path ({e}); one image at a time")
+            return [one(*g) for g in group]
+        except Exception as e:  # noqa: BLE001 -- a failure of the whole pass must not cost the group its images
+            print(f"Batch of {[p['index'] for _, p, _ in group]} failed as a whole ({e}); one image at a time")
+            return [one(*g) for g in group]
+        _tally(sharding.local_metrics(pipeline.guidance_batch, n_steps=int(pipeline.stats["inner_iterations"]), wall_ms=0.0).cpu().numpy())
+        for (name, p, _), res in zip(group, out):
+            try:
+                obj_mesh, hand_mesh = res       # None: no decode of this image ever gave a surface
+                obj_mesh, hand_mesh = _postprocess_and_save(obj_mesh, hand_mesh, p["cropped_obj_img_path"], p["save_path_obj"], p["save_path_hand"])
+                print(f"Error in reconstruction for {p['index']}" if obj_mesh is None or hand_mesh is None else f"Reconstructed object {p['index']}")
+            except Exception as e:  # noqa: BLE001
+                print(f"Error in processing {name} : {e}")
+                _tally_named(n_failed=1)
+
+    groups = {}      # images of one mask size travel together (a GuidanceBatch has one H x W)
+    for cropped_obj_img in assigned_imgs:
+        try:
+            scr = _screen(cropped_obj_img, dirs)
+            if scr is None:
+                continue
+            p, fovx = scr
+            shape = _read_mask(p["cropped_hand_mask_path"]).shape[:2]
+        except Exception as e:  # noqa: BLE001
+            print(f"Error in processing {cropped_obj_img} : {e}")
+            _tally_named(n_failed=1)
+            continue
+        g = groups.setdefault(shape, [])
+        g.append((cropped_obj_img, p, fovx))
+        if len(g) == batch:
+            flush(groups.pop(shape))
+    for g in groups.values():
+        flush(g)
 
 
 def _run_one_by_one(assigned_imgs, dirs, config) -> None:

@@ -143,7 +143,7 @@ class GuidedShapePipeline:
     # ------------------------------------------------------------------ B images through one pass of the schedule
     @torch.no_grad()
     def call_batch(self, images, paths, generators=None, guidance_scale=7.5, num_chunks=8000, config=None, renderer=None,
-                   J_regressor=None, guidance_octree_resolution=64, final_octree_resolution=384, obj_capacity=None):
+                   J_regressor=None, guidance_octree_resolution=64, final_octree_resolution=384, obj_capacity=None, fovs=None):
         """`__call__` for B images at once ("within a GPU, batch the rank's images through each kernel
         launch").  The reference runs its images one after the other (RUN:208-259, batch_size = 1, guid_config.py:9); here
         one pass of the 20-step schedule serves all of them: the DiT and the ShapeVAE transformer run on B latents, the
@@ -152,8 +152,9 @@ class GuidedShapePipeline:
         and one AdamW over the (B, L, D) noise prediction (element-wise: B independent optimisers).
 
         images: list of B images (as `__call__` takes one); paths: list of B dicts with `__call__`'s eight path arguments;
-        generators: list of B torch.Generators (default: every image seeded with 2, RUN:120, 144).  All images must share
-        H x W.  -> list of B (object Meshes, hand Meshes) in the MoGe world.
+        generators: list of B torch.Generators (default: every image seeded with 2, RUN:120, 144); fovs: list of B fields of
+        view in degrees (default: the renderer's camera for all, else each image's fov.json -- what RUN:228-230 hands to its
+        camera).  All images must share H x W.  -> list of B (object Meshes, hand Meshes) in the MoGe world.
 
         Raises BatchLeftFastPath when an image needs what only the one-image path offers -- an empty / non-manifold /
         over-capacity iso-surface (PL:1394-1397, 1511-1513) or a NaN loss (PL:1442-1444, 1590-1592), whose handling is per
@@ -184,10 +185,11 @@ class GuidedShapePipeline:
             generators = [torch.Generator().manual_seed(2) for _ in range(B)]
         latents = torch.cat([self.prepare_latents(1, dtype, device, g) for g in generators], 0).clone()
 
-        fov = float(renderer.rasterizer.cameras.fov) if renderer is not None else None
+        if fovs is None:
+            fovs = [float(renderer.rasterizer.cameras.fov) if renderer is not None else None] * B
         jr = inputs.load_j_regressor() if J_regressor is None else np.asarray(J_regressor, np.float32)
         scenes = []
-        for p_ in paths:
+        for p_, fov in zip(paths, fovs):
             q = dict(cropped_hand_mask_path=p_["hand_mask_path"], cropped_obj_mask_path=p_["obj_mask_path"], moge_mesh_path=p_["moge_mesh_path"],
                      moge_fov_path=os.path.join(os.path.dirname(p_["moge_mesh_path"]), "fov.json"), T_h2m_path=p_["h2m_rt_path"],
                      aligned_mano_mesh_path=p_["aligned_mano_mesh_path"], hamer_for_guid_path=p_["hamer_for_guid_path"])

@@ -410,7 +410,47 @@ def test_call_batch_equals_two_single_image_calls(tmp_path):
         (o1, h1), (o2, h2) = singles[b], both[b]
         assert torch.allclose(h1.verts_packed(), h2.verts_packed(), atol=5e-5)
         assert o1.faces_packed().shape == o2.faces_packed().shape and torch.allclose(o1.verts_packed(), o2.verts_packed(), atol=2e-4)
-    assert not torch.allclose(both[0][0].verts_packed().mean(0), both[1][0].verts_packed().mean(0), atol=1e-3)     # two different images
+    ext = [(m[0].verts_packed().max(0)[0] - m[0].verts_packed().min(0)[0]).max().item() for m in both]
+    assert abs(ext[0] - ext[1]) > 5e-3, ext                                              # two different images (object sizes)
     # an iso-surface beyond the capacity is the one-image path's business: the batch says so instead of approximating
     with pytest.raises(PLN.BatchLeftFastPath):
         pipe.call_batch(imgs, paths, obj_capacity=(64, 128), **kw)
+
+
+@gpu
+def test_guidance_stage_driver_batches_images_with_the_networks_in_the_loop(tmp_path, monkeypatch, capsys):
+    """`foho.guidance.run.run` over three images with FOHO_PIPELINE_BATCH=2: two go through ONE pass of the schedule
+    (GuidedShapePipeline.call_batch), the third on its own; the reference's messages per image, six PLY files, metrics of
+    three images.  A batch that leaves the fast path (here: forced by a tiny object capacity) is redone one image at a time."""
+    from foho.guidance import run as G
+    from followmyhold_amd import meshio, pipeline as PL_
+    scs = [_scene_for_pipeline(), _scene_for_pipeline(radius=0.7), _scene_for_pipeline(radius=0.75)]
+    for b, sc in enumerate(scs):
+        _write(tmp_path, sc, index=str(41 + b))
+    jr = str(tmp_path / "J.npy")
+    np.save(jr, scs[0]["J_regressor"])
+    monkeypatch.setenv("FOHO_J_REGRESSOR", jr)
+    monkeypatch.setenv("FOHO_STANDIN_NETWORKS", "1")
+    monkeypatch.setenv("FOHO_PIPELINE_BATCH", "2")
+    monkeypatch.setattr(G, "_PIPELINE", None)
+    monkeypatch.setattr(G, "OptimizationConfig", lambda: _short_config())
+    calls = []
+    orig = PL_.GuidedShapePipeline.call_batch
+    monkeypatch.setattr(PL_.GuidedShapePipeline, "call_batch", lambda self, images, paths, **kw: (calls.append(len(images)), orig(self, images, paths, **kw))[1])
+    d = {k: os.path.join(str(tmp_path), k) for k in ["cropped_obj_img_dir", "mask_dir", "moge_out_dir", "hunyuan_hoi_mesh_dir",
+                                                     "hamer_out_dir", "h2m_rt_dir", "aligned_mano_dir", "guidance_out_dir"]}
+    tot = G.run(project_root=str(tmp_path), task_list_file=None, **d)
+    out = capsys.readouterr().out
+    assert calls == [2] and tot["n_images"] == 3 and tot["n_failed"] == 0
+    for idx in ("41", "42", "43"):
+        assert f"Processing {idx}" in out and f"Reconstructed object {idx}" in out
+        ov, of = meshio.load_ply(os.path.join(d["guidance_out_dir"], f"{idx}_obj.ply"))
+        hv, _ = meshio.load_ply(os.path.join(d["guidance_out_dir"], f"{idx}_hand.ply"))
+        assert len(ov) > 1000 and len(of) == 2 * len(ov) - 4 and np.isfinite(ov).all() and hv.shape == (778, 3)
+    # the fall-back: a batch whose surfaces exceed the capacity is redone image by image
+    import shutil
+    shutil.rmtree(d["guidance_out_dir"])
+    monkeypatch.setattr(PL_.GuidedShapePipeline, "call_batch", lambda self, images, paths, **kw: orig(self, images, paths, obj_capacity=(64, 128), **kw))
+    tot = G.run(project_root=str(tmp_path), task_list_file=None, **d)
+    out = capsys.readouterr().out
+    assert "left the batched path" in out and tot["n_failed"] == 0 and len(os.listdir(d["guidance_out_dir"])) == 6
