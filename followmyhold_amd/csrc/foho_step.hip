@@ -251,7 +251,11 @@ static WS make_ws(const foho_dims& d) {
     w.frac_count = take(R * B * 4);
     {
         int rf_h, rf_o, nRh, nRo;
+#ifdef FOHO_NSEG_AUTO
+        raster_blocks(d, rf_h, rf_o, nRh, nRo, 0);
+#else
         raster_blocks(d, rf_h, rf_o, nRh, nRo, RF_H_MIN);  // room for the most workgroups any hand_faces_per_block gives
+#endif
         w.nseg = nRh + nRo;
     }
     w.seg_count = take(R * B * (size_t)w.nseg * 4);  // entries in every raster workgroup's segment of the fragment list

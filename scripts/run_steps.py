@@ -8,6 +8,7 @@ from followmyhold_amd import engine as E, synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--crop", default=None)
+ap.add_argument("--fov", type=float, default=60.0, help="field of view of the synthetic camera when --crop is not given (22: the round-3 close-up)")
 ap.add_argument("--images", type=int, default=1)
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--steps", type=int, default=500)
@@ -16,7 +17,7 @@ ap.add_argument("--eager", action="store_true", help="plain launches instead of 
 ap.add_argument("--listed-cap", type=int, default=0)
 a = ap.parse_args()
 rf = E.hip_render_fn("cuda")
-scenes = [synthetic.build_scene(rf, obj_kind=a.obj, H=512, W=512, seed=100 + j, crop=a.crop) for j in range(a.images)]
+scenes = [synthetic.build_scene(rf, obj_kind=a.obj, H=512, W=512, seed=100 + j, crop=a.crop, fov=a.fov) for j in range(a.images)]
 group = E.GuidanceGroup(scenes, a.streams, device="cuda")
 cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
 cfg.listed_cap = a.listed_cap
