@@ -81,6 +81,86 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v + 0.5f * fabsf(v) * e;                                                   // v erf(v / sqrt 2) = |v| erf(|v| / sqrt 2)
 }
 
+// Epilogue of both GEMM kernels for one 64 (M) x 64 (N) part of a wave's tile, accumulators t[n tile][m tile] in the transposed
+// C layout (D rows = n, D columns = m: a lane holds, for ONE m, 4 consecutive n per register group).  bias / GELU / scale in
+// fp32, rounded to fp16, through a wave-private LDS image (64 rows x CPAD halfs) to whole-row 16-byte stores; at read-back
+// the residual is added (EP_RESID) or the value is multiplied by gelu'(Z) (EP_GELUBWD: the backward of the MLP's
+// activation, Z = the saved pre-activation, passed in R).  EP_SAVEZ: the pre-activation itself goes to C2 first (same shape as
+// C).  EP_TRANS: a TRANSPOSED copy goes to C2[n][pos(m)], pos = m with bits 2 and 3 of (m & 15) swapped -- the order in
+// which an MFMA operand built from a C-layout accumulator holds its k index (see the attention kernels): the backward
+// attention kernel reads Q^T and dO^T from such copies.  m0 / n0: first row / column of the 64 x 64 part.
+constexpr int EP_GELUBWD = 4, EP_SAVEZ = 8, EP_TRANS = 16;
+
+__device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
+    const float x = v * 0.70710678118654752f, ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float g = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);   // exp(-v^2 / 2)
+    const float erfa = 1.0f - p * t * g;
+    const float cdf = 0.5f + 0.5f * copysignf(erfa, v);
+    return cdf + v * 0.3989422804014327f * g;
+}
+
+template <int EP>
+__device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16& t01, const f32x16& t10, const f32x16& t11, h16* img,
+                                                const float* __restrict__ bias, const h16* __restrict__ R, int ldr, h16* __restrict__ C, int ldc,
+                                                h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane) {
+    const int hi = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int pass = (EP & EP_SAVEZ) ? 0 : 1; pass < 2; pass++) {   // pass 0: the pre-activation (EP_SAVEZ only); pass 1: the output
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int nl = jn * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns (within the 64)
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const f32x16& t = jn == 0 ? (i == 0 ? t00 : t01) : (i == 0 ? t10 : t11);
+                    half4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float v = t[4 * g + q] + b4[q];
+                        if ((EP & EP_GELU) && pass == 1) v = gelu_erf(v);
+                        v *= scale;
+                        o[q] = (h16)v;
+                    }
+                    *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
+                    if ((EP & EP_TRANS) && pass == 1) {
+                        const int gm = m0 + i * 32 + l31;
+                        if (gm < M) {
+                            const int pm = (gm & ~15) | (gm & 3) | ((gm & 4) << 1) | ((gm & 8) >> 1);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) C2[(size_t)(n0 + nl + q) * ldc2 + pm] = o[q];
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is wave-private: no barrier, only this wave's own writes
+        h16* dst = (pass == 0) ? C2 : C;
+        const int ldd = (pass == 0) ? ldc2 : ldc;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int ml = q * 8 + (lane >> 3), ch = lane & 7;
+            const int gm = m0 + ml, gn = n0 + ch * 8;
+            half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
+            if (gm < M) {
+                if ((EP & (EP_RESID | EP_GELUBWD)) && pass == 1) {
+                    const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
+                }
+                *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is reused
+    }
+}
+
 // LDS byte address of a __shared__ object (for the inline-asm reads below)
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
@@ -90,7 +170,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 template <int EP>
 __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                      const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
-                                                     h16* __restrict__ C, int ldc, int M, int N, int K, float scale) {
+                                                     h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
+                                                     int ldc2) {
     __shared__ uint4 lds[2][2][GM * GK * 2 / 16];  // [buffer][A | W][128 rows x 8 chunks] = 64 KB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     // XCD-aware tile order: the blocks of one XCD (L mod 8) sweep N inside one row panel of A, eight panels (one per XCD) at a time
@@ -188,43 +269,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
     }
     __syncthreads();  // every wave is done with the staging buffers: they become the epilogue's transpose image
 
-    // ---- epilogue: bias / GELU / scale in fp32, round to fp16, through LDS to whole-row stores (+ residual)
+    // ---- epilogue (gemm_epilogue64): the staging buffers become the waves' transpose images
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
-#pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int nl = jn * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns (within the wave's 64)
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + nl);
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                half4 o;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float v = acc[jn][i][4 * g + q] + b4[q];
-                    if (EP & EP_GELU) v = gelu_erf(v);
-                    v *= scale;
-                    o[q] = (h16)v;
-                }
-                *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is wave-private: no barrier, only this wave's own writes
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int ml = q * 8 + (lane >> 3), ch = lane & 7;
-        const int gm = m0 + wr * 64 + ml, gn = n0 + wc * 64 + ch * 8;
-        half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
-        if (gm < M) {
-            if (EP & EP_RESID) {
-                const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] + (float)r[e]);
-            }
-            *reinterpret_cast<half8*>(C + (size_t)gm * ldc + gn) = v;
-        }
-    }
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, bias, R, ldr, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +285,8 @@ constexpr int HM = 256, HN = 256;
 template <int EP>
 __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
-                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale) {
+                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
+                                                        int ldc2) {
     __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int ntn = N / HN, ntm = (M + HM - 1) / HM;
@@ -330,44 +378,9 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int nl = jn * 32 + 8 * g + 4 * hi;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + nl);
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    half4 o;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float v = acc[jn][2 * half + i][4 * g + q] + b4[q];
-                        if (EP & EP_GELU) v = gelu_erf(v);
-                        v *= scale;
-                        o[q] = (h16)v;
-                    }
-                    *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int ml = q * 8 + (lane >> 3), ch = lane & 7;
-            const int gm = m0 + wr * 128 + half * 64 + ml, gn = n0 + wc * 64 + ch * 8;
-            half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
-            if (gm < M) {
-                if (EP & EP_RESID) {
-                    const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] + (float)r[e]);
-                }
-                *reinterpret_cast<half8*>(C + (size_t)gm * ldc + gn) = v;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the second half overwrites the image
-    }
+    for (int half = 0; half < 2; half++)
+        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, bias, R, ldr, C, ldc, C2, ldc2, M,
+                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,7 +408,7 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
-                                                     int heads) {
+                                                     int heads, float* __restrict__ lse) {
     __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     int head, qblk;
@@ -562,6 +575,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         const float inv = 1.0f / lt;
         const int row = q0 + qb * 32 + l31;
         if (row < M) {
+            // log2 of the softmax denominator in the scores' own (log2) units: the backward pass rebuilds P = exp2(s - lse)
+            if (lse && hi == 0) lse[(size_t)row * heads + head] = __builtin_amdgcn_logf(lt) - negm[qb][0];
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -584,6 +599,251 @@ __global__ void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, i
     if (c >= width) return;
     const int kq = l & 15, pos = (l & ~15) | (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1);
     Vt[(size_t)c * L + pos] = KV[(size_t)l * ldkv + width + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the cross attention with respect to K and V (the query side is constant: the queries are grid points).
+//   P = exp2(S - lse), S = Qs K^T (Qs = Q log2(e) / 8);  dV = P^T dO;  dP = dO V^T;  dS = P (dP - delta), delta = rowsum(dO O);
+//   dK = dS^T Qs ln 2.
+// Workgroup = 4 waves x 32 keys of ONE head (K and V fragments of a wave's keys stay in registers); it walks query tiles of 64
+// (tile ti = split + n splits: `splits` workgroups share a key block and add their sums with float atomics).  Per tile the
+// 4 waves share, in LDS: Qs and dO (rows = queries: A operands of S and dP) and their TRANSPOSED copies (rows = d, columns
+// = queries in operand order, written by the GEMM epilogue EP_TRANS: A operands of dK^T = Qs^T dS and dV^T = dO^T P).  S and
+// dP come out with the key in the lane and the query in the register index, which is exactly the B operand of those two
+// products (k = query) -- no transpose, no cross-lane traffic; lse / delta of the register's query come from LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int BQ = 64;  // queries per tile
+
+__global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__ Qs, const h16* __restrict__ QsT, const h16* __restrict__ dO,
+                                                         const h16* __restrict__ dOT, int ldt, const float* __restrict__ lse,
+                                                         const float* __restrict__ delta, const h16* __restrict__ KV, int ldkv, int width,
+                                                         int heads, int M, int splits, float* __restrict__ dKV) {
+    __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
+    __shared__ float lsd[2][2][BQ];       // [buffer][lse | delta]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nkt = gridDim.x / (heads * splits);
+    int bid = blockIdx.x;
+    const int split = bid % splits;
+    bid /= splits;
+    const int head = bid % heads, kt = bid / heads;
+    (void)nkt;
+    const int key = kt * 128 + w * 32 + l31;
+    half8 kf[4], vf[4];   // B operands: lane (key, hi) holds K / V [key][16 kk + 8 hi .. + 7]
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        kf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + head * 64 + 16 * kk + 8 * hi);
+        vf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + width + head * 64 + 16 * kk + 8 * hi);
+    }
+    f32x16 dk[2], dv[2];  // dK^T / dV^T [d tile]: rows d, columns key
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dk[a][r] = dv[a][r] = 0.0f;
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const int sidx = srow * 8 + (sch ^ swz(srow));
+    const int ntiles = (M + BQ - 1) / BQ;
+    uint4 s0, s1, s2, s3, s4, s5, s6, s7;
+    float sl = 0.0f;
+#define BWD_GLOAD(ti)                                                                                              \
+    do {                                                                                                           \
+        const int q0_ = (ti) * BQ;                                                                                 \
+        const size_t ra_ = (size_t)min(q0_ + srow, M - 1) * width + head * 64 + sch * 8;                           \
+        const size_t rb_ = (size_t)min(q0_ + srow + 32, M - 1) * width + head * 64 + sch * 8;                      \
+        const size_t ta_ = (size_t)(head * 64 + srow) * ldt + q0_ + sch * 8;                                       \
+        s0 = *reinterpret_cast<const uint4*>(Qs + ra_);                                                            \
+        s1 = *reinterpret_cast<const uint4*>(Qs + rb_);                                                            \
+        s2 = *reinterpret_cast<const uint4*>(dO + ra_);                                                            \
+        s3 = *reinterpret_cast<const uint4*>(dO + rb_);                                                            \
+        s4 = *reinterpret_cast<const uint4*>(QsT + ta_);                                                           \
+        s5 = *reinterpret_cast<const uint4*>(QsT + ta_ + (size_t)32 * ldt);                                        \
+        s6 = *reinterpret_cast<const uint4*>(dOT + ta_);                                                           \
+        s7 = *reinterpret_cast<const uint4*>(dOT + ta_ + (size_t)32 * ldt);                                        \
+        if (tid < 2 * BQ) {                                                                                        \
+            const int q_ = q0_ + (tid & (BQ - 1));                                                                 \
+            sl = (tid < BQ) ? ((q_ < M) ? lse[(size_t)q_ * heads + head] : INFINITY)                               \
+                            : ((q_ < M) ? delta[(size_t)q_ * heads + head] : 0.0f);                                \
+        }                                                                                                          \
+    } while (0)
+#define BWD_LWRITE(buf)                                  \
+    do {                                                 \
+        lds[buf][0][sidx] = s0;                          \
+        lds[buf][0][sidx + 256] = s1;                    \
+        lds[buf][1][sidx] = s2;                          \
+        lds[buf][1][sidx + 256] = s3;                    \
+        lds[buf][2][sidx] = s4;                          \
+        lds[buf][2][sidx + 256] = s5;                    \
+        lds[buf][3][sidx] = s6;                          \
+        lds[buf][3][sidx + 256] = s7;                    \
+        if (tid < 2 * BQ) lsd[buf][tid >> 6][tid & (BQ - 1)] = sl; \
+    } while (0)
+
+    int ti = split, it = 0;
+    if (ti < ntiles) {
+        BWD_GLOAD(ti);
+        BWD_LWRITE(0);
+    }
+    __syncthreads();
+    for (; ti < ntiles; ti += splits, it++) {
+        const int buf = it & 1;
+        if (ti + splits < ntiles) BWD_GLOAD(ti + splits);
+        const uint4 *lq = lds[buf][0], *ldo = lds[buf][1], *lqt = lds[buf][2], *ldot = lds[buf][3];
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++) {
+            const int qrow = qb * 32 + l31;
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = dp[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint4 uq = lq[qrow * 8 + ((2 * kk + hi) ^ swz(qrow))], ud = ldo[qrow * 8 + ((2 * kk + hi) ^ swz(qrow))];
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&uq), kf[kk], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&ud), vf[kk], dp, 0, 0, 0);
+            }
+            // register r of this lane (one key) belongs to query 32 qb + (r & 3) + 8 (r >> 2) + 4 hi
+            half8 pb[2], db[2];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lsd[buf][0][qb * 32 + 8 * g + 4 * hi]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&lsd[buf][1][qb * 32 + 8 * g + 4 * hi]);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float p0 = ex2(sc[4 * g + e] - l4[e]), p1 = ex2(sc[4 * g + e + 1] - l4[e + 1]);
+                    const f32x2 pp = {p0, p1}, dd = {p0 * (dp[4 * g + e] - d4[e]), p1 * (dp[4 * g + e + 1] - d4[e + 1])};
+                    const half2v ph = __builtin_convertvector(pp, half2v), dh = __builtin_convertvector(dd, half2v);
+                    pb[g >> 1][4 * (g & 1) + e] = ph[0];
+                    pb[g >> 1][4 * (g & 1) + e + 1] = ph[1];
+                    db[g >> 1][4 * (g & 1) + e] = dh[0];
+                    db[g >> 1][4 * (g & 1) + e + 1] = dh[1];
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) {
+                const int drow = dt * 32 + l31;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const int ch = (4 * qb + 2 * ks + hi) ^ swz(drow);
+                    const uint4 ut = ldot[drow * 8 + ch], uqt = lqt[drow * 8 + ch];
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&ut), pb[ks], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&uqt), db[ks], dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (ti + splits < ntiles) BWD_LWRITE(buf ^ 1);
+        __syncthreads();
+    }
+#undef BWD_GLOAD
+#undef BWD_LWRITE
+    // sums of this workgroup's share of the queries -> dKV (float atomics: `splits` workgroups and all row blocks add up)
+    float* gk = dKV + (size_t)key * (2 * width) + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            atomicAdd(gk + d, dk[dt][r] * 0.6931471805599453f);
+            atomicAdd(gk + width + d, dv[dt][r]);
+        }
+}
+
+// delta[q][head] = sum_d dO[q][head, d] O[q][head, d]: one wave per row, 8 lanes per head and half row
+__global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, const h16* __restrict__ O, int width, int heads, int M,
+                                                   float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int col = (c * 64 + lane) * 8;
+        float s = 0.0f;
+        if (col < width) {
+            const half8 a = *reinterpret_cast<const half8*>(dO + (size_t)row * width + col), b = *reinterpret_cast<const half8*>(O + (size_t)row * width + col);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += (float)a[e] * (float)b[e];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if ((lane & 7) == 0 && col < width) delta[(size_t)row * heads + col / 64] = s;
+    }
+}
+
+// Backward of a LayerNorm row (one wave per row): x = the forward's input, y = xhat gamma + beta.
+// MODE 0: dy from DY (fp16), DX = (DR ? DR : 0) + dx.   MODE 1 (ln_post + output_proj): dy_i = gvec[row] w_out[i].
+template <int MODE>
+__global__ __launch_bounds__(256) void k_geo_ln_bwd(const h16* __restrict__ X, const float* __restrict__ gamma, const h16* __restrict__ DY,
+                                                    const h16* __restrict__ DR, const float* __restrict__ gvec, float gain,
+                                                    const float* __restrict__ w_out, h16* __restrict__ DX, int M, int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float x[2][8], dy[2][8];
+    float sum = 0.0f;
+    const float gr = (MODE == 1) ? gvec[row] * gain : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < width) {
+            const half8 h = *reinterpret_cast<const half8*>(X + (size_t)row * width + col);
+            half8 g;
+            if (MODE == 0) g = *reinterpret_cast<const half8*>(DY + (size_t)row * width + col);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                x[c][e] = (float)h[e];
+                sum += x[c][e];
+                dy[c][e] = ((MODE == 0) ? (float)g[e] : gr * w_out[col + e]) * gamma[col + e];   // d / d xhat
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[c][e] = dy[c][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)width;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        if ((c * 64 + lane) * 8 < width)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float d = x[c][e] - mean;
+                sq += d * d;
+            }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq / (float)width + eps);
+    float a = 0.0f, b = 0.0f;   // mean(d xhat), mean(d xhat . xhat)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        if ((c * 64 + lane) * 8 < width)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                a += dy[c][e];
+                b += dy[c][e] * (x[c][e] - mean) * rstd;
+            }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    a /= (float)width;
+    b /= (float)width;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < width) {
+            half8 r;
+            if (DR) r = *reinterpret_cast<const half8*>(DR + (size_t)row * width + col);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float dx = rstd * (dy[c][e] - a - (x[c][e] - mean) * rstd * b);
+                o[e] = (h16)(dx + (DR ? (float)r[e] : 0.0f));
+            }
+            *reinterpret_cast<half8*>(DX + (size_t)row * width + col) = o;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -698,29 +958,36 @@ static bool launch_ok(const char* what) {
 }
 
 static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
+template <int EP>
+static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
+                        h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2) {
+    if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2);
+    else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2);
+}
+
+// ep: bit mask of EP_*.  R: the residual (EP_RESID) or the saved pre-activation (EP_GELUBWD); C2: the pre-activation output
+// (EP_SAVEZ, leading dimension ldc2) or the transposed copy (EP_TRANS, row length ldc2)
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
-                int N, int K, float scale, hipStream_t s) {
+                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0) {
     if (M <= 0) return FOHO_OK;
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
-    if (N % HN == 0 && K >= 256 && M >= 2048 && !g_force128) {  // the big GEMMs of the chain: 256 x 256 tiles
-        const int ntn = N / HN, ntm = (M + HM - 1) / HM;
-        const dim3 grid(8 * ((ntm + 7) / 8) * ntn), block(512);
-        switch (ep) {
-            case 0: hipLaunchKernelGGL(k_geo_gemm256<0>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
-            case EP_GELU: hipLaunchKernelGGL(k_geo_gemm256<EP_GELU>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
-            case EP_RESID: hipLaunchKernelGGL(k_geo_gemm256<EP_RESID>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
-            default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
-        }
-        return launch_ok("k_geo_gemm256") ? FOHO_OK : FOHO_ERR_LAUNCH;
-    }
-    const int ntn = N / GN, ntm = (M + GM - 1) / GM;
-    const dim3 grid(8 * ((ntm + 7) / 8) * ntn), block(256);
+    if ((ep & (EP_RESID | EP_GELUBWD)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
+    if ((ep & (EP_SAVEZ | EP_TRANS)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
+    const bool big = N % HN == 0 && K >= 256 && M >= 2048 && !g_force128;  // the big GEMMs of the chain: 256 x 256 tiles
+    const int tn = big ? HN : GN, tm = big ? HM : GM;
+    const int ntn = N / tn, ntm = (M + tm - 1) / tm;
+    const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
+#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(big, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2); break
     switch (ep) {
-        case 0: hipLaunchKernelGGL(k_geo_gemm<0>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
-        case EP_GELU: hipLaunchKernelGGL(k_geo_gemm<EP_GELU>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
-        case EP_RESID: hipLaunchKernelGGL(k_geo_gemm<EP_RESID>, grid, block, 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale); break;
+        GEO_GEMM_CASE(0);
+        GEO_GEMM_CASE(EP_GELU);
+        GEO_GEMM_CASE(EP_RESID);
+        GEO_GEMM_CASE(EP_GELU | EP_SAVEZ);
+        GEO_GEMM_CASE(EP_GELUBWD);
+        GEO_GEMM_CASE(EP_TRANS);
         default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
     }
+#undef GEO_GEMM_CASE
     return launch_ok("k_geo_gemm") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
@@ -815,7 +1082,7 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
         if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
         if (int rc = gemm(0, bB, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, bC, W, M, W, W, qscale, s)) return rc;
         // attention over the latent tokens                                           C -> B
-        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads);
+        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads, (float*)nullptr);
         if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
         // x1 = x0 + c_proj(attn)                                                      B (+A) -> C
         if (int rc = gemm(EP_RESID, bB, W, (const h16*)w->w_proj, W, w->b_proj, bA, W, bC, W, M, W, W, 1.0f, s)) return rc;
@@ -829,6 +1096,111 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
         hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, W, w->ln_eps, w->w_out,
                            w->b_out, q, w->prior_radius, w->prior_sharpness, w->out_gain, logits + r0);
         if (!launch_ok("k_geo_ln(post)")) return FOHO_ERR_LAUNCH;
+    }
+    return FOHO_OK;
+}
+
+struct BwdLayout {
+    size_t e, x0, xn, qs, qst, at, x1, z, h, x2, dx2, dat, lse, delta, total;
+    int ldt;
+};
+static BwdLayout bwd_layout(const foho_geo_weights* w, int chunk) {
+    BwdLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t W = w->width, F = w->hidden, C = chunk;
+    l.ldt = (chunk + 63) & ~63;
+    l.e = take(C * 64 * 2);
+    l.x0 = take(C * W * 2);
+    l.xn = take(C * W * 2);
+    l.qs = take(C * W * 2);
+    l.qst = take(W * (size_t)l.ldt * 2);
+    l.at = take(C * W * 2);
+    l.x1 = take(C * W * 2);
+    l.z = take(C * F * 2);
+    l.h = take(C * F * 2);
+    l.x2 = take(C * W * 2);
+    l.dx2 = take(C * W * 2);
+    l.dat = take(W * (size_t)l.ldt * 2);
+    l.lse = take(C * (size_t)w->heads * 4);
+    l.delta = take(C * (size_t)w->heads * 4);
+    l.total = off;
+    return l;
+}
+
+extern "C" size_t foho_geo_bwd_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows) {
+    if (check_weights(w) != FOHO_OK || chunk_rows <= 0) return 0;
+    return bwd_layout(w, chunk_rows).total;
+}
+
+extern "C" int foho_geo_set_kv(const foho_geo_weights* w, const void* kv_in, int32_t chunk_rows, void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!kv_in || !ws || chunk_rows <= 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_set_kv: null argument");
+    const Layout l = layout(w, chunk_rows);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_set_kv: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    char* base = (char*)ws;
+    h16 *kv = (h16*)(base + l.kv), *vt = (h16*)(base + l.vt);
+    const int W = w->width, Lr = w->n_latents;
+    if (hipMemcpyAsync(kv, kv_in, (size_t)Lr * 2 * W * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(FOHO_ERR_LAUNCH, "foho_geo_set_kv: copy failed");
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
+    return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+extern "C" int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+                                   int32_t chunk_rows, void* ws, size_t ws_bytes, void* bws, size_t bws_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!queries || !grad_logits || !grad_kv || !ws || !bws || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: null argument");
+    if (!w->w_fc2_t || !w->w_fc1_t || !w->w_proj_t || !w->zeros) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: transposed weights / zeros missing");
+    if (w->n_latents % 128) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: n_latents must be a multiple of 128");
+    const Layout l = layout(w, chunk_rows);
+    const BwdLayout b = bwd_layout(w, chunk_rows);
+    if (ws_bytes < l.total || bws_bytes < b.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
+    char* base = (char*)bws;
+    h16 *E = (h16*)(base + b.e), *X0 = (h16*)(base + b.x0), *Xn = (h16*)(base + b.xn), *Qs = (h16*)(base + b.qs), *QsT = (h16*)(base + b.qst),
+        *At = (h16*)(base + b.at), *X1 = (h16*)(base + b.x1), *Z = (h16*)(base + b.z), *H = (h16*)(base + b.h), *X2 = (h16*)(base + b.x2),
+        *dX2 = (h16*)(base + b.dx2), *dAT = (h16*)(base + b.dat);
+    float *lse = (float*)(base + b.lse), *delta = (float*)(base + b.delta);
+    const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
+    const float qscale = 1.4426950408889634f * 0.125f;
+    const float* nof = nullptr;
+    // columns of the transposed copies beyond a ragged block's rows must be finite (they meet P = 0): clear both once
+    if (hipMemsetAsync(QsT, 0, (size_t)W * b.ldt * 2, s) != hipSuccess || hipMemsetAsync(dAT, 0, (size_t)W * b.ldt * 2, s) != hipSuccess ||
+        hipMemsetAsync(grad_kv, 0, (size_t)Lr * 2 * W * 4, s) != hipSuccess)
+        return fail(FOHO_ERR_LAUNCH, "foho_geo_decode_bwd: memset failed");
+    for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
+        const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
+        const float* q = queries + 3 * r0;
+        const dim3 rows((M + 3) / 4), blk(256);
+        // ---- the forward chain again, keeping what the backward needs
+        hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), blk, 0, s, q, M, w->n_freqs, w->freqs, E);
+        if (int rc = gemm(0, E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, X0, W, M, W, 64, 1.0f, s)) return rc;
+        hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, X0, W, w->ln_q_g, w->ln_q_b, Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+        if (int rc = gemm(EP_TRANS, Xn, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, Qs, W, M, W, W, qscale, s, QsT, b.ldt)) return rc;
+        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), blk, 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse);
+        if (int rc = gemm(EP_RESID, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s)) return rc;
+        hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, X1, W, w->ln_2_g, w->ln_2_b, Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+        if (int rc = gemm(EP_GELU | EP_SAVEZ, Xn, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, H, F, M, F, W, 1.0f, s, Z, F)) return rc;
+        if (int rc = gemm(EP_RESID, H, F, (const h16*)w->w_fc2, F, w->b_fc2, X1, W, X2, W, M, W, F, 1.0f, s)) return rc;
+        // ---- backwards: logits -> ln_post -> fc2 -> GELU -> fc1 -> ln_2 (+ residual) -> c_proj -> attention (K, V)
+        hipLaunchKernelGGL(k_geo_ln_bwd<1>, rows, blk, 0, s, X2, w->ln_post_g, (const h16*)nullptr, (const h16*)nullptr, grad_logits + r0, w->out_gain, w->w_out,
+                           dX2, M, W, w->ln_eps);
+        if (int rc = gemm(EP_GELUBWD, dX2, W, (const h16*)w->w_fc2_t, W, w->zeros, Z, F, H, F, M, F, W, 1.0f, s)) return rc;          // dZ -> H
+        if (int rc = gemm(0, H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, Xn, W, M, W, F, 1.0f, s)) return rc;                 // d ln_2 out -> Xn
+        hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, X1, w->ln_2_g, Xn, dX2, nof, 0.0f, nof, X0, M, W, w->ln_eps);                // dX1 -> X0
+        if (int rc = gemm(EP_TRANS, X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, dX2, W, M, W, W, 1.0f, s, dAT, b.ldt)) return rc;   // dO -> dX2
+        hipLaunchKernelGGL(k_geo_delta, rows, blk, 0, s, dX2, At, W, NH, M, delta);
+        if (!launch_ok("foho_geo_decode_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
+        const int ntiles = (M + BQ - 1) / BQ, nkb = Lr / 128;
+        const int splits = std::max(1, std::min(ntiles, (4 * 256 + nkb * NH - 1) / (nkb * NH)));   // ~4 workgroups per CU
+        hipLaunchKernelGGL(k_geo_attn_bwd, dim3(nkb * NH * splits), blk, 0, s, Qs, QsT, dX2, dAT, b.ldt, lse, delta, kv, 2 * W, W, NH, M, splits, grad_kv);
+        if (!launch_ok("k_geo_attn_bwd")) return FOHO_ERR_LAUNCH;
     }
     return FOHO_OK;
 }
@@ -854,6 +1226,6 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
-                       n_latents, (h16*)O, W, M, heads);
+                       n_latents, (h16*)O, W, M, heads, (float*)nullptr);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }

@@ -3,12 +3,14 @@
 Reference: third_party_patches/hy3dgen/shapegen/pipelines.py:298-308 -- 35 chunks of 8000 grid points through
 `vae.geo_decoder(queries, latents)` per decode of a 65^3 grid (hy3dgen's CrossAttentionDecoder: Fourier embedding,
 query projection, one cross-attention block over the latent tokens, MLP, LayerNorm, one logit per point).  Here one call
-decodes all points.  FORWARD ONLY in this version: `pipeline.latent2sdf` uses it where the reference decodes without
-gradients (the per-step clean-sample decode PL:1614-1662, 385^3 points on the last step) and keeps the torch modules
-where autograd has to reach the latent (PL:1391-1393, 1507-1509).
+decodes all points: `pipeline.latent2sdf` uses it for the reference's no-gradient decodes (the per-step clean-sample
+decode PL:1614-1662, 385^3 points on the last step) and, through `foho_geo_decode_bwd`, for the decodes autograd has to
+cross on its way to the latent (PL:1391-1393, 1507-1509): the gradient reaches the latent tokens (the decoder's weights
+are constants of the guidance, as in the reference, where only the latent / pose parameters are optimised).
 
     dec = HipGeoDecoder.from_module(vae.geo_decoder)         # weights packed once (fp16 matrices, fp32 vectors)
-    logits = dec(queries (1, N, 3), latents (1, L, width))    # (1, N, 1), dtype of the latents -- the module's signature
+    logits = dec(queries (1, N, 3), latents (1, L, width))    # (1, N, 1), dtype of the latents -- the module's signature;
+                                                              # differentiable w.r.t. the latents when they require grad
 
 There is no CPU path: the constructor raises when the module's shape is outside what the kernels take (head dimension
 64, width % 128 == 0 and <= 1024, n_latents % 64 == 0, hidden % 128 == 0).
@@ -26,7 +28,8 @@ class FohoGeoWeights(ctypes.Structure):
                 ("ln_kv_b", L.vp), ("w_q", L.vp), ("b_q", L.vp), ("w_kv", L.vp), ("b_kv", L.vp), ("w_proj", L.vp), ("b_proj", L.vp),
                 ("ln_2_g", L.vp), ("ln_2_b", L.vp), ("w_fc1", L.vp), ("b_fc1", L.vp), ("w_fc2", L.vp), ("b_fc2", L.vp),
                 ("ln_post_g", L.vp), ("ln_post_b", L.vp), ("w_out", L.vp), ("b_out", L.c_f), ("ln_eps", L.c_f),
-                ("prior_radius", L.c_f), ("prior_sharpness", L.c_f), ("out_gain", L.c_f)]
+                ("prior_radius", L.c_f), ("prior_sharpness", L.c_f), ("out_gain", L.c_f),
+                ("w_fc2_t", L.vp), ("w_fc1_t", L.vp), ("w_proj_t", L.vp), ("zeros", L.vp)]
 
 
 def _bias(lin, n, device):
@@ -83,6 +86,9 @@ class HipGeoDecoder:
         for name, lin in (("q", p["q"]), ("proj", p["proj"]), ("fc1", p["fc1"]), ("fc2", p["fc2"])):
             t["w_" + name] = lin.weight.detach().to(dev, h).contiguous()
             t["b_" + name] = _bias(lin, lin.weight.shape[0], dev)
+        for name in ("fc2", "fc1", "proj"):              # the backward's GEMMs multiply by the transposes
+            t[f"w_{name}_t"] = t["w_" + name].t().contiguous()
+        t["zeros"] = torch.zeros(max(hidden, 2 * width), dtype=torch.float32, device=dev)
         t["w_out"] = p["out"].weight.detach().reshape(-1).to(dev, torch.float32).contiguous()
         t["freqs"] = p["freqs"].detach().to(dev, torch.float32).contiguous()
         self.t = t
@@ -97,9 +103,11 @@ class HipGeoDecoder:
         self.w = w
         self.chunk = int(chunk_rows or self.CHUNK)
         self.workspace = None
+        self.bwd_workspace = None
         self._prepared = None
-        self.lib.foho_geo_workspace_bytes.restype = ctypes.c_size_t
-        self.lib.foho_geo_workspace_bytes.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
+        for fn in (self.lib.foho_geo_workspace_bytes, self.lib.foho_geo_bwd_workspace_bytes):
+            fn.restype = ctypes.c_size_t
+            fn.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
         self.lib.foho_geo_last_error.restype = ctypes.c_char_p
         if self.lib.foho_geo_workspace_bytes(ctypes.byref(w), self.chunk) == 0:
             raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
@@ -117,16 +125,56 @@ class HipGeoDecoder:
         lat = latents.reshape(-1, latents.shape[-1]).to(self.device, torch.float16).contiguous()
         if lat.shape[1] != self.w.width:
             raise L.FohoError(f"HipGeoDecoder: latent tokens of width {lat.shape[1]}, decoder of width {self.w.width}")
-        if lat.shape[0] != self.w.n_latents or self.workspace is None:
-            self.w.n_latents = lat.shape[0]
-            n = int(self.lib.foho_geo_workspace_bytes(ctypes.byref(self.w), self.chunk))
-            if n == 0:
-                raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
-            self.workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._size_for(lat.shape[0])
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.foho_geo_prepare(ctypes.byref(self.w), L.vp(lat.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
                                               ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_prepare")
         self._lat = lat        # kept alive until the stream has consumed it
+
+    def _size_for(self, n_latents):
+        if n_latents != self.w.n_latents or self.workspace is None:
+            self.w.n_latents = n_latents
+            n = int(self.lib.foho_geo_workspace_bytes(ctypes.byref(self.w), self.chunk))
+            if n == 0:
+                raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
+            self.workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self.bwd_workspace = None
+
+    def kv_of(self, latents):
+        """c_kv(ln(latents)) with torch ops, rows [K of all heads | V of all heads], fp16: the part of the decoder autograd
+        differentiates itself (3072 tokens; the 274 625 query rows are foho_geo_decode_bwd's)."""
+        t = self.t
+        lat = latents.reshape(-1, latents.shape[-1]).to(self.device)
+        x = torch.nn.functional.layer_norm(lat.float(), (self.w.width,), t["ln_kv_g"], t["ln_kv_b"], self.w.ln_eps)
+        return (x.half() @ t["w_kv"].t() + t["b_kv"].half()).contiguous()
+
+    def set_kv(self, kv):
+        """Install K / V (L, 2 width) fp16 computed by the caller in place of prepare()."""
+        kv = kv.detach().to(self.device, torch.float16).contiguous()
+        if kv.dim() != 2 or kv.shape[1] != 2 * self.w.width:
+            raise L.FohoError(f"HipGeoDecoder: kv of shape {tuple(kv.shape)}, decoder of width {self.w.width}")
+        self._size_for(kv.shape[0])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_set_kv(ctypes.byref(self.w), L.vp(kv.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
+                                             ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_set_kv")
+        self._prepared = None
+
+    def decode_bwd(self, queries, grad_logits):
+        """d sum(grad_logits . logits) / d kv -> (L, 2 width) float32, for the K / V of the last set_kv() / prepare()."""
+        q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
+        g = grad_logits.reshape(-1).to(self.device, torch.float32).contiguous()
+        if g.shape[0] != q.shape[0]:
+            raise L.FohoError(f"HipGeoDecoder: {q.shape[0]} queries, {g.shape[0]} logit gradients")
+        if self.bwd_workspace is None:
+            n = int(self.lib.foho_geo_bwd_workspace_bytes(ctypes.byref(self.w), self.chunk))
+            self.bwd_workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        out = torch.empty(self.w.n_latents, 2 * self.w.width, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_decode_bwd(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(g.data_ptr()),
+                                                 L.vp(out.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
+                                                 ctypes.c_size_t(self.workspace.numel()), L.vp(self.bwd_workspace.data_ptr()),
+                                                 ctypes.c_size_t(self.bwd_workspace.numel()), L.vp(stream)), "foho_geo_decode_bwd")
+        return out
 
     def decode(self, queries):
         """queries (N, 3) -> logits (N,) float32, against the tokens of the last prepare()."""
@@ -142,6 +190,8 @@ class HipGeoDecoder:
         """The module's signature: queries (1, N, 3), latents (1, L, width) -> (1, N, 1) in the latents' dtype."""
         if latents.dim() == 3 and latents.shape[0] != 1:
             raise L.FohoError("HipGeoDecoder: one set of latent tokens per call")
+        if torch.is_grad_enabled() and latents.requires_grad:
+            return _GeoDecodeFn.apply(self.kv_of(latents), queries, self).to(latents.dtype).reshape(1, -1, 1)
         key = (latents.data_ptr(), latents._version, tuple(latents.shape))
         if self._prepared != key:
             self.prepare(latents)
@@ -149,8 +199,26 @@ class HipGeoDecoder:
         return self.decode(queries).to(latents.dtype).reshape(1, -1, 1)
 
 
+class _GeoDecodeFn(torch.autograd.Function):
+    """logits(kv): forward = foho_geo_set_kv + foho_geo_decode_fwd, backward = foho_geo_decode_bwd (which recomputes the
+    forward per row block: nothing but kv and the query points is kept between the two)."""
+
+    @staticmethod
+    def forward(ctx, kv, queries, dec):
+        dec.set_kv(kv)
+        ctx.dec = dec
+        ctx.save_for_backward(kv.detach(), queries)
+        return dec.decode(queries)
+
+    @staticmethod
+    def backward(ctx, grad):
+        kv, queries = ctx.saved_tensors
+        ctx.dec.set_kv(kv)                    # the workspace may have served another decode since
+        return ctx.dec.decode_bwd(queries, grad).to(kv.dtype), None, None
+
+
 def install(vae, device="cuda", chunk_rows=None):
-    """Attach a HipGeoDecoder built from `vae.geo_decoder` as `vae.hip_geo`: `pipeline.latent2sdf` then decodes with it
-    wherever no gradient is required.  Raises when the decoder's shape is outside what the kernels take."""
+    """Attach a HipGeoDecoder built from `vae.geo_decoder` as `vae.hip_geo`: `pipeline.latent2sdf` then decodes with it,
+    with or without gradients to the latent.  Raises when the decoder's shape is outside what the kernels take."""
     vae.hip_geo = HipGeoDecoder.from_module(vae.geo_decoder, device=device, chunk_rows=chunk_rows)
     return vae.hip_geo

@@ -40,9 +40,10 @@ def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     8000 grid points, negate the logits so that the field is negative inside.  -> (1, G, G, G) float32."""
     pred = 1 / vae.scale_factor * pred
     pred = vae(pred)
-    hip = getattr(vae, "hip_geo", None)          # geo_decode.install(vae): the decoder on the matrix cores, forward only
-    if hip is not None and not (torch.is_grad_enabled() and pred.requires_grad):
-        # the reference's no-gradient decodes (PL:1614-1662): all grid points in one call, no 8000-query chunks
+    hip = getattr(vae, "hip_geo", None)          # geo_decode.install(vae): the decoder on the matrix cores
+    if hip is not None:
+        # all grid points in one call, no 8000-query chunks; under autograd (PL:1391-1393, 1507-1509) the gradient reaches
+        # `pred` through foho_geo_decode_bwd
         grid_logits = hip(xyz_samples.to(device).half().float().unsqueeze(0), pred)      # fp16 query points like PL:303
         return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
     logits = []
@@ -205,7 +206,11 @@ class GuidedShapePipeline:
             """latent2sdf (PL:292-313) for B latents: the VAE transformer on all of them, the geometry decoder per image."""
             pred = self.vae(1 / self.vae.scale_factor * x1)
             out = []
+            hip = getattr(self.vae, "hip_geo", None)
             for b in range(x1.shape[0]):
+                if hip is not None:          # geo_decode.install(vae): all points in one call, gradients through foho_geo_decode_bwd
+                    out.append(-hip(xyz.to(device).half().float().unsqueeze(0), pred[b:b + 1]).view(-1).float())
+                    continue
                 logits = [self.vae.geo_decoder(xyz[s0:s0 + num_chunks].half().unsqueeze(0), pred[b:b + 1]) for s0 in range(0, xyz.shape[0], num_chunks)]
                 out.append(-torch.cat(logits, dim=1).view(-1).float())
             return torch.stack(out, 0)

@@ -409,6 +409,12 @@ typedef struct {
     float ln_eps;                    /* 1e-5 (torch default) unless the model says otherwise                    */
     float prior_radius, prior_sharpness, out_gain;  /* logits = sharpness (radius - |x|) + gain * learned.  A trained decoder:
                                         0, 0, 1.  (The random-initialised stand-in of the tests adds an analytic sphere.) */
+    /* backward only (foho_geo_decode_bwd; may be NULL for forward-only use): the three matrices the gradient flows back
+     * through, TRANSPOSED once by the caller, and a buffer of zeros (the backward GEMMs have no bias)               */
+    const void* w_fc2_t;             /* (hidden, width) fp16 = w_fc2^T                                          */
+    const void* w_fc1_t;             /* (width, hidden) fp16 = w_fc1^T                                          */
+    const void* w_proj_t;            /* (width, width) fp16 = w_proj^T                                          */
+    const float* zeros;              /* (max(hidden, width)) fp32 zeros                                         */
 } foho_geo_weights;
 
 /* workspace for row blocks of `chunk_rows` queries: K / V of the latent tokens + the block's activations (14.5 KB per
@@ -423,6 +429,20 @@ int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chu
  * foho_geo_prepare left in the workspace.  9 launches per row block, asynchronous, no host synchronisation. */
 int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* Gradients to the latent tokens: the decoder as a differentiable function of K / V.
+ * foho_geo_set_kv installs K / V computed by the caller -- kv (n_latents, 2 width) fp16 = c_kv(ln(latents)), rows [K of all
+ * heads | V of all heads]: the caller's autograd owns LayerNorm + projection of the 3072 tokens (0.1 % of the work) -- into the
+ * forward workspace, in place of foho_geo_prepare.  foho_geo_decode_bwd then returns grad_kv (n_latents, 2 width) fp32 =
+ * d sum(grad_logits . logits) / d kv for the logits foho_geo_decode_fwd computes from those K / V and `queries`: per row block
+ * it RECOMPUTES the forward chain (nothing is kept between the two calls: 14.5 KB per query would be 4 GB per 65^3 grid)
+ * with the pre-activation, the attention's log-sum-exp and transposed copies of Q saved, and runs the chain backwards --
+ * LayerNorm / GELU backward, three GEMMs with the transposed weights, the attention backward for K and V (queries are
+ * constants: nothing flows to them).  `bwd_workspace`: foho_geo_bwd_workspace_bytes(w, chunk_rows). */
+size_t foho_geo_bwd_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
+int foho_geo_set_kv(const foho_geo_weights* w, const void* kv, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+                        int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
+                        void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.
