@@ -613,11 +613,40 @@ def geo_decode_record(torch, dev, res=64, reps=5):
         ts.append(time.perf_counter() - t0)
     t_torch = min(ts)
     err = (out.float() - ref.float()).abs().max().item()
-    return {"queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
+    # forward + backward to the latent tokens (the decodes of PL:1391-1393 / 1507-1509): foho_geo_decode_fwd + foho_geo_decode_bwd
+    # (which recomputes the chain) beside torch autograd through the same 35 chunks
+    go = torch.randn(1, n, 1, device=dev)
+    def hip_fb():
+        l = lat.clone().requires_grad_(True)
+        (hip(q32, l).float() * go).sum().backward()
+        return l.grad
+    def torch_fb():
+        l = lat.clone().requires_grad_(True)
+        outs = [dech(xyz[s0:s0 + 8000].half().unsqueeze(0), l) for s0 in range(0, n, 8000)]
+        (torch.cat(outs, 1).float() * go).sum().backward()
+        return l.grad
+    fb = {}
+    for name, fn, r in (("hip", hip_fb, reps), ("torch", torch_fb, 2)):
+        g = fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(r):
+            t0 = time.perf_counter()
+            g = fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        fb[name] = (min(ts), g.float())
+    # backward flops: the recomputed forward + dX GEMMs of fc2 / fc1 / c_proj (no weight gradients) + dP, dV, dK of the attention
+    flops_bwd = flops + n * (4 * W * F + 2 * W * W + 6 * NL * W)
+    gerr = (fb["hip"][1] - fb["torch"][1]).abs().max().item() / fb["torch"][1].abs().max().item()
+    return {"fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
+            "fwd_bwd_tflops": (flops + flops_bwd) / fb["hip"][0] / 1e12, "grad_rel_diff_vs_torch_fp16": gerr,
+            "queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
             "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops / 1e12,
             "tflops": flops / t_hip / 1e12, "roofline": {"bound": "mfma", "achieved": flops / t_hip / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                                           "frac": flops / t_hip / 1e12 / 2500.0},
-            "max_abs_diff_vs_torch_fp16": err, "logit_scale": ref.float().abs().max().item(), "backward": "not implemented (torch autograd)"}
+            "max_abs_diff_vs_torch_fp16": err, "logit_scale": ref.float().abs().max().item(),
+            "backward": "foho_geo_decode_bwd: gradient to K / V of the latent tokens, forward recomputed per 16384-row block"}
 
 
 def obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg, steps=1000):

@@ -1,5 +1,6 @@
 """Times foho_geo_decode_fwd at the Hunyuan3D-2 decoder shape against the torch module (bench.py's geo_decode record alone),
-and each GEMM / the attention kernel on their own.  python scripts/geo_bench.py [--parts]"""
+and each GEMM / the attention kernel on their own.  python scripts/geo_bench.py [--parts | --fb]
+(--fb: three forward + backward passes of the HIP decoder and nothing else -- the run to put under rocprofv3)"""
 import ctypes, json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -7,6 +8,23 @@ import bench
 from followmyhold_amd import _lib as L
 
 dev = torch.device("cuda", 0)
+if "--fb" in sys.argv:
+    from followmyhold_amd import standins
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=1, num_freqs=8)
+    hip = HipGeoDecoder.from_module(vae.geo_decoder.to(dev).eval(), device=dev)
+    n = 65 ** 3
+    q = (torch.rand(1, n, 3, device=dev) * 2.2 - 1.1).half().float()
+    lat = torch.randn(1, 3072, 1024, device=dev).half()
+    go = torch.randn(1, n, 1, device=dev)
+    for _ in range(3):
+        l = lat.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        (hip(q, l).float() * go).sum().backward()
+        torch.cuda.synchronize()
+        print(f"forward + backward: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
+    sys.exit(0)
 if "--parts" in sys.argv:
     lib = L.lib()
     lib.foho_geo_last_error.restype = ctypes.c_char_p

@@ -1,4 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r04k
-timeout 900 python -m pytest tests/test_geo_decode.py -x -q -m gpu 2>&1 | tail -30 > gpurun_out/r04k/geo_tests.log
-cat gpurun_out/r04k/geo_tests.log
+mkdir -p gpurun_out/r04l
+timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > gpurun_out/r04l/gpu_tests.log
+cat gpurun_out/r04l/gpu_tests.log

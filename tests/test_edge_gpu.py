@@ -106,7 +106,7 @@ def test_hand_only_scene_without_object():
     torch.cuda.synchronize()
     gb.raise_on_flags()
     # phase A only looks at the hand: loss, gradient and the first update must not depend on the presence of an object
-    # mesh (one iteration: over several, Adam amplifies the 1e-7 noise of the atomic gradient sums, see DESIGN.md 10)
+    # mesh (one iteration: over several, Adam amplifies the 1e-7 noise of the atomic gradient sums, see DESIGN.md 11)
     ga_, gb_ = ref.grad_params.cpu().numpy()[0, :8], gb.grad_params.cpu().numpy()[0, :8]
     assert np.linalg.norm(ga_ - gb_) <= 1e-4 * np.linalg.norm(ga_)
     assert abs(gb.loss_dict(0)["total"] - ref.loss_dict(0)["total"]) <= 1e-6 * abs(ref.loss_dict(0)["total"])

@@ -190,7 +190,7 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
     assert g.shape == (Hs, 2 * sc["W"] + 8, 3) and (g[:, :sc["W"]] > 0).any() and (g[:, sc["W"] + 8:] > 0).any()
     # capacity mode's escape hatch: with an object capacity that is far too small the first latent iteration is redone on the
     # exact-size path, the capacity grows, and the run completes (the two runs are not comparable vertex by vertex: phase A's
-    # learning rate of 0.5 makes the trajectory chaotic, DESIGN.md section 7)
+    # learning rate of 0.5 makes the trajectory chaotic, DESIGN.md section 8)
     monkeypatch.delenv("FOHO_DEBUG_DIR")
     monkeypatch.setenv("FOHO_OBJ_CAPACITY", "64,128")
     obj_c, hand_c = run(_short_config())
@@ -386,7 +386,7 @@ def test_call_batch_equals_two_single_image_calls(tmp_path):
     """GuidedShapePipeline.call_batch: two images through ONE pass of the schedule (DiT / VAE on two latents, one two-slot
     capacity-mode GuidanceBatch, one AdamW over both noise predictions) against two `__call__` runs -- the reference's way,
     one image after the other (RUN:208-259) -- at tame learning rates (1/500: at the reference's own rates two executions
-    of ONE image already separate, DESIGN.md section 7)."""
+    of ONE image already separate, DESIGN.md section 8)."""
     from PIL import Image
     scs = [_scene_for_pipeline(), _scene_for_pipeline(radius=0.7)]
     scs[1]["kps_2d"] = scs[1]["kps_2d"] + 1.5
