@@ -26,6 +26,7 @@
 // Translation unit of its own: compiled WITHOUT -ffp-contract=off / correctly rounded division (nothing here decides a
 // face index), linked into libfoho_hip.so next to foho_step.hip.
 #include <hip/hip_runtime.h>
+#include <string>
 #include <stdint.h>
 #include <math.h>
 #include <stdio.h>
@@ -48,6 +49,7 @@ static int fail(int code, const char* what) {
     snprintf(g_err, sizeof(g_err), "%s", what);
     return code;
 }
+static int fail(int code, const std::string& what) { return fail(code, what.c_str()); }
 
 // 16-byte chunk `c` of row `row` of a [rows][64 halfs] LDS tile (128-byte rows) lives in slot c ^ swz(row): the 32 rows x
 // 2 chunks a 32x32x16 fragment read touches then fall on 16 distinct 16-byte bank groups within each of ds_read_b128's
@@ -617,7 +619,7 @@ constexpr int BQ = 64;  // queries per tile
 __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__ Qs, const h16* __restrict__ QsT, const h16* __restrict__ dO,
                                                          const h16* __restrict__ dOT, int ldt, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, const h16* __restrict__ KV, int ldkv, int width,
-                                                         int heads, int M, int splits, float* __restrict__ dKV) {
+                                                         int heads, int M, int splits, int L, int accumulate, float* __restrict__ part) {
     __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
     __shared__ float lsd[2][2][BQ];       // [buffer][lse | delta]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -734,16 +736,52 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
     }
 #undef BWD_GLOAD
 #undef BWD_LWRITE
-    // sums of this workgroup's share of the queries -> dKV (float atomics: `splits` workgroups and all row blocks add up)
-    float* gk = dKV + (size_t)key * (2 * width) + head * 64;
+    // This workgroup's sums -> part[split][key][dK (ln 2 folded in) | dV]: the (split, key block, head) slice is this workgroup's
+    // alone, launches of successive row blocks are ordered by the stream, so a plain read-modify-write accumulates over the
+    // row blocks -- no atomics (16 384 per workgroup were 0.8 of the kernel's time at 21-26 memory-side atomics per ns), and
+    // the result does not depend on the order anything ran in.  Through LDS: a lane holds 4 consecutive d of ONE key.
+    if (accumulate && split >= ntiles) return;   // nothing to add
+    float* stage = reinterpret_cast<float*>(&lds[0][0][0]) + w * (32 * 68);
+    float* gk = part + ((size_t)split * L + kt * 128 + w * 32) * (2 * width) + head * 64;
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
+    for (int m = 0; m < 2; m++) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            atomicAdd(gk + d, dk[dt][r] * 0.6931471805599453f);
-            atomicAdd(gk + width + d, dv[dt][r]);
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = m ? dv[dt][4 * g + e] : dk[dt][4 * g + e] * 0.6931471805599453f;
+                *reinterpret_cast<f32x4*>(stage + l31 * 68 + dt * 32 + 8 * g + 4 * hi) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it2 = 0; it2 < 8; it2++) {
+            const int idx = it2 * 64 + lane, kr = idx >> 4, c4 = idx & 15;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stage + kr * 68 + c4 * 4);
+            float* dst = gk + (size_t)kr * (2 * width) + m * width + c4 * 4;
+            if (accumulate) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += o[e];
+            }
+            *reinterpret_cast<f32x4*>(dst) = v;
         }
+    }
+}
+
+// grad_kv = sum over the splits of k_geo_attn_bwd's partial sums (fixed order: bitwise repeatable)
+__global__ __launch_bounds__(256) void k_geo_dkv_reduce(const float* __restrict__ part, int splits, size_t n4, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+    for (int sp = 1; sp < splits; sp++) {
+        const f32x4 b = reinterpret_cast<const f32x4*>(part)[(size_t)sp * n4 + i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] += b[e];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = a;
 }
 
 // delta[q][head] = sum_d dO[q][head, d] O[q][head, d]: one wave per row, 8 lanes per head and half row
@@ -1101,9 +1139,21 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
 }
 
 struct BwdLayout {
-    size_t e, x0, xn, qs, qst, at, x1, z, h, x2, dx2, dat, lse, delta, total;
-    int ldt;
+    size_t e, x0, xn, qs, qst, at, x1, z, h, x2, dx2, dat, lse, delta, part, total;
+    int ldt, splits;
 };
+// workgroups of k_geo_attn_bwd per (key block, head): enough for ~4 per CU, preferring a count that fills whole rounds of the
+// 512 resident workgroups (2 per CU)
+static int bwd_splits(const foho_geo_weights* w, int chunk) {
+    const int ntiles = (chunk + 63) / 64, base = (w->n_latents / 128) * w->heads;
+    int s0 = std::max(1, (1024 + base - 1) / base), best = s0;
+    double bw = 1e9;
+    for (int sp = s0; sp < s0 + 4; sp++) {
+        const double n = (double)base * sp, waste = std::ceil(n / 512.0) * 512.0 / n;
+        if (waste < bw - 1e-9) bw = waste, best = sp;
+    }
+    return std::max(1, std::min(best, ntiles));
+}
 static BwdLayout bwd_layout(const foho_geo_weights* w, int chunk) {
     BwdLayout l{};
     size_t off = 0;
@@ -1128,6 +1178,8 @@ static BwdLayout bwd_layout(const foho_geo_weights* w, int chunk) {
     l.dat = take(W * (size_t)l.ldt * 2);
     l.lse = take(C * (size_t)w->heads * 4);
     l.delta = take(C * (size_t)w->heads * 4);
+    l.splits = bwd_splits(w, chunk);
+    l.part = take((size_t)l.splits * w->n_latents * 2 * W * 4);
     l.total = off;
     return l;
 }
@@ -1151,58 +1203,158 @@ extern "C" int foho_geo_set_kv(const foho_geo_weights* w, const void* kv_in, int
     return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
-extern "C" int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
-                                   int32_t chunk_rows, void* ws, size_t ws_bytes, void* bws, size_t bws_bytes, void* stream_) {
-    if (int rc = check_weights(w)) return rc;
-    if (!queries || !grad_logits || !grad_kv || !ws || !bws || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: null argument");
-    if (!w->w_fc2_t || !w->w_fc1_t || !w->w_proj_t || !w->zeros) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: transposed weights / zeros missing");
-    if (w->n_latents % 128) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: n_latents must be a multiple of 128");
-    const Layout l = layout(w, chunk_rows);
-    const BwdLayout b = bwd_layout(w, chunk_rows);
-    if (ws_bytes < l.total || bws_bytes < b.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_bwd: workspace too small");
-    hipStream_t s = (hipStream_t)stream_;
-    const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
-    char* base = (char*)bws;
-    h16 *E = (h16*)(base + b.e), *X0 = (h16*)(base + b.x0), *Xn = (h16*)(base + b.xn), *Qs = (h16*)(base + b.qs), *QsT = (h16*)(base + b.qst),
-        *At = (h16*)(base + b.at), *X1 = (h16*)(base + b.x1), *Z = (h16*)(base + b.z), *H = (h16*)(base + b.h), *X2 = (h16*)(base + b.x2),
-        *dX2 = (h16*)(base + b.dx2), *dAT = (h16*)(base + b.dat);
-    float *lse = (float*)(base + b.lse), *delta = (float*)(base + b.delta);
+// What the backward of one row block needs from its forward: per block in the `save` buffer (kept mode) or in the backward
+// workspace (recompute mode)
+struct SavedLayout {
+    size_t qs, qst, at, x1, z, x2, lse, total;
+};
+static SavedLayout saved_layout(const foho_geo_weights* w, int chunk) {
+    SavedLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t W = w->width, F = w->hidden, C = chunk, ldt = (chunk + 63) & ~63;
+    l.qs = take(C * W * 2);
+    l.qst = take(W * ldt * 2);
+    l.at = take(C * W * 2);
+    l.x1 = take(C * W * 2);
+    l.z = take(C * F * 2);
+    l.x2 = take(C * W * 2);
+    l.lse = take(C * (size_t)w->heads * 4);
+    l.total = off;
+    return l;
+}
+struct ChunkPtrs {
+    h16 *E, *X0, *Xn, *H, *dX2, *dAT;        // scratch
+    h16 *Qs, *QsT, *At, *X1, *Z, *X2;        // saved by the forward
+    float *lse, *delta;
+    int ldt;
+};
+
+// the forward chain of one row block with everything its backward needs kept (P.Qs .. P.lse)
+static int chain_fwd_keep(const foho_geo_weights* w, const float* q, int M, const ChunkPtrs& P, const h16* kv, const h16* vt, hipStream_t s) {
     const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
     const float qscale = 1.4426950408889634f * 0.125f;
     const float* nof = nullptr;
-    // columns of the transposed copies beyond a ragged block's rows must be finite (they meet P = 0): clear both once
-    if (hipMemsetAsync(QsT, 0, (size_t)W * b.ldt * 2, s) != hipSuccess || hipMemsetAsync(dAT, 0, (size_t)W * b.ldt * 2, s) != hipSuccess ||
-        hipMemsetAsync(grad_kv, 0, (size_t)Lr * 2 * W * 4, s) != hipSuccess)
-        return fail(FOHO_ERR_LAUNCH, "foho_geo_decode_bwd: memset failed");
-    for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
+    const dim3 rows((M + 3) / 4), blk(256);
+    hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), blk, 0, s, q, M, w->n_freqs, w->freqs, P.E);
+    if (int rc = gemm(0, P.E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, P.X0, W, M, W, 64, 1.0f, s)) return rc;
+    hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X0, W, w->ln_q_g, w->ln_q_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+    if (int rc = gemm(EP_TRANS, P.Xn, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, P.Qs, W, M, W, W, qscale, s, P.QsT, P.ldt)) return rc;
+    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), blk, 0, s, P.Qs, W, kv, 2 * W, vt, Lr, P.At, W, M, NH, P.lse);
+    if (int rc = gemm(EP_RESID, P.At, W, (const h16*)w->w_proj, W, w->b_proj, P.X0, W, P.X1, W, M, W, W, 1.0f, s)) return rc;
+    hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X1, W, w->ln_2_g, w->ln_2_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+    if (int rc = gemm(EP_GELU | EP_SAVEZ, P.Xn, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, P.H, F, M, F, W, 1.0f, s, P.Z, F)) return rc;
+    if (int rc = gemm(EP_RESID, P.H, F, (const h16*)w->w_fc2, F, w->b_fc2, P.X1, W, P.X2, W, M, W, F, 1.0f, s)) return rc;
+    return launch_ok("geometry decoder forward chain") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+// ... and backwards: logits -> ln_post -> fc2 -> GELU -> fc1 -> ln_2 (+ residual) -> c_proj -> attention (K, V partial sums)
+static int chain_bwd(const foho_geo_weights* w, const float* grad_logits, int M, const ChunkPtrs& P, const h16* kv, int splits, int accumulate, float* part,
+                     hipStream_t s) {
+    const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
+    const float* nof = nullptr;
+    const dim3 rows((M + 3) / 4), blk(256);
+    hipLaunchKernelGGL(k_geo_ln_bwd<1>, rows, blk, 0, s, P.X2, w->ln_post_g, (const h16*)nullptr, (const h16*)nullptr, grad_logits, w->out_gain, w->w_out, P.dX2,
+                       M, W, w->ln_eps);
+    if (int rc = gemm(EP_GELUBWD, P.dX2, W, (const h16*)w->w_fc2_t, W, w->zeros, P.Z, F, P.H, F, M, F, W, 1.0f, s)) return rc;                // dZ -> H
+    if (int rc = gemm(0, P.H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, P.Xn, W, M, W, F, 1.0f, s)) return rc;                       // d ln_2 out -> Xn
+    hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, P.X1, w->ln_2_g, P.Xn, P.dX2, nof, 0.0f, nof, P.X0, M, W, w->ln_eps);                // dX1 -> X0
+    if (int rc = gemm(EP_TRANS, P.X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, P.dX2, W, M, W, W, 1.0f, s, P.dAT, P.ldt)) return rc;  // dO -> dX2
+    hipLaunchKernelGGL(k_geo_delta, rows, blk, 0, s, P.dX2, P.At, W, NH, M, P.delta);
+    if (!launch_ok("geometry decoder backward chain (row kernels)")) return FOHO_ERR_LAUNCH;
+    const int nkb = Lr / 128;
+    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(nkb * NH * splits), blk, 0, s, P.Qs, P.QsT, P.dX2, P.dAT, P.ldt, P.lse, P.delta, kv, 2 * W, W, NH, M, splits, Lr,
+                       accumulate, part);
+    return launch_ok("k_geo_attn_bwd") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+static ChunkPtrs chunk_ptrs(const BwdLayout& b, char* base, const SavedLayout& sl, char* saved) {
+    ChunkPtrs P;
+    P.E = (h16*)(base + b.e), P.X0 = (h16*)(base + b.x0), P.Xn = (h16*)(base + b.xn), P.H = (h16*)(base + b.h), P.dX2 = (h16*)(base + b.dx2);
+    P.dAT = (h16*)(base + b.dat), P.delta = (float*)(base + b.delta), P.ldt = b.ldt;
+    if (saved) {
+        P.Qs = (h16*)(saved + sl.qs), P.QsT = (h16*)(saved + sl.qst), P.At = (h16*)(saved + sl.at), P.X1 = (h16*)(saved + sl.x1);
+        P.Z = (h16*)(saved + sl.z), P.X2 = (h16*)(saved + sl.x2), P.lse = (float*)(saved + sl.lse);
+    } else {
+        P.Qs = (h16*)(base + b.qs), P.QsT = (h16*)(base + b.qst), P.At = (h16*)(base + b.at), P.X1 = (h16*)(base + b.x1);
+        P.Z = (h16*)(base + b.z), P.X2 = (h16*)(base + b.x2), P.lse = (float*)(base + b.lse);
+    }
+    return P;
+}
+
+extern "C" size_t foho_geo_saved_bytes(const foho_geo_weights* w, int32_t chunk_rows, int64_t n_queries) {
+    if (check_weights(w) != FOHO_OK || chunk_rows <= 0 || n_queries < 0) return 0;
+    const int64_t nchunks = (n_queries + chunk_rows - 1) / chunk_rows;
+    return (size_t)std::max<int64_t>(nchunks, 1) * saved_layout(w, chunk_rows).total;
+}
+
+static int bwd_args(const char* who, const foho_geo_weights* w, const void* a, const void* b_, const void* ws, const void* bws, int32_t chunk_rows,
+                    int64_t n_queries, bool need_t) {
+    if (int rc = check_weights(w)) return rc;
+    if (!a || !b_ || !ws || !bws || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": null argument");
+    if (need_t && (!w->w_fc2_t || !w->w_fc1_t || !w->w_proj_t || !w->zeros)) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": transposed weights / zeros missing");
+    if (w->n_latents % 128) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": n_latents must be a multiple of 128");
+    return FOHO_OK;
+}
+
+extern "C" int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows, void* ws,
+                                        size_t ws_bytes, void* bws, size_t bws_bytes, void* saved, size_t saved_bytes, void* stream_) {
+    if (int rc = bwd_args("foho_geo_decode_fwd_keep", w, queries, logits, ws, bws, chunk_rows, n_queries, false)) return rc;
+    const Layout l = layout(w, chunk_rows);
+    const BwdLayout b = bwd_layout(w, chunk_rows);
+    const SavedLayout sl = saved_layout(w, chunk_rows);
+    if (ws_bytes < l.total || bws_bytes < b.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd_keep: workspace too small");
+    if (!saved || saved_bytes < foho_geo_saved_bytes(w, chunk_rows, n_queries)) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd_keep: buffer for the activations too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
+    const float* nof = nullptr;
+    (void)nof;
+    for (int64_t r0 = 0, c = 0; r0 < n_queries; r0 += chunk_rows, c++) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
-        const float* q = queries + 3 * r0;
-        const dim3 rows((M + 3) / 4), blk(256);
-        // ---- the forward chain again, keeping what the backward needs
-        hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), blk, 0, s, q, M, w->n_freqs, w->freqs, E);
-        if (int rc = gemm(0, E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, X0, W, M, W, 64, 1.0f, s)) return rc;
-        hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, X0, W, w->ln_q_g, w->ln_q_b, Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
-        if (int rc = gemm(EP_TRANS, Xn, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, Qs, W, M, W, W, qscale, s, QsT, b.ldt)) return rc;
-        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), blk, 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse);
-        if (int rc = gemm(EP_RESID, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s)) return rc;
-        hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, X1, W, w->ln_2_g, w->ln_2_b, Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
-        if (int rc = gemm(EP_GELU | EP_SAVEZ, Xn, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, H, F, M, F, W, 1.0f, s, Z, F)) return rc;
-        if (int rc = gemm(EP_RESID, H, F, (const h16*)w->w_fc2, F, w->b_fc2, X1, W, X2, W, M, W, F, 1.0f, s)) return rc;
-        // ---- backwards: logits -> ln_post -> fc2 -> GELU -> fc1 -> ln_2 (+ residual) -> c_proj -> attention (K, V)
-        hipLaunchKernelGGL(k_geo_ln_bwd<1>, rows, blk, 0, s, X2, w->ln_post_g, (const h16*)nullptr, (const h16*)nullptr, grad_logits + r0, w->out_gain, w->w_out,
-                           dX2, M, W, w->ln_eps);
-        if (int rc = gemm(EP_GELUBWD, dX2, W, (const h16*)w->w_fc2_t, W, w->zeros, Z, F, H, F, M, F, W, 1.0f, s)) return rc;          // dZ -> H
-        if (int rc = gemm(0, H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, Xn, W, M, W, F, 1.0f, s)) return rc;                 // d ln_2 out -> Xn
-        hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, X1, w->ln_2_g, Xn, dX2, nof, 0.0f, nof, X0, M, W, w->ln_eps);                // dX1 -> X0
-        if (int rc = gemm(EP_TRANS, X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, dX2, W, M, W, W, 1.0f, s, dAT, b.ldt)) return rc;   // dO -> dX2
-        hipLaunchKernelGGL(k_geo_delta, rows, blk, 0, s, dX2, At, W, NH, M, delta);
-        if (!launch_ok("foho_geo_decode_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
-        const int ntiles = (M + BQ - 1) / BQ, nkb = Lr / 128;
-        const int splits = std::max(1, std::min(ntiles, (4 * 256 + nkb * NH - 1) / (nkb * NH)));   // ~4 workgroups per CU
-        hipLaunchKernelGGL(k_geo_attn_bwd, dim3(nkb * NH * splits), blk, 0, s, Qs, QsT, dX2, dAT, b.ldt, lse, delta, kv, 2 * W, W, NH, M, splits, grad_kv);
-        if (!launch_ok("k_geo_attn_bwd")) return FOHO_ERR_LAUNCH;
+        const ChunkPtrs P = chunk_ptrs(b, (char*)bws, sl, (char*)saved + c * sl.total);
+        // columns of Qs^T beyond a ragged block's rows meet P = 0 in the backward and must be finite
+        if ((M & 63) && hipMemsetAsync(P.QsT, 0, (size_t)w->width * b.ldt * 2, s) != hipSuccess) return fail(FOHO_ERR_LAUNCH, "foho_geo_decode_fwd_keep: memset failed");
+        if (int rc = chain_fwd_keep(w, queries + 3 * r0, M, P, kv, vt, s)) return rc;
+        hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, P.X2, w->width, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, w->width, w->ln_eps,
+                           w->w_out, w->b_out, queries + 3 * r0, w->prior_radius, w->prior_sharpness, w->out_gain, logits + r0);
+        if (!launch_ok("k_geo_ln(post)")) return FOHO_ERR_LAUNCH;
     }
     return FOHO_OK;
+}
+
+extern "C" int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+                                   int32_t chunk_rows, void* ws, size_t ws_bytes, void* bws, size_t bws_bytes, const void* saved, size_t saved_bytes,
+                                   void* stream_) {
+    if (int rc = bwd_args("foho_geo_decode_bwd", w, queries, grad_logits, ws, bws, chunk_rows, n_queries, true)) return rc;
+    if (!grad_kv) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd: null argument");
+    const Layout l = layout(w, chunk_rows);
+    const BwdLayout b = bwd_layout(w, chunk_rows);
+    const SavedLayout sl = saved_layout(w, chunk_rows);
+    if (ws_bytes < l.total || bws_bytes < b.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_bwd: workspace too small");
+    if (saved && saved_bytes < foho_geo_saved_bytes(w, chunk_rows, n_queries)) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_bwd: buffer of activations too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
+    char* base = (char*)bws;
+    const int W = w->width, Lr = w->n_latents;
+    // columns of the transposed copies beyond a ragged block's rows must be finite (they meet P = 0): clear them once
+    if (hipMemsetAsync(base + b.dat, 0, (size_t)W * b.ldt * 2, s) != hipSuccess || (!saved && hipMemsetAsync(base + b.qst, 0, (size_t)W * b.ldt * 2, s) != hipSuccess))
+        return fail(FOHO_ERR_LAUNCH, "foho_geo_decode_bwd: memset failed");
+    float* part = (float*)(base + b.part);
+    if (n_queries == 0) return hipMemsetAsync(grad_kv, 0, (size_t)Lr * 2 * W * 4, s) == hipSuccess ? FOHO_OK : fail(FOHO_ERR_LAUNCH, "foho_geo_decode_bwd: memset failed");
+    for (int64_t r0 = 0, c = 0; r0 < n_queries; r0 += chunk_rows, c++) {
+        const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
+        const ChunkPtrs P = chunk_ptrs(b, base, sl, saved ? (char*)const_cast<void*>(saved) + c * sl.total : nullptr);
+        if (!saved)
+            if (int rc = chain_fwd_keep(w, queries + 3 * r0, M, P, kv, vt, s)) return rc;
+        if (int rc = chain_bwd(w, grad_logits + r0, M, P, kv, b.splits, r0 > 0 ? 1 : 0, part, s)) return rc;
+    }
+    const size_t n4 = (size_t)Lr * 2 * W / 4;
+    hipLaunchKernelGGL(k_geo_dkv_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, b.splits, n4, grad_kv);
+    return launch_ok("k_geo_dkv_reduce") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.

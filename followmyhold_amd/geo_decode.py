@@ -104,6 +104,7 @@ class HipGeoDecoder:
         self.chunk = int(chunk_rows or self.CHUNK)
         self.workspace = None
         self.bwd_workspace = None
+        self.keep_activations = True      # forward under autograd keeps what the backward needs (False: recompute, no memory)
         self._prepared = None
         for fn in (self.lib.foho_geo_workspace_bytes, self.lib.foho_geo_bwd_workspace_bytes):
             fn.restype = ctypes.c_size_t
@@ -159,21 +160,43 @@ class HipGeoDecoder:
                                              ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_set_kv")
         self._prepared = None
 
-    def decode_bwd(self, queries, grad_logits):
-        """d sum(grad_logits . logits) / d kv -> (L, 2 width) float32, for the K / V of the last set_kv() / prepare()."""
+    def _bwd_ws(self):
+        if self.bwd_workspace is None:
+            n = int(self.lib.foho_geo_bwd_workspace_bytes(ctypes.byref(self.w), self.chunk))
+            self.bwd_workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self.bwd_workspace
+
+    def decode_keep(self, queries):
+        """decode() for a forward whose backward will follow: -> (logits (N,) float32, saved), `saved` = the activations
+        decode_bwd needs (18 KB per query at width 1024: 5 GB for a 65^3 grid), so that it does not recompute them."""
+        q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
+        self.lib.foho_geo_saved_bytes.restype = ctypes.c_size_t
+        n = int(self.lib.foho_geo_saved_bytes(ctypes.byref(self.w), ctypes.c_int32(self.chunk), ctypes.c_int64(q.shape[0])))
+        saved = torch.empty(n, dtype=torch.uint8, device=self.device)
+        out = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
+        bws = self._bwd_ws()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_decode_fwd_keep(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(out.data_ptr()),
+                                                      ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()), ctypes.c_size_t(self.workspace.numel()),
+                                                      L.vp(bws.data_ptr()), ctypes.c_size_t(bws.numel()), L.vp(saved.data_ptr()),
+                                                      ctypes.c_size_t(saved.numel()), L.vp(stream)), "foho_geo_decode_fwd_keep")
+        return out, saved
+
+    def decode_bwd(self, queries, grad_logits, saved=None):
+        """d sum(grad_logits . logits) / d kv -> (L, 2 width) float32, for the K / V of the last set_kv() / prepare(); with
+        `saved` (decode_keep) from the kept activations, without from a recomputation of the forward per row block."""
         q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
         g = grad_logits.reshape(-1).to(self.device, torch.float32).contiguous()
         if g.shape[0] != q.shape[0]:
             raise L.FohoError(f"HipGeoDecoder: {q.shape[0]} queries, {g.shape[0]} logit gradients")
-        if self.bwd_workspace is None:
-            n = int(self.lib.foho_geo_bwd_workspace_bytes(ctypes.byref(self.w), self.chunk))
-            self.bwd_workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        bws = self._bwd_ws()
         out = torch.empty(self.w.n_latents, 2 * self.w.width, dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self.lib.foho_geo_decode_bwd(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(g.data_ptr()),
                                                  L.vp(out.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
-                                                 ctypes.c_size_t(self.workspace.numel()), L.vp(self.bwd_workspace.data_ptr()),
-                                                 ctypes.c_size_t(self.bwd_workspace.numel()), L.vp(stream)), "foho_geo_decode_bwd")
+                                                 ctypes.c_size_t(self.workspace.numel()), L.vp(bws.data_ptr()), ctypes.c_size_t(bws.numel()),
+                                                 L.vp(saved.data_ptr()) if saved is not None else None,
+                                                 ctypes.c_size_t(saved.numel() if saved is not None else 0), L.vp(stream)), "foho_geo_decode_bwd")
         return out
 
     def decode(self, queries):
@@ -200,21 +223,26 @@ class HipGeoDecoder:
 
 
 class _GeoDecodeFn(torch.autograd.Function):
-    """logits(kv): forward = foho_geo_set_kv + foho_geo_decode_fwd, backward = foho_geo_decode_bwd (which recomputes the
-    forward per row block: nothing but kv and the query points is kept between the two)."""
+    """logits(kv): forward = foho_geo_set_kv + foho_geo_decode_fwd_keep (the activations the backward needs stay in HBM, 5 GB
+    per 65^3 grid; `dec.keep_activations = False`: foho_geo_decode_fwd, and the backward recomputes the forward per row block),
+    backward = foho_geo_decode_bwd."""
 
     @staticmethod
     def forward(ctx, kv, queries, dec):
         dec.set_kv(kv)
         ctx.dec = dec
+        if dec.keep_activations:
+            out, saved = dec.decode_keep(queries)
+            ctx.save_for_backward(kv.detach(), queries, saved)
+            return out
         ctx.save_for_backward(kv.detach(), queries)
         return dec.decode(queries)
 
     @staticmethod
     def backward(ctx, grad):
-        kv, queries = ctx.saved_tensors
+        kv, queries, *saved = ctx.saved_tensors
         ctx.dec.set_kv(kv)                    # the workspace may have served another decode since
-        return ctx.dec.decode_bwd(queries, grad).to(kv.dtype), None, None
+        return ctx.dec.decode_bwd(queries, grad, saved[0] if saved else None).to(kv.dtype), None, None
 
 
 def install(vae, device="cuda", chunk_rows=None):

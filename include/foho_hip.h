@@ -433,16 +433,24 @@ int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t
  * foho_geo_set_kv installs K / V computed by the caller -- kv (n_latents, 2 width) fp16 = c_kv(ln(latents)), rows [K of all
  * heads | V of all heads]: the caller's autograd owns LayerNorm + projection of the 3072 tokens (0.1 % of the work) -- into the
  * forward workspace, in place of foho_geo_prepare.  foho_geo_decode_bwd then returns grad_kv (n_latents, 2 width) fp32 =
- * d sum(grad_logits . logits) / d kv for the logits foho_geo_decode_fwd computes from those K / V and `queries`: per row block
- * it RECOMPUTES the forward chain (nothing is kept between the two calls: 14.5 KB per query would be 4 GB per 65^3 grid)
- * with the pre-activation, the attention's log-sum-exp and transposed copies of Q saved, and runs the chain backwards --
- * LayerNorm / GELU backward, three GEMMs with the transposed weights, the attention backward for K and V (queries are
- * constants: nothing flows to them).  `bwd_workspace`: foho_geo_bwd_workspace_bytes(w, chunk_rows). */
+ * d sum(grad_logits . logits) / d kv for the logits the forward computes from those K / V and `queries`, running the chain
+ * backwards per row block -- LayerNorm / GELU backward, three GEMMs with the transposed weights, the attention backward for K and
+ * V (queries are constants: nothing flows to them); no atomics: partial sums per (split of the row tiles, key block), added in a
+ * fixed order, so the result is bitwise repeatable.  What the backward needs from the forward (pre-activation, attention output and
+ * log-sum-exp, the scaled queries in both orientations, the two residual streams: 18.1 KB per query at width 1024) comes
+ *   - from `saved`, filled by foho_geo_decode_fwd_keep (the forward to call when a backward will follow; foho_geo_saved_bytes:
+ *     5 GB for a 65^3 grid -- the part has 288), or
+ *   - with saved = NULL, from a RECOMPUTATION of the forward chain per row block (+11 ms per 65^3 grid, no memory).
+ * `bwd_workspace`: foho_geo_bwd_workspace_bytes(w, chunk_rows), used by both calls. */
 size_t foho_geo_bwd_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
+size_t foho_geo_saved_bytes(const foho_geo_weights* w, int32_t chunk_rows, int64_t n_queries);
 int foho_geo_set_kv(const foho_geo_weights* w, const void* kv, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
+                             void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, void* saved,
+                             size_t saved_bytes, void* stream);
 int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
                         int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
-                        void* stream);
+                        const void* saved, size_t saved_bytes, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.

@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/r04l
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > gpurun_out/r04l/gpu_tests.log
-cat gpurun_out/r04l/gpu_tests.log
+timeout 600 python -m pytest tests/test_geo_decode.py tests/test_pipeline.py -x -q -m gpu 2>&1 | tail -8
+timeout 600 python scripts/geo_bench.py 2>&1 | tail -1

@@ -170,13 +170,22 @@ def test_decoder_backward_against_torch_autograd(width, heads, n_lat, n_q, chunk
     err = (gh - gr).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(gh.flatten(), gr.flatten(), dim=0).item()
     assert err <= 1e-2 * gr.abs().max().item() and cos >= 1 - 1e-4, (err, gr.abs().max().item(), cos)
-    # the K / V gradient on its own (before torch's LayerNorm / projection backward), against autograd on the same K / V
+    # the K / V gradient on its own: from kept activations and from the recomputed forward -- the same kernels on the same
+    # numbers, no atomics anywhere (partial sums per (split, key block), fixed order): bitwise equal, bitwise repeatable
     kv = hip.kv_of(lat).detach()
     hip.set_kv(kv)
     gkv = hip.decode_bwd(q.float(), go)
     gkv2 = hip.decode_bwd(q.float(), go)
-    rel = (gkv - gkv2).abs().max().item() / gkv.abs().max().item()
-    assert rel <= 1e-5, rel                       # fp32 atomics: the order of the row blocks' contributions varies, nothing else
+    assert torch.isfinite(gkv).all() and torch.equal(gkv, gkv2)
+    out_k, saved = hip.decode_keep(q.float())
+    # (the keeping forward is another instantiation of the GEMM epilogue: where the compiler folds "times scale, to fp16" into
+    # one v_fma_mixlo_f16 it rounds once, elsewhere twice -- a handful of logits differ in the last fp16 bit of an activation)
+    assert (out_k - hip.decode(q.float())).abs().max().item() <= 1e-3 * dec.gain
+    assert torch.equal(hip.decode_bwd(q.float(), go, saved), gkv)
+    hip.keep_activations = False
+    lat_n = lat.clone().requires_grad_(True)
+    (hip(q.float(), lat_n).float() * go).sum().backward()
+    assert torch.equal(lat_n.grad, lat_h.grad)
 
 
 @gpu
