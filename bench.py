@@ -272,10 +272,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # FOHO_BENCH_FORCE_DIST=1: join a process group even as the only rank, so that the RCCL branch of this file (init with
+    # a device id, barriers, device-side all-reduces) runs on a one-GPU box too (tests/test_bench_gpu.py)
+    if world > 1 or os.environ.get("FOHO_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

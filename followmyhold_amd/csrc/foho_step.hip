@@ -292,7 +292,7 @@ static WS make_ws(const foho_dims& d) {
     w.vbox = take(B * (size_t)VERT_BLOCKS_MAX * 4 * 8 * 4);  // world-space AABB of every 64 consecutive object vertices (k_xform -> role_knn)
     w.world = take(V3);
     w.ndc = take(V3);
-    w.vn_raw = take(V3);
+    w.vn_raw = take((size_t)d.Vtot * 16);  // per vertex: normalised raw normal (by the reciprocal) + the reciprocal norm
     w.vn = take(V3);
     w.face_ndc = take((size_t)d.Ftot * 9 * 4);
     w.state_next = take(B * (size_t)STATE_NEXT * 4);   // deferred update: params 16 | adam m 16 | adam v 16 | t | flags, written by k_xform

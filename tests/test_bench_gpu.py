@@ -99,3 +99,17 @@ def test_bench_plain_form_launches_one_rank_per_gpu():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode != 0
     assert r.stdout.count("bench.py needs an MI355X") == 2, r.stdout[-3000:]
+
+
+@gpu
+def test_bench_rccl_branch_runs_with_one_rank():
+    """The box has one GPU, so the N > 1 tests above go through gloo.  FOHO_BENCH_FORCE_DIST=1 makes the single rank join an
+    `nccl` (= RCCL) process group all the same: init with the device id, the barriers around the timed region and the
+    device-side all-reduces of the timing and the metrics vector all execute on the real backend."""
+    flags = ["--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + flags, env=_env(FOHO_BENCH_FORCE_DIST="1"), cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    o = _line(r.stdout)
+    assert o["n_gpus"] == 1 and o["rccl_ranks"] == 1 and o["collective_backend"] == "nccl"
+    assert o["metrics"]["n_images"] == 1 and o["nan_images"] == 0 and o["value"] > 0
