@@ -410,7 +410,7 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
-                                                     int heads, float* __restrict__ lse) {
+                                                     int heads, float* __restrict__ nlse) {
     __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     int head, qblk;
@@ -576,9 +576,10 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         const float lt = lsum[qb] + other_half(lsum[qb]);
         const float inv = 1.0f / lt;
         const int row = q0 + qb * 32 + l31;
+        // MINUS the log2 of the softmax denominator in the scores' own (log2) units: the backward pass starts its score accumulators
+        // at this value and gets P = exp2(s - lse) without a subtraction; -inf for the rows that pad the last tile of 64 (P = 0)
+        if (nlse && hi == 0 && row < ((M + 63) & ~63)) nlse[(size_t)row * heads + head] = (row < M) ? negm[qb][0] - __builtin_amdgcn_logf(lt) : -INFINITY;
         if (row < M) {
-            // log2 of the softmax denominator in the scores' own (log2) units: the backward pass rebuilds P = exp2(s - lse)
-            if (lse && hi == 0) lse[(size_t)row * heads + head] = __builtin_amdgcn_logf(lt) - negm[qb][0];
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -616,19 +617,34 @@ __global__ void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, i
 // ------------------------------------------------------------------------------------------------
 constexpr int BQ = 64;  // queries per tile
 
+__device__ __forceinline__ void glds4(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ f32x16 cat16(f32x4 a, f32x4 b, f32x4 c, f32x4 d) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    const f32x8 lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+
+// Staging: LDS-DMA (no staging registers, no ds_write pass), tile t + 1 in flight while tile t is computed; every LDS read of the
+// loop is inline assembly with its own s_waitcnt (a read the compiler can see after an LDS-DMA gets a vmcnt(0) in front of it).
+// The accumulators of S and dP are INITIALISED by reads of -lse / -delta (stored negated by the producers), so S - lse and
+// dP - delta come out of the matrix pipe.  One tile = ten groups of four matrix instructions; the reads of group i + 1 are
+// issued before the instructions of group i, and the softmax / dS arithmetic of one half of the queries is written BETWEEN the
+// matrix instructions of the other half's groups: a wave issues in order, so vector work only overlaps its own matrix work when
+// the two alternate in the instruction stream.
 __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__ Qs, const h16* __restrict__ QsT, const h16* __restrict__ dO,
-                                                         const h16* __restrict__ dOT, int ldt, const float* __restrict__ lse,
-                                                         const float* __restrict__ delta, const h16* __restrict__ KV, int ldkv, int width,
+                                                         const h16* __restrict__ dOT, int ldt, const float* __restrict__ nlse,
+                                                         const float* __restrict__ ndelta, const h16* __restrict__ KV, int ldkv, int width,
                                                          int heads, int M, int splits, int L, int accumulate, float* __restrict__ part) {
     __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
-    __shared__ float lsd[2][2][BQ];       // [buffer][lse | delta]
+    __shared__ float lsd[2][2][BQ];       // [buffer][-lse | -delta]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int nkt = gridDim.x / (heads * splits);
     int bid = blockIdx.x;
     const int split = bid % splits;
     bid /= splits;
     const int head = bid % heads, kt = bid / heads;
-    (void)nkt;
     const int key = kt * 128 + w * 32 + l31;
     half8 kf[4], vf[4];   // B operands: lane (key, hi) holds K / V [key][16 kk + 8 hi .. + 7]
 #pragma unroll
@@ -636,106 +652,170 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
         kf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + head * 64 + 16 * kk + 8 * hi);
         vf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + width + head * 64 + 16 * kk + 8 * hi);
     }
-    f32x16 dk[2], dv[2];  // dK^T / dV^T [d tile]: rows d, columns key
+    f32x16 dk0, dk1, dv0, dv1;  // dK^T / dV^T [d tile]: rows d, columns key
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dk[a][r] = dv[a][r] = 0.0f;
-
-    const int srow = tid >> 3, sch = tid & 7;
-    const int sidx = srow * 8 + (sch ^ swz(srow));
+    for (int r = 0; r < 16; r++) dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.0f;
     const int ntiles = (M + BQ - 1) / BQ;
-    uint4 s0, s1, s2, s3, s4, s5, s6, s7;
-    float sl = 0.0f;
-#define BWD_GLOAD(ti)                                                                                              \
-    do {                                                                                                           \
-        const int q0_ = (ti) * BQ;                                                                                 \
-        const size_t ra_ = (size_t)min(q0_ + srow, M - 1) * width + head * 64 + sch * 8;                           \
-        const size_t rb_ = (size_t)min(q0_ + srow + 32, M - 1) * width + head * 64 + sch * 8;                      \
-        const size_t ta_ = (size_t)(head * 64 + srow) * ldt + q0_ + sch * 8;                                       \
-        s0 = *reinterpret_cast<const uint4*>(Qs + ra_);                                                            \
-        s1 = *reinterpret_cast<const uint4*>(Qs + rb_);                                                            \
-        s2 = *reinterpret_cast<const uint4*>(dO + ra_);                                                            \
-        s3 = *reinterpret_cast<const uint4*>(dO + rb_);                                                            \
-        s4 = *reinterpret_cast<const uint4*>(QsT + ta_);                                                           \
-        s5 = *reinterpret_cast<const uint4*>(QsT + ta_ + (size_t)32 * ldt);                                        \
-        s6 = *reinterpret_cast<const uint4*>(dOT + ta_);                                                           \
-        s7 = *reinterpret_cast<const uint4*>(dOT + ta_ + (size_t)32 * ldt);                                        \
-        if (tid < 2 * BQ) {                                                                                        \
-            const int q_ = q0_ + (tid & (BQ - 1));                                                                 \
-            sl = (tid < BQ) ? ((q_ < M) ? lse[(size_t)q_ * heads + head] : INFINITY)                               \
-                            : ((q_ < M) ? delta[(size_t)q_ * heads + head] : 0.0f);                                \
-        }                                                                                                          \
+
+    // DMA sources: wave w stages rows 16 w .. 16 w + 15 of each of the four tiles, two pieces of 8 rows x 128 bytes; a lane's 16
+    // bytes land at (row, slot = lane & 7), so it FETCHES chunk slot ^ swz(row)
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int row0 = 16 * w + prow, row1 = row0 + 8;
+    const int col0 = head * 64 + ((pslot ^ swz(row0)) << 3), col1 = head * 64 + ((pslot ^ swz(row1)) << 3);
+    const size_t tr0 = (size_t)(head * 64 + row0) * ldt + ((pslot ^ swz(row0)) << 3), tr1 = (size_t)(head * 64 + row1) * ldt + ((pslot ^ swz(row1)) << 3);
+#define BWD_ISSUE(ti, buf)                                                                   \
+    do {                                                                                     \
+        const int q0_ = (ti) * BQ;                                                           \
+        const size_t ra_ = (size_t)min(q0_ + row0, M - 1) * width + col0;                    \
+        const size_t rb_ = (size_t)min(q0_ + row1, M - 1) * width + col1;                    \
+        glds16(Qs + ra_, &lds[buf][0][(16 * w) * 8]);                                        \
+        glds16(Qs + rb_, &lds[buf][0][(16 * w + 8) * 8]);                                    \
+        glds16(dO + ra_, &lds[buf][1][(16 * w) * 8]);                                        \
+        glds16(dO + rb_, &lds[buf][1][(16 * w + 8) * 8]);                                    \
+        glds16(QsT + tr0 + q0_, &lds[buf][2][(16 * w) * 8]);                                 \
+        glds16(QsT + tr1 + q0_, &lds[buf][2][(16 * w + 8) * 8]);                             \
+        glds16(dOT + tr0 + q0_, &lds[buf][3][(16 * w) * 8]);                                 \
+        glds16(dOT + tr1 + q0_, &lds[buf][3][(16 * w + 8) * 8]);                             \
+        if (w == 0) glds4(nlse + (size_t)(q0_ + lane) * heads + head, &lsd[buf][0][0]);      \
+        if (w == 1) glds4(ndelta + (size_t)(q0_ + lane) * heads + head, &lsd[buf][1][0]);    \
     } while (0)
-#define BWD_LWRITE(buf)                                  \
-    do {                                                 \
-        lds[buf][0][sidx] = s0;                          \
-        lds[buf][0][sidx + 256] = s1;                    \
-        lds[buf][1][sidx] = s2;                          \
-        lds[buf][1][sidx + 256] = s3;                    \
-        lds[buf][2][sidx] = s4;                          \
-        lds[buf][2][sidx + 256] = s5;                    \
-        lds[buf][3][sidx] = s6;                          \
-        lds[buf][3][sidx + 256] = s7;                    \
-        if (tid < 2 * BQ) lsd[buf][tid >> 6][tid & (BQ - 1)] = sl; \
-    } while (0)
+
+    // read addresses (buffer 0): A fragments of the row-major tiles (row = query), of the transposed tiles (row = d), -lse / -delta
+    const unsigned lbase = lds_addr(&lds[0][0][0]);
+    unsigned ar0[4], ar1[4], at00[2], at01[2], at10[2], at11[2];  // at<dt><qb>[ks]
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        ar0[kk] = lbase + l31 * 128 + (((2 * kk + hi) ^ swz(l31)) << 4);
+        ar1[kk] = lbase + (32 + l31) * 128 + (((2 * kk + hi) ^ swz(32 + l31)) << 4);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        at00[ks] = lbase + l31 * 128 + (((2 * ks + hi) ^ swz(l31)) << 4);
+        at01[ks] = lbase + l31 * 128 + (((4 + 2 * ks + hi) ^ swz(l31)) << 4);
+        at10[ks] = lbase + (32 + l31) * 128 + (((2 * ks + hi) ^ swz(32 + l31)) << 4);
+        at11[ks] = lbase + (32 + l31) * 128 + (((4 + 2 * ks + hi) ^ swz(32 + l31)) << 4);
+    }
+    const unsigned sbase = lds_addr(&lsd[0][0][0]) + hi * 16;
+
+    // one group's fragments: Qs / dO (A operands of S / dP, K steps 0..3) or dO^T, Qs^T (A operands of dV / dK, query steps 0, 1)
+#define BWD_RD_ROWS(F, AR, TILE_OFF)     \
+    GEO_DSR(F##0, AR[0] + bo, TILE_OFF); \
+    GEO_DSR(F##1, AR[1] + bo, TILE_OFF); \
+    GEO_DSR(F##2, AR[2] + bo, TILE_OFF); \
+    GEO_DSR(F##3, AR[3] + bo, TILE_OFF)
+#define BWD_RD_T(F, AT)                \
+    GEO_DSR(F##0, AT[0] + bo, 24576);  \
+    GEO_DSR(F##1, AT[0] + bo, 16384);  \
+    GEO_DSR(F##2, AT[1] + bo, 24576);  \
+    GEO_DSR(F##3, AT[1] + bo, 16384)
+    // accumulator initial values of query half QB: -lse into S##0..3, -delta into D##0..3 (register r <-> query 32 QB + (r & 3) + 8 (r >> 2) + 4 hi)
+#define BWD_RD_INIT(QB, S, D)                      \
+    GEO_DSR(S##0, sl, (QB) * 128 + 0);             \
+    GEO_DSR(S##1, sl, (QB) * 128 + 32);            \
+    GEO_DSR(S##2, sl, (QB) * 128 + 64);            \
+    GEO_DSR(S##3, sl, (QB) * 128 + 96);            \
+    GEO_DSR(D##0, sl, 256 + (QB) * 128 + 0);       \
+    GEO_DSR(D##1, sl, 256 + (QB) * 128 + 32);      \
+    GEO_DSR(D##2, sl, 256 + (QB) * 128 + 64);      \
+    GEO_DSR(D##3, sl, 256 + (QB) * 128 + 96)
+#define BWD_WAIT4(F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F##0), "+v"(F##1), "+v"(F##2), "+v"(F##3))
+#define BWD_WAIT12(F, S, D)                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                      \
+                 : "+v"(F##0), "+v"(F##1), "+v"(F##2), "+v"(F##3), "+v"(S##0), "+v"(S##1), "+v"(S##2), "+v"(S##3), "+v"(D##0), "+v"(D##1), \
+                   "+v"(D##2), "+v"(D##3))
+#define BWD_MFMA(ACC, F, I, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(F##I, B, ACC, 0, 0, 0)
+    // P (fp16) = exp2(S - lse) of registers [R0, R0 + 8) -> one B operand (k = query); likewise dS = P (dP - delta)
+#define BWD_EXP8(PF, SC, R0)                                                       \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) PF[e_] = ex2(SC[(R0) + e_])
+#define BWD_PACK8(PB, DB, PF, DPV, R0)                                                                               \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; e_ += 2) {                                                            \
+        const f32x2 pp_ = {PF[e_], PF[e_ + 1]}, dd_ = {PF[e_] * DPV[(R0) + e_], PF[e_ + 1] * DPV[(R0) + e_ + 1]};    \
+        const half2v ph_ = __builtin_convertvector(pp_, half2v), dh_ = __builtin_convertvector(dd_, half2v);         \
+        PB[e_] = ph_[0], PB[e_ + 1] = ph_[1], DB[e_] = dh_[0], DB[e_ + 1] = dh_[1];                                  \
+    }
 
     int ti = split, it = 0;
-    if (ti < ntiles) {
-        BWD_GLOAD(ti);
-        BWD_LWRITE(0);
-    }
-    __syncthreads();
+    if (ti < ntiles) BWD_ISSUE(ti, 0);
     for (; ti < ntiles; ti += splits, it++) {
-        const int buf = it & 1;
-        if (ti + splits < ntiles) BWD_GLOAD(ti + splits);
-        const uint4 *lq = lds[buf][0], *ldo = lds[buf][1], *lqt = lds[buf][2], *ldot = lds[buf][3];
-#pragma unroll
-        for (int qb = 0; qb < 2; qb++) {
-            const int qrow = qb * 32 + l31;
-            f32x16 sc, dp;
-#pragma unroll
-            for (int r = 0; r < 16; r++) sc[r] = dp[r] = 0.0f;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const uint4 uq = lq[qrow * 8 + ((2 * kk + hi) ^ swz(qrow))], ud = ldo[qrow * 8 + ((2 * kk + hi) ^ swz(qrow))];
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&uq), kf[kk], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&ud), vf[kk], dp, 0, 0, 0);
-            }
-            // register r of this lane (one key) belongs to query 32 qb + (r & 3) + 8 (r >> 2) + 4 hi
-            half8 pb[2], db[2];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lsd[buf][0][qb * 32 + 8 * g + 4 * hi]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&lsd[buf][1][qb * 32 + 8 * g + 4 * hi]);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const float p0 = ex2(sc[4 * g + e] - l4[e]), p1 = ex2(sc[4 * g + e + 1] - l4[e + 1]);
-                    const f32x2 pp = {p0, p1}, dd = {p0 * (dp[4 * g + e] - d4[e]), p1 * (dp[4 * g + e + 1] - d4[e + 1])};
-                    const half2v ph = __builtin_convertvector(pp, half2v), dh = __builtin_convertvector(dd, half2v);
-                    pb[g >> 1][4 * (g & 1) + e] = ph[0];
-                    pb[g >> 1][4 * (g & 1) + e + 1] = ph[1];
-                    db[g >> 1][4 * (g & 1) + e] = dh[0];
-                    db[g >> 1][4 * (g & 1) + e + 1] = dh[1];
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; dt++) {
-                const int drow = dt * 32 + l31;
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    const int ch = (4 * qb + 2 * ks + hi) ^ swz(drow);
-                    const uint4 ut = ldot[drow * 8 + ch], uqt = lqt[drow * 8 + ch];
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&ut), pb[ks], dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&uqt), db[ks], dk[dt], 0, 0, 0);
-                }
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // tile `it` has landed for every wave, and every wave is done reading the other buffer
+        if (ti + splits < ntiles) {
+            if (it & 1) BWD_ISSUE(ti + splits, 0);
+            else BWD_ISSUE(ti + splits, 1);
         }
-        if (ti + splits < ntiles) BWD_LWRITE(buf ^ 1);
-        __syncthreads();
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(it & 1) << 15, sl = sbase + ((unsigned)(it & 1) << 9);
+        half8 fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;    // two fragment groups in flight
+        f32x4 s00, s01, s02, s03, d00, d01, d02, d03, s10, s11, s12, s13, d10, d11, d12, d13;
+        float pf[8], pg[8];
+        half8 pb0[2], db0[2], pb1[2], db1[2];
+        BWD_RD_INIT(0, s0, d0);
+        BWD_RD_ROWS(fa, ar0, 0);                     // Qs, query half 0
+        BWD_WAIT12(fa, s0, d0);
+        f32x16 sc0 = cat16(s00, s01, s02, s03), dp0 = cat16(d00, d01, d02, d03);
+        BWD_RD_ROWS(fb, ar0, 8192);                  // dO, half 0
+        BWD_RD_INIT(1, s1, d1);
+        // ---- group 1: S, half 0
+        BWD_MFMA(sc0, fa, 0, kf[0]); BWD_MFMA(sc0, fa, 1, kf[1]); BWD_MFMA(sc0, fa, 2, kf[2]); BWD_MFMA(sc0, fa, 3, kf[3]);
+        BWD_WAIT12(fb, s1, d1);
+        f32x16 sc1 = cat16(s10, s11, s12, s13), dp1 = cat16(d10, d11, d12, d13);
+        BWD_RD_ROWS(fa, ar1, 0);                     // Qs, half 1
+        // ---- group 2: dP, half 0
+        BWD_MFMA(dp0, fb, 0, vf[0]); BWD_MFMA(dp0, fb, 1, vf[1]); BWD_MFMA(dp0, fb, 2, vf[2]); BWD_MFMA(dp0, fb, 3, vf[3]);
+        BWD_WAIT4(fa);
+        BWD_RD_ROWS(fb, ar1, 8192);                  // dO, half 1
+        // ---- group 3: S, half 1 || exp of half 0
+        BWD_MFMA(sc1, fa, 0, kf[0]);
+        BWD_EXP8(pf, sc0, 0);
+        BWD_MFMA(sc1, fa, 1, kf[1]);
+        BWD_MFMA(sc1, fa, 2, kf[2]);
+        BWD_EXP8(pg, sc0, 8);
+        BWD_MFMA(sc1, fa, 3, kf[3]);
+        BWD_WAIT4(fb);
+        BWD_RD_T(fa, at00);                          // dO^T / Qs^T rows d 0..31, half 0
+        // ---- group 4: dP, half 1 || dS of half 0
+        BWD_MFMA(dp1, fb, 0, vf[0]);
+        BWD_PACK8(pb0[0], db0[0], pf, dp0, 0);
+        BWD_MFMA(dp1, fb, 1, vf[1]);
+        BWD_MFMA(dp1, fb, 2, vf[2]);
+        BWD_PACK8(pb0[1], db0[1], pg, dp0, 8);
+        BWD_MFMA(dp1, fb, 3, vf[3]);
+        BWD_WAIT4(fa);
+        BWD_RD_T(fb, at10);                          // rows d 32..63, half 0
+        // ---- group 5: dV, dK (d 0..31) of half 0 || exp of half 1
+        BWD_MFMA(dv0, fa, 0, pb0[0]);
+        BWD_EXP8(pf, sc1, 0);
+        BWD_MFMA(dk0, fa, 1, db0[0]);
+        BWD_MFMA(dv0, fa, 2, pb0[1]);
+        BWD_EXP8(pg, sc1, 8);
+        BWD_MFMA(dk0, fa, 3, db0[1]);
+        BWD_WAIT4(fb);
+        BWD_RD_T(fa, at01);                          // rows d 0..31, half 1
+        // ---- group 6: dV, dK (d 32..63) of half 0 || dS of half 1
+        BWD_MFMA(dv1, fb, 0, pb0[0]);
+        BWD_PACK8(pb1[0], db1[0], pf, dp1, 0);
+        BWD_MFMA(dk1, fb, 1, db0[0]);
+        BWD_MFMA(dv1, fb, 2, pb0[1]);
+        BWD_PACK8(pb1[1], db1[1], pg, dp1, 8);
+        BWD_MFMA(dk1, fb, 3, db0[1]);
+        BWD_WAIT4(fa);
+        BWD_RD_T(fb, at11);                          // rows d 32..63, half 1
+        // ---- groups 7, 8: dV, dK of half 1
+        BWD_MFMA(dv0, fa, 0, pb1[0]); BWD_MFMA(dk0, fa, 1, db1[0]); BWD_MFMA(dv0, fa, 2, pb1[1]); BWD_MFMA(dk0, fa, 3, db1[1]);
+        BWD_WAIT4(fb);
+        BWD_MFMA(dv1, fb, 0, pb1[0]); BWD_MFMA(dk1, fb, 1, db1[0]); BWD_MFMA(dv1, fb, 2, pb1[1]); BWD_MFMA(dk1, fb, 3, db1[1]);
     }
-#undef BWD_GLOAD
-#undef BWD_LWRITE
+#undef BWD_ISSUE
+#undef BWD_RD_ROWS
+#undef BWD_RD_T
+#undef BWD_RD_INIT
+#undef BWD_WAIT4
+#undef BWD_WAIT12
+#undef BWD_MFMA
+#undef BWD_EXP8
+#undef BWD_PACK8
+    __syncthreads();
+    f32x16 dk[2] = {dk0, dk1}, dv[2] = {dv0, dv1};
     // This workgroup's sums -> part[split][key][dK (ln 2 folded in) | dV]: the (split, key block, head) slice is this workgroup's
     // alone, launches of successive row blocks are ordered by the stream, so a plain read-modify-write accumulates over the
     // row blocks -- no atomics (16 384 per workgroup were 0.8 of the kernel's time at 21-26 memory-side atomics per ns), and
@@ -784,17 +864,18 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce(const float* __restrict_
     reinterpret_cast<f32x4*>(out)[i] = a;
 }
 
-// delta[q][head] = sum_d dO[q][head, d] O[q][head, d]: one wave per row, 8 lanes per head and half row
+// ndelta[q][head] = - sum_d dO[q][head, d] O[q][head, d] (negated: the backward attention starts its dP accumulators there); one
+// wave per row, 8 lanes per head and half row; rows M .. the next multiple of 64 (the padding of the last query tile) get 0
 __global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, const h16* __restrict__ O, int width, int heads, int M,
-                                                   float* __restrict__ delta) {
+                                                   float* __restrict__ ndelta) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    if (row >= ((M + 63) & ~63)) return;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int col = (c * 64 + lane) * 8;
         float s = 0.0f;
-        if (col < width) {
+        if (col < width && row < M) {
             const half8 a = *reinterpret_cast<const half8*>(dO + (size_t)row * width + col), b = *reinterpret_cast<const half8*>(O + (size_t)row * width + col);
 #pragma unroll
             for (int e = 0; e < 8; e++) s += (float)a[e] * (float)b[e];
@@ -802,7 +883,7 @@ __global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, c
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        if ((lane & 7) == 0 && col < width) delta[(size_t)row * heads + col / 64] = s;
+        if ((lane & 7) == 0 && col < width) ndelta[(size_t)row * heads + col / 64] = -s;
     }
 }
 
@@ -1176,8 +1257,8 @@ static BwdLayout bwd_layout(const foho_geo_weights* w, int chunk) {
     l.x2 = take(C * W * 2);
     l.dx2 = take(C * W * 2);
     l.dat = take(W * (size_t)l.ldt * 2);
-    l.lse = take(C * (size_t)w->heads * 4);
-    l.delta = take(C * (size_t)w->heads * 4);
+    l.lse = take((size_t)l.ldt * w->heads * 4);    // rows up to the next multiple of 64: the padding of the last query tile
+    l.delta = take((size_t)l.ldt * w->heads * 4);
     l.splits = bwd_splits(w, chunk);
     l.part = take((size_t)l.splits * w->n_latents * 2 * W * 4);
     l.total = off;
@@ -1223,7 +1304,7 @@ static SavedLayout saved_layout(const foho_geo_weights* w, int chunk) {
     l.x1 = take(C * W * 2);
     l.z = take(C * F * 2);
     l.x2 = take(C * W * 2);
-    l.lse = take(C * (size_t)w->heads * 4);
+    l.lse = take(ldt * (size_t)w->heads * 4);
     l.total = off;
     return l;
 }
@@ -1264,7 +1345,7 @@ static int chain_bwd(const foho_geo_weights* w, const float* grad_logits, int M,
     if (int rc = gemm(0, P.H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, P.Xn, W, M, W, F, 1.0f, s)) return rc;                       // d ln_2 out -> Xn
     hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, P.X1, w->ln_2_g, P.Xn, P.dX2, nof, 0.0f, nof, P.X0, M, W, w->ln_eps);                // dX1 -> X0
     if (int rc = gemm(EP_TRANS, P.X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, P.dX2, W, M, W, W, 1.0f, s, P.dAT, P.ldt)) return rc;  // dO -> dX2
-    hipLaunchKernelGGL(k_geo_delta, rows, blk, 0, s, P.dX2, P.At, W, NH, M, P.delta);
+    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), blk, 0, s, P.dX2, P.At, W, NH, M, P.delta);
     if (!launch_ok("geometry decoder backward chain (row kernels)")) return FOHO_ERR_LAUNCH;
     const int nkb = Lr / 128;
     hipLaunchKernelGGL(k_geo_attn_bwd, dim3(nkb * NH * splits), blk, 0, s, P.Qs, P.QsT, P.dX2, P.dAT, P.ldt, P.lse, P.delta, kv, 2 * W, W, NH, M, splits, Lr,

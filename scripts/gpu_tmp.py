@@ -1,16 +1,40 @@
-import sys, os, torch
+import sys, os, time, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from test_geo_decode import _decoder
+from followmyhold_amd import standins
 from followmyhold_amd.geo_decode import HipGeoDecoder
-for (width, heads, n_lat, n_q, chunk) in [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384)]:
-    dec = _decoder(width, heads, n_lat)
-    g = torch.Generator().manual_seed(5)
-    lat = torch.randn(1, n_lat, width, generator=g).half().cuda()
-    q = (torch.rand(1, n_q, 3, generator=g) * 2.2 - 1.1).half().cuda()
-    hip = HipGeoDecoder.from_module(dec, chunk_rows=chunk)
-    hip.set_kv(hip.kv_of(lat).detach())
-    a = hip.decode(q.float()); b, saved = hip.decode_keep(q.float()); c = hip.decode(q.float()); d, _ = hip.decode_keep(q.float())
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=1, num_freqs=8)
+mod = vae.geo_decoder.to(dev).eval()
+n = 65 ** 3
+q = (torch.rand(n, 3, device=dev) * 2.2 - 1.1).half().float()
+lat = torch.randn(1, 3072, 1024, device=dev).half()
+def bench(nstreams, chunk):
+    decs = [HipGeoDecoder.from_module(mod, device=dev, chunk_rows=chunk) for _ in range(nstreams)]
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    per = (n + nstreams - 1) // nstreams
+    per = (per + chunk - 1) // chunk * chunk if nstreams > 1 else n
+    parts = [q[i * per:(i + 1) * per] for i in range(nstreams)]
+    for d in decs:
+        d.prepare(lat)
     torch.cuda.synchronize()
-    print(width, "decode vs decode", (a - c).abs().max().item(), "keep vs keep", (b - d).abs().max().item(), "decode vs keep", (a - b).abs().max().item(),
-          "rows differing", (a != b).nonzero().flatten()[:10].tolist(), int((a != b).sum()))
+    def run():
+        cur = torch.cuda.current_stream()
+        outs = []
+        for d, s, p in zip(decs, streams, parts):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs.append(d.decode(p))
+        for s in streams:
+            cur.wait_stream(s)
+        return outs
+    run(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); o = run(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3, torch.cat(o)
+ref_t, ref = bench(1, 16384)
+print(f"1 stream chunk 16384: {ref_t:.2f} ms")
+for ns, ch in ((1, 8192), (1, 32768), (2, 8192), (2, 16384), (3, 8192), (4, 4096), (4, 8192)):
+    t, o = bench(ns, ch)
+    print(f"{ns} stream(s) chunk {ch}: {t:.2f} ms  equal {torch.equal(o, ref)}", flush=True)
