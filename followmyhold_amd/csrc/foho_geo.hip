@@ -641,10 +641,13 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
     __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
     __shared__ float lsd[2][2][BQ];       // [buffer][-lse | -delta]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    int bid = blockIdx.x;
-    const int split = bid % splits;
-    bid /= splits;
-    const int head = bid % heads, kt = bid / heads;
+    // The L / 128 workgroups of one (head, split) GROUP stream the same query tiles: a group's workgroups get consecutive slots on
+    // ONE XCD (workgroup b runs on XCD b % 8), so that a tile comes over the fabric once per group and out of that XCD's L2 for the
+    // rest (dealt out round robin over the XCDs every tile was fetched by all of them: 463 -> 450 us).
+    const int nkb = L / 128, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int grp = (slot / nkb) * 8 + xcd, kt = slot % nkb;
+    if (grp >= heads * splits) return;
+    const int split = grp % splits, head = grp / splits;
     const int key = kt * 128 + w * 32 + l31;
     half8 kf[4], vf[4];   // B operands: lane (key, hi) holds K / V [key][16 kk + 8 hi .. + 7]
 #pragma unroll
@@ -1348,7 +1351,7 @@ static int chain_bwd(const foho_geo_weights* w, const float* grad_logits, int M,
     hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), blk, 0, s, P.dX2, P.At, W, NH, M, P.delta);
     if (!launch_ok("geometry decoder backward chain (row kernels)")) return FOHO_ERR_LAUNCH;
     const int nkb = Lr / 128;
-    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(nkb * NH * splits), blk, 0, s, P.Qs, P.QsT, P.dX2, P.dAT, P.ldt, P.lse, P.delta, kv, 2 * W, W, NH, M, splits, Lr,
+    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((NH * splits + 7) / 8) * nkb), blk, 0, s, P.Qs, P.QsT, P.dX2, P.dAT, P.ldt, P.lse, P.delta, kv, 2 * W, W, NH, M, splits, Lr,
                        accumulate, part);
     return launch_ok("k_geo_attn_bwd") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
