@@ -127,6 +127,34 @@ def sq_table(workload):
     return {}, None
 
 
+def geo_pipe_busy():
+    """Matrix / vector / LDS pipe occupancy of the geometry decoder's kernels from the committed counter passes
+    (profiles/r0N_rocprofv3_counters_geo_decode.csv, scripts/profile_r04.sh): SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the
+    SIMDs) and 4 x SQ_ACTIVE_INST_VALU (quad-cycles) over 1024 SIMDs x the launch's cycles (GRBM_GUI_ACTIVE is summed over the 8
+    XCDs), LDS_IDX_ACTIVE over 256 CUs x the same."""
+    import csv
+    for rel in _prof("rocprofv3_counters_geo_decode.csv"):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        tab = {}
+        for r in csv.DictReader(open(path)):
+            tab.setdefault(r["kernel"], {})[r["counter"]] = float(r["mean_per_launch"])
+        out = {}
+        for k, c in tab.items():
+            if "GRBM_GUI_ACTIVE" not in c or not c.get("SQ_INSTS_MFMA"):
+                continue
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            # _ZN3geo13k_geo_gemm256ILi9EEEvPK... -> k_geo_gemm256<9>
+            name = "k_geo" + k.split("k_geo", 1)[1].split("EPK")[0].split("ILi")[0] + (("<" + k.split("ILi")[1].split("E")[0] + ">") if "ILi" in k else "")
+            out[name] = {"mfma_busy_frac": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc), 3),
+                         "valu_busy_frac": round(4 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024 * cyc), 3),
+                         "lds_busy_frac": round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256 * cyc), 3),
+                         "wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") else None}
+        return out, rel
+    return {}, None
+
+
 def valu_roofline(sq, kernel_ms, images):
     """The vector-ALU side of the roofline, per kernel: busy SIMD cycles of one launch (SQ_ACTIVE_INST_VALU counts quad-cycles
     in which a VALU instruction issues, x 4) over the SIMD cycles the chip offers during the launch's LIVE duration (1024
@@ -647,7 +675,8 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     # activations are kept: nothing else is recomputed)
     flops_bwd = n * (4 * W * F + 2 * W * W + 8 * NL * W)
     gerr = (fb["hip"][1] - fb["torch"][1]).abs().max().item() / fb["torch"][1].abs().max().item()
-    return {"fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
+    pipes, pipes_src = geo_pipe_busy()
+    return {"pipe_busy_by_kernel": pipes, "pipe_busy_source": pipes_src, "fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
             "fwd_bwd_tflops": (flops + flops_bwd) / fb["hip"][0] / 1e12, "grad_rel_diff_vs_torch_fp16": gerr,
             "queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
             "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops / 1e12,

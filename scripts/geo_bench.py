@@ -24,6 +24,13 @@ if "--fb" in sys.argv:
         (hip(q, l).float() * go).sum().backward()
         torch.cuda.synchronize()
         print(f"forward + backward: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
+    for _ in range(3):                       # ... and the no-gradient forward (K / V projection of the tokens included)
+        hip._prepared = None
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            hip(q, lat)
+        torch.cuda.synchronize()
+        print(f"forward: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
     sys.exit(0)
 if "--parts" in sys.argv:
     lib = L.lib()
