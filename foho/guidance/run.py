@@ -446,7 +446,7 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                     aligned_mano_dir=aligned_mano_dir, guidance_out_dir=guidance_out_dir)
         if _mesh_level_batched():
             _run_batched(assigned_imgs, dirs, config, device)
-        elif _pipeline_batch_size() > 1 and len(assigned_imgs) > 1 and _build_pipeline(device) is not None:
+        elif _pipeline_batch_size() > 1 and len(assigned_imgs) > 1 and _networks_available() and _build_pipeline(device) is not None:
             _run_pipeline_batched(assigned_imgs, dirs, config, device, _pipeline_batch_size())
         else:
             _run_one_by_one(assigned_imgs, dirs, config)
@@ -461,6 +461,18 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
         if error is not None:
             raise error
     return out
+
+
+def _networks_available() -> bool:
+    """Can _build_pipeline succeed?  (Stand-ins requested, or hy3dgen importable.)  Without networks the one-by-one path keeps
+    its behaviour: the per-image call raises the explanatory error, which the per-image handler reports (RUN:257-259)."""
+    if os.environ.get("FOHO_STANDIN_NETWORKS") == "1":
+        return True
+    import importlib.util
+    try:
+        return importlib.util.find_spec("hy3dgen.shapegen") is not None
+    except (ImportError, ValueError):
+        return False
 
 
 def _pipeline_batch_size() -> int:
