@@ -215,3 +215,76 @@ def test_latent2sdf_uses_the_hip_decoder_with_and_without_gradients():
     (sdf * wgt).sum().backward()
     err = (lat_h.grad - lat_r.grad).abs().max().item()
     assert err <= 2e-2 * lat_r.grad.abs().max().item(), (err, lat_r.grad.abs().max().item())
+
+
+class _Hy3dLikeDecoder(torch.nn.Module):
+    """A module laid out like hy3dgen's CrossAttentionDecoder (hy3dgen/shapegen/models/autoencoders/attention_blocks.py, not in
+    the reference tree; restated from its published structure): FourierEmbedder.frequencies, query_proj,
+    cross_attn_decoder = ResidualCrossAttentionBlock{ln_1 (queries), ln_2 (latents), ln_3, attn{c_q, c_kv, c_proj,
+    attention{heads, q_norm, k_norm}}, mlp{c_fc, c_proj}}, ln_post, output_proj -- c_kv's output is viewed as (tokens, heads, 2 d)
+    and split into K and V per head, i.e. K and V rows INTERLEAVE head by head."""
+
+    def __init__(self, width, heads, num_freqs=8):
+        super().__init__()
+        nn = torch.nn
+        self.fourier_embedder = nn.Module()
+        self.fourier_embedder.register_buffer("frequencies", 2.0 ** torch.arange(num_freqs, dtype=torch.float32))      # include_pi=False
+        self.query_proj = nn.Linear(3 * (2 * num_freqs + 1), width)
+        blk = nn.Module()
+        blk.ln_1, blk.ln_2, blk.ln_3 = nn.LayerNorm(width), nn.LayerNorm(width), nn.LayerNorm(width)
+        blk.attn = nn.Module()
+        blk.attn.c_q, blk.attn.c_kv, blk.attn.c_proj = nn.Linear(width, width, bias=False), nn.Linear(width, 2 * width, bias=False), nn.Linear(width, width)
+        blk.attn.attention = nn.Module()
+        blk.attn.attention.heads = heads
+        blk.attn.attention.q_norm, blk.attn.attention.k_norm = nn.Identity(), nn.Identity()
+        blk.mlp = nn.Module()
+        blk.mlp.c_fc, blk.mlp.c_proj = nn.Linear(width, 4 * width), nn.Linear(4 * width, width)
+        self.cross_attn_decoder = blk
+        self.ln_post, self.output_proj = nn.LayerNorm(width), nn.Linear(width, 1)
+        self.heads = heads
+
+    def forward(self, queries, latents):
+        q32 = queries.float()
+        emb = (q32[..., None] * self.fourier_embedder.frequencies).flatten(-2)
+        x = self.query_proj(torch.cat([q32, emb.sin(), emb.cos()], -1).to(latents.dtype))
+        b = self.cross_attn_decoder
+        B, N, C = x.shape
+        q = b.attn.c_q(b.ln_1(x)).view(B, N, self.heads, -1)
+        kv = b.attn.c_kv(b.ln_2(latents)).view(B, latents.shape[1], self.heads, -1)
+        k, v = torch.split(kv, C // self.heads, dim=-1)
+        a = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(B, N, C)
+        x = x + b.attn.c_proj(a)
+        x = x + b.mlp.c_proj(torch.nn.functional.gelu(b.mlp.c_fc(b.ln_3(x))))
+        return self.output_proj(self.ln_post(x))
+
+
+@gpu
+def test_decoder_adopts_a_module_laid_out_like_hy3dgen():
+    """geo_decode._parts on the hy3dgen layout: bias-free c_q / c_kv, K and V interleaved per head in c_kv's rows, frequencies
+    without pi, no analytic prior -- forward and latent gradient against the module itself."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    from followmyhold_amd import _lib as L
+    torch.manual_seed(4)
+    dec = _Hy3dLikeDecoder(256, 4).cuda().eval()
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.copy_(p.half().float())
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 384, 256, generator=g).half().cuda()
+    q = (torch.rand(1, 3000, 3, generator=g) * 2.0 - 1.0).half().cuda()
+    go = torch.randn(1, 3000, 1, generator=g).cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)
+    lat_h = lat.clone().requires_grad_(True)
+    out = hip(q.float(), lat_h)
+    (out.float() * go).sum().backward()
+    lat_r = lat.float().requires_grad_(True)
+    ref = dec(q, lat_r)
+    (ref * go).sum().backward()
+    scale = ref.abs().max().item()
+    assert scale > 0.1 and (out.float() - ref).abs().max().item() <= 3e-3 * max(scale, 1.0), ((out.float() - ref).abs().max().item(), scale)
+    gh, gr = lat_h.grad.float(), lat_r.grad
+    cos = torch.nn.functional.cosine_similarity(gh.flatten(), gr.flatten(), dim=0).item()
+    assert (gh - gr).abs().max().item() <= 1e-2 * gr.abs().max().item() and cos >= 1 - 1e-4, ((gh - gr).abs().max().item(), gr.abs().max().item(), cos)
+    dec.cross_attn_decoder.attn.attention.q_norm = torch.nn.LayerNorm(64).cuda()                # qk_norm decoders: refused, not mis-decoded
+    with pytest.raises(L.FohoError):
+        HipGeoDecoder.from_module(dec)
