@@ -27,6 +27,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   driver_on_files     foho.guidance.run.run() on scene folders in the reference's file formats, wall time per image
   topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
   geo_decode          the ShapeVAE geometry decoder of latent2sdf (65^3 queries x 3072 tokens) on the matrix cores vs torch
+  pipeline_iteration  one inner iteration of the real pipeline (VAE transformer -> geometry decoder -> FlexiCubes -> step -> backward)
+                      with Hunyuan-shaped stand-in networks: torch decoder vs the HIP decoder
 """
 import argparse
 import json
@@ -477,6 +479,7 @@ def main():
                             ("closeup", lambda: closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("geo_decode", lambda: geo_decode_record(torch, dev)),
+                            ("pipeline_iteration", lambda: pipeline_iteration_record(E, torch, scenes[0], dev)),
                             ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
                             ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
                 try:
@@ -735,6 +738,62 @@ def job_record(E, torch, synthetic, render_fn, args, dev):
                                          "graph_captures": runner.stats["captures"], "slots_built": runner.stats["slots_built"]}
         rec[f"in_flight_{in_flight}"].update({k: v for k, v in valu_record(args, n_img * n_iter / dt).items() if k == "valu_issue_frac"})
     return rec
+
+
+def pipeline_iteration_record(E, torch, scene, dev, iters=5):
+    """One inner iteration of phases B / C as the real pipeline runs it (PL:1478-1601): clean latent -> ShapeVAE transformer ->
+    geometry decoder on the 65^3 grid (`latent2sdf`) -> FlexiCubes -> new object installed -> fused guidance step -> backward
+    through all of it to the noise prediction.  Stand-in networks of the Hunyuan3D-2 shape (3072 x 64 latents, width 1024, 16
+    heads, 16 transformer layers, fp16; random weights -- no checkpoint on this box); the geometry decoder once as the torch
+    module in the reference's 35 chunks of 8000 queries, once through `geo_decode.install` (foho_geo_decode_fwd_keep / _bwd)."""
+    import numpy as np
+    from followmyhold_amd import geo_decode, pipeline as PLN, standins
+    res = 64
+    g = np.linspace(-1.1, 1.1, res + 1, dtype=np.float32)
+    xyz = torch.from_numpy(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)).to(dev)
+    scene = dict(scene)
+    T = np.array(scene["T_h2m"], np.float32)
+    T[:3, :3] *= 0.9 * 0.06
+    scene["T_h2m"] = T
+    gb = E.GuidanceBatch([scene], device=dev, obj_capacity=(32768, 65536))
+    obj = E.SdfObjective(gb, xyz, res)
+    cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=16, num_freqs=8).to(dev).half().eval()
+    lat = torch.randn(1, 3072, 64, device=dev, dtype=torch.float16)
+    gsz = (res + 1, res + 1, res + 1)
+    out, sdfs = {}, {}
+    for name in ("torch_decoder", "hip_decoder"):
+        if name == "hip_decoder":
+            geo_decode.install(vae, device=dev)
+        noise = torch.zeros_like(lat).requires_grad_(True)
+        def one():
+            if noise.grad is not None:
+                noise.grad = None
+            t = {}
+            torch.cuda.synchronize(dev); a = time.perf_counter()
+            sdf = PLN.latent2sdf(lat + 0.1 * noise, xyz, gsz, vae, dev)
+            torch.cuda.synchronize(dev); t["latent2sdf_fwd_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
+            sdfs[name] = sdf.detach()
+            loss = obj(sdf.reshape(1, -1), cfg)
+            torch.cuda.synchronize(dev); t["flexicubes_step_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
+            loss.sum().backward()
+            torch.cuda.synchronize(dev); t["backward_ms"] = (time.perf_counter() - a) * 1e3
+            return t
+        one(); one()
+        ts = [one() for _ in range(iters)]
+        rec = {k: float(np.median([x[k] for x in ts])) for k in ts[0]}
+        rec["iteration_ms"] = sum(rec.values())
+        rec["grad_abs_max"] = float(noise.grad.abs().max())
+        out[name] = rec
+    nv, nf, flags = obj.status()[0]
+    out["faces"] = nf
+    out["sdf_max_abs_diff_between_decoders"] = float((sdfs["torch_decoder"] - sdfs["hip_decoder"]).abs().max())
+    out["sdf_abs_max"] = float(sdfs["torch_decoder"].abs().max())
+    out["speedup"] = out["torch_decoder"]["iteration_ms"] / out["hip_decoder"]["iteration_ms"]
+    out["what"] = ("latent -> 16-layer VAE transformer (torch) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
+                   "step -> backward to the noise prediction; stand-in networks of the Hunyuan3D-2 shape, fp16")
+    return out
 
 
 def topology_record(E, torch, scene, dev, steps=200):
