@@ -784,7 +784,7 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         ts = [one() for _ in range(iters)]
         rec = {k: float(np.median([x[k] for x in ts])) for k in ts[0]}
         rec["iteration_ms"] = sum(rec.values())
-        rec["grad_abs_max"] = float(noise.grad.abs().max())
+        rec["grad_finite"] = bool(torch.isfinite(noise.grad).all())     # (fp16 leaf, random networks: its magnitude means nothing)
         out[name] = rec
     nv, nf, flags = obj.status()[0]
     out["faces"] = nf

@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
+timeout 900 python scripts/gpu_tmp.py 2>&1 | tail -6
