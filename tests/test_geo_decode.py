@@ -42,6 +42,27 @@ def test_geo_workspace_query_and_argument_checks_run_without_a_gpu():
     assert lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384) == 0 and b"n_latents" in lib.foho_geo_last_error()
     lib.foho_geo_decode_fwd.restype = ctypes.c_int
     assert lib.foho_geo_decode_fwd(None, None, ctypes.c_int64(0), None, 0, None, ctypes.c_size_t(0), None) == -1
+    # the backward's sizes: 18.1 KB of kept activations per query row (rounded up to whole row blocks), a workspace that holds one
+    # row block's scratch + the partial sums of the K / V gradient; argument errors come back as codes, not as faults
+    w.n_latents = 3072
+    for fn in (lib.foho_geo_bwd_workspace_bytes, lib.foho_geo_saved_bytes):
+        fn.restype = ctypes.c_size_t
+    lib.foho_geo_bwd_workspace_bytes.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
+    lib.foho_geo_saved_bytes.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32, ctypes.c_int64]
+    per_row_saved = 2 * (5 * 1024 + 4096) + 16 * 4
+    n = lib.foho_geo_saved_bytes(ctypes.byref(w), 16384, 65 ** 3)
+    assert 17 * 16384 * per_row_saved <= n <= 17 * 16384 * (per_row_saved + 64) + 17 * 8192
+    nb = lib.foho_geo_bwd_workspace_bytes(ctypes.byref(w), 16384)
+    part = 3072 * 2048 * 4
+    assert nb >= 16384 * 2 * (64 + 7 * 1024 + 2 * 4096) + part and (nb - 16384 * 2 * (64 + 9 * 1024 + 2 * 4096)) % part < part
+    lib.foho_geo_decode_bwd.restype = ctypes.c_int
+    assert lib.foho_geo_decode_bwd(None, None, ctypes.c_int64(0), None, None, 0, None, ctypes.c_size_t(0), None, ctypes.c_size_t(0), None,
+                                   ctypes.c_size_t(0), None) == -1
+    w.n_latents = 3072 + 64              # fine for the forward, not for the backward's 128-key blocks
+    assert lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384) > 0
+    one = ctypes.c_void_p(1)
+    assert lib.foho_geo_decode_bwd(ctypes.byref(w), one, ctypes.c_int64(8), one, one, 16384, one, ctypes.c_size_t(1 << 40), one, ctypes.c_size_t(1 << 40), None,
+                                   ctypes.c_size_t(0), None) != 0 and b"multiple of 128" in lib.foho_geo_last_error()
 
 
 @gpu
