@@ -57,7 +57,10 @@ def _parts(m):
 
 
 class HipGeoDecoder:
-    CHUNK = 16384        # rows per block of the chain: its activations (14.5 KB per row at width 1024) stay in the Infinity Cache
+    CHUNK = 49152        # rows per block of the chain (14.5 KB of activations per row at width 1024: 0.7 GB of workspace, 1.7 GB for
+                         # the backward's).  Measured per 65^3 decode, forward / forward + backward, ms: 16384 rows (the block that
+                         # stays in the 256 MB Infinity Cache) 11.3 / 26.8, 24576 11.9 / 27.8, 32768 11.0 / 26.1, 49152 10.9 / 25.7,
+                         # 65536 10.8 / 25.8 -- fewer, fuller launches beat cache residency
 
     def __init__(self, parts, device="cuda", chunk_rows=None):
         self.lib = L.lib()
