@@ -165,7 +165,8 @@ def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk)
 
 
 @gpu
-@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384), (1024, 16, 3072, 3000, 16384)])
+@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384), (1024, 16, 3072, 3000, 16384),
+                                                         (256, 4, 128, 70, 2048), (256, 4, 256, 4097, 4096)])
 def test_decoder_backward_against_torch_autograd(width, heads, n_lat, n_q, chunk):
     """foho_geo_decode_bwd: d sum(g . logits) / d latents through the HIP chain (forward recomputed per row block, K / V gradients
     accumulated over the blocks, LayerNorm + K/V projection of the tokens by torch autograd) against float32 autograd through the
