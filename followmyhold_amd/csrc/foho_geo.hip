@@ -92,6 +92,10 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // which an MFMA operand built from a C-layout accumulator holds its k index (see the attention kernels): the backward
 // attention kernel reads Q^T and dO^T from such copies.  m0 / n0: first row / column of the 64 x 64 part.
 constexpr int EP_GELUBWD = 4, EP_SAVEZ = 8, EP_TRANS = 16;
+// EP_QNORM (hy3dgen's qk_norm on the query side): the 64 columns of an epilogue part are exactly one head; every row of the
+// part is LayerNorm-ed over them (gain / bias / eps: 129 floats passed in the R slot) BEFORE the scale, from the fp16-rounded
+// projection, the way the module normalises c_q's output per head.
+constexpr int EP_QNORM = 32;
 
 __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
     const float x = v * 0.70710678118654752f, ax = fabsf(x);
@@ -127,11 +131,11 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                     for (int q = 0; q < 4; q++) {
                         float v = t[4 * g + q] + b4[q];
                         if ((EP & EP_GELU) && pass == 1) v = gelu_erf(v);
-                        v *= scale;
+                        if (!(EP & EP_QNORM)) v *= scale;
                         o[q] = (h16)v;
                     }
                     *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
-                    if ((EP & EP_TRANS) && pass == 1) {
+                    if ((EP & EP_TRANS) && !(EP & EP_QNORM) && pass == 1) {
                         const int gm = m0 + i * 32 + l31;
                         if (gm < M) {
                             const int pm = (gm & ~15) | (gm & 3) | ((gm & 4) << 1) | ((gm & 8) >> 1);
@@ -150,8 +154,38 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
             const int ml = q * 8 + (lane >> 3), ch = lane & 7;
             const int gm = m0 + ml, gn = n0 + ch * 8;
             half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
+            if ((EP & EP_QNORM) && pass == 1) {   // the row's 64 columns sit in 8 consecutive lanes
+                const float* qn = reinterpret_cast<const float*>(R);
+                float x[8], sm = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    x[e] = (float)v[e];
+                    sm += x[e];
+                }
+                sm += __shfl_xor(sm, 1);
+                sm += __shfl_xor(sm, 2);
+                sm += __shfl_xor(sm, 4);
+                const float mean = sm * (1.0f / 64.0f);
+                float sq = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    x[e] -= mean;
+                    sq += x[e] * x[e];
+                }
+                sq += __shfl_xor(sq, 1);
+                sq += __shfl_xor(sq, 2);
+                sq += __shfl_xor(sq, 4);
+                const float rstd = rsqrtf(sq * (1.0f / 64.0f) + qn[128]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (h16)((x[e] * rstd * qn[ch * 8 + e] + qn[64 + ch * 8 + e]) * scale);
+                if ((EP & EP_TRANS) && gm < M) {
+                    const int pm = (gm & ~15) | (gm & 3) | ((gm & 4) << 1) | ((gm & 8) >> 1);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) C2[(size_t)(gn + e) * ldc2 + pm] = v[e];
+                }
+            }
             if (gm < M) {
-                if ((EP & (EP_RESID | EP_GELUBWD)) && pass == 1) {
+                if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM) && pass == 1) {
                     const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
@@ -590,6 +624,39 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
                     *reinterpret_cast<half4*>(O + (size_t)row * ldo + head * 64 + dt * 32 + 8 * g + 4 * hi) = v;
                 }
         }
+    }
+}
+
+// hy3dgen's qk_norm on the key side: LayerNorm over the 64 dimensions of every head of K, in place (one thread per token
+// and head; 3072 x 16 of them, once per set of latent tokens).  kn: gain (64), bias (64), eps.
+__global__ void k_geo_knorm(h16* __restrict__ KV, int ldkv, int L, int heads, const float* __restrict__ kn) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L * heads) return;
+    h16* k = KV + (size_t)(i / heads) * ldkv + (i % heads) * 64;
+    float x[64], sm = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const half8 v = *reinterpret_cast<const half8*>(k + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            x[8 * c + e] = (float)v[e];
+            sm += x[8 * c + e];
+        }
+    }
+    const float mean = sm * (1.0f / 64.0f);
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 64; c++) {
+        x[c] -= mean;
+        sq += x[c] * x[c];
+    }
+    const float rstd = rsqrtf(sq * (1.0f / 64.0f) + kn[128]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (h16)(x[8 * c + e] * rstd * kn[8 * c + e] + kn[64 + 8 * c + e]);
+        *reinterpret_cast<half8*>(k + 8 * c) = v;
     }
 }
 
@@ -1092,8 +1159,8 @@ static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int ld
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
                 int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0) {
     if (M <= 0) return FOHO_OK;
-    if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
-    if ((ep & (EP_RESID | EP_GELUBWD)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
+    if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & EP_QNORM) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
+    if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
     if ((ep & (EP_SAVEZ | EP_TRANS)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
     const bool big = N % HN == 0 && K >= 256 && M >= 2048 && !g_force128;  // the big GEMMs of the chain: 256 x 256 tiles
     const int tn = big ? HN : GN, tm = big ? HM : GM;
@@ -1107,6 +1174,8 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
         GEO_GEMM_CASE(EP_GELU | EP_SAVEZ);
         GEO_GEMM_CASE(EP_GELUBWD);
         GEO_GEMM_CASE(EP_TRANS);
+        GEO_GEMM_CASE(EP_QNORM);
+        GEO_GEMM_CASE(EP_TRANS | EP_QNORM);
         default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
     }
 #undef GEO_GEMM_CASE
@@ -1156,6 +1225,8 @@ using namespace geo;
 
 extern "C" const char* foho_geo_last_error(void) { return g_err; }
 
+extern "C" int64_t foho_geo_abi_size(void) { return (int64_t)sizeof(foho_geo_weights); }
+
 extern "C" size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows) {
     if (check_weights(w) != FOHO_OK || chunk_rows <= 0) return 0;
     return layout(w, chunk_rows).total;
@@ -1174,6 +1245,7 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
                        (const float*)nullptr, 0.0f, (const float*)nullptr, 0.0f, 0.0f, 0.0f, (float*)nullptr);
     if (!launch_ok("k_geo_ln(kv)")) return FOHO_ERR_LAUNCH;
     if (int rc = gemm(0, ln, W, (const h16*)w->w_kv, W, w->b_kv, nullptr, 0, kv, 2 * W, Lr, 2 * W, W, 1.0f, s)) return rc;
+    if (w->k_norm) hipLaunchKernelGGL(k_geo_knorm, dim3((Lr * w->heads + 255) / 256), dim3(256), 0, s, kv, 2 * W, Lr, w->heads, w->k_norm);
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
     return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
@@ -1202,7 +1274,7 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
         hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_q_g, w->ln_q_b, bB, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f,
                            0.0f, (float*)nullptr);
         if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
-        if (int rc = gemm(0, bB, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, bC, W, M, W, W, qscale, s)) return rc;
+        if (int rc = gemm(w->q_norm ? EP_QNORM : 0, bB, W, (const h16*)w->w_q, W, w->b_q, (const h16*)w->q_norm, 0, bC, W, M, W, W, qscale, s)) return rc;
         // attention over the latent tokens                                           C -> B
         hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads, (float*)nullptr);
         if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
@@ -1327,7 +1399,9 @@ static int chain_fwd_keep(const foho_geo_weights* w, const float* q, int M, cons
     hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), blk, 0, s, q, M, w->n_freqs, w->freqs, P.E);
     if (int rc = gemm(0, P.E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, P.X0, W, M, W, 64, 1.0f, s)) return rc;
     hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X0, W, w->ln_q_g, w->ln_q_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
-    if (int rc = gemm(EP_TRANS, P.Xn, W, (const h16*)w->w_q, W, w->b_q, nullptr, 0, P.Qs, W, M, W, W, qscale, s, P.QsT, P.ldt)) return rc;
+    if (int rc = gemm(EP_TRANS | (w->q_norm ? EP_QNORM : 0), P.Xn, W, (const h16*)w->w_q, W, w->b_q, (const h16*)w->q_norm, 0, P.Qs, W, M, W, W, qscale, s,
+                      P.QsT, P.ldt))
+        return rc;
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), blk, 0, s, P.Qs, W, kv, 2 * W, vt, Lr, P.At, W, M, NH, P.lse);
     if (int rc = gemm(EP_RESID, P.At, W, (const h16*)w->w_proj, W, w->b_proj, P.X0, W, P.X1, W, M, W, W, 1.0f, s)) return rc;
     hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X1, W, w->ln_2_g, w->ln_2_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);

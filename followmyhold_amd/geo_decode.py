@@ -29,7 +29,7 @@ class FohoGeoWeights(ctypes.Structure):
                 ("ln_2_g", L.vp), ("ln_2_b", L.vp), ("w_fc1", L.vp), ("b_fc1", L.vp), ("w_fc2", L.vp), ("b_fc2", L.vp),
                 ("ln_post_g", L.vp), ("ln_post_b", L.vp), ("w_out", L.vp), ("b_out", L.c_f), ("ln_eps", L.c_f),
                 ("prior_radius", L.c_f), ("prior_sharpness", L.c_f), ("out_gain", L.c_f),
-                ("w_fc2_t", L.vp), ("w_fc1_t", L.vp), ("w_proj_t", L.vp), ("zeros", L.vp)]
+                ("w_fc2_t", L.vp), ("w_fc1_t", L.vp), ("w_proj_t", L.vp), ("zeros", L.vp), ("q_norm", L.vp), ("k_norm", L.vp)]
 
 
 def _bias(lin, n, device):
@@ -47,11 +47,16 @@ def _parts(m):
                     prior=(float(m.radius), float(m.sharpness), float(m.gain)))
     blk = m.cross_attn_decoder
     att = blk.attn
-    for name in ("q_norm", "k_norm"):
+    qk = {}
+    for name in ("q_norm", "k_norm"):      # qk_norm: LayerNorm over the head dimension (attention_blocks.py); anything else is refused
         nrm = getattr(att.attention, name, None)
-        if nrm is not None and not isinstance(nrm, torch.nn.Identity):
-            raise L.FohoError("HipGeoDecoder: qk_norm decoders are not supported by this version of foho_geo_decode_fwd")
-    return dict(freqs=m.fourier_embedder.frequencies, query_proj=m.query_proj, ln_q=blk.ln_1, ln_kv=blk.ln_2, ln_2=blk.ln_3, q=att.c_q,
+        if nrm is None or isinstance(nrm, torch.nn.Identity):
+            qk[name] = None
+        elif isinstance(nrm, torch.nn.LayerNorm) and tuple(nrm.normalized_shape) == (64,):
+            qk[name] = nrm
+        else:
+            raise L.FohoError(f"HipGeoDecoder: {name} of type {type(nrm).__name__} is not supported (LayerNorm over the 64 head dimensions is)")
+    return dict(q_norm=qk["q_norm"], k_norm=qk["k_norm"], freqs=m.fourier_embedder.frequencies, query_proj=m.query_proj, ln_q=blk.ln_1, ln_kv=blk.ln_2, ln_2=blk.ln_3, q=att.c_q,
                 kv=att.c_kv, proj=att.c_proj, fc1=blk.mlp.c_fc, fc2=blk.mlp.c_proj, ln_post=m.ln_post, out=m.output_proj,
                 heads=att.attention.heads, kv_interleaved=True, prior=(0.0, 0.0, 1.0))
 
@@ -64,6 +69,10 @@ class HipGeoDecoder:
 
     def __init__(self, parts, device="cuda", chunk_rows=None):
         self.lib = L.lib()
+        self.lib.foho_geo_abi_size.restype = ctypes.c_int64
+        if int(self.lib.foho_geo_abi_size()) != ctypes.sizeof(FohoGeoWeights):
+            raise L.FohoError(f"HipGeoDecoder: libfoho_hip.so was built with a foho_geo_weights of {int(self.lib.foho_geo_abi_size())} bytes, "
+                              f"this binding's is {ctypes.sizeof(FohoGeoWeights)}: rebuild (make -C followmyhold_amd/csrc)")
         self.device = torch.device(device)
         dev, h = self.device, torch.float16
         p = parts
@@ -92,6 +101,13 @@ class HipGeoDecoder:
         for name in ("fc2", "fc1", "proj"):              # the backward's GEMMs multiply by the transposes
             t[f"w_{name}_t"] = t["w_" + name].t().contiguous()
         t["zeros"] = torch.zeros(max(hidden, 2 * width), dtype=torch.float32, device=dev)
+        for name in ("q_norm", "k_norm"):                 # 129 floats: gain, bias, eps
+            nrm = p.get(name)
+            if nrm is not None:
+                g = nrm.weight.detach().float() if nrm.weight is not None else torch.ones(64)
+                b = nrm.bias.detach().float() if nrm.bias is not None else torch.zeros(64)
+                t[name] = torch.cat([g.reshape(-1).cpu(), b.reshape(-1).cpu(), torch.tensor([float(nrm.eps)])]).to(dev).contiguous()
+                t[name + "_eps"] = float(nrm.eps)
         t["w_out"] = p["out"].weight.detach().reshape(-1).to(dev, torch.float32).contiguous()
         t["freqs"] = p["freqs"].detach().to(dev, torch.float32).contiguous()
         self.t = t
@@ -150,7 +166,12 @@ class HipGeoDecoder:
         t = self.t
         lat = latents.reshape(-1, latents.shape[-1]).to(self.device)
         x = torch.nn.functional.layer_norm(lat.float(), (self.w.width,), t["ln_kv_g"], t["ln_kv_b"], self.w.ln_eps)
-        return (x.half() @ t["w_kv"].t() + t["b_kv"].half()).contiguous()
+        kv = x.half() @ t["w_kv"].t() + t["b_kv"].half()
+        if "k_norm" in t:                                 # qk_norm on the key side, differentiable like the rest of this function
+            W, kn = self.w.width, t["k_norm"]
+            k = torch.nn.functional.layer_norm(kv[:, :W].float().reshape(-1, self.w.heads, 64), (64,), kn[:64], kn[64:128], t["k_norm_eps"])
+            kv = torch.cat([k.reshape(-1, W).half(), kv[:, W:]], dim=1)
+        return kv.contiguous()
 
     def set_kv(self, kv):
         """Install K / V (L, 2 width) fp16 computed by the caller in place of prepare()."""

@@ -415,8 +415,16 @@ typedef struct {
     const void* w_fc1_t;             /* (width, hidden) fp16 = w_fc1^T                                          */
     const void* w_proj_t;            /* (width, width) fp16 = w_proj^T                                          */
     const float* zeros;              /* (max(hidden, width)) fp32 zeros                                         */
+    /* hy3dgen's qk_norm (attention_blocks.py: LayerNorm over the head dimension on q and on k, before the scaled dot
+     * product): 129 floats each -- gain (64), bias (64), eps -- or NULL for a decoder without it.  foho_geo_prepare
+     * normalises K; K / V handed to foho_geo_set_kv are expected normalised already (the caller's autograd owns that).     */
+    const float* q_norm;
+    const float* k_norm;
 } foho_geo_weights;
 
+/* sizeof(foho_geo_weights) of the loaded build (version 103): the Python side compares it with its ctypes mirror before the
+ * first call, like foho_abi_sizes does for the step's structs */
+int64_t foho_geo_abi_size(void);
 /* workspace for row blocks of `chunk_rows` queries: K / V of the latent tokens + the block's activations (14.5 KB per
  * query at width 1024 / hidden 4096; 16384 rows keep a block inside the 256 MB Infinity Cache).  0 on bad arguments. */
 size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);

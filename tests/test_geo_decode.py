@@ -246,7 +246,7 @@ class _Hy3dLikeDecoder(torch.nn.Module):
     attention{heads, q_norm, k_norm}}, mlp{c_fc, c_proj}}, ln_post, output_proj -- c_kv's output is viewed as (tokens, heads, 2 d)
     and split into K and V per head, i.e. K and V rows INTERLEAVE head by head."""
 
-    def __init__(self, width, heads, num_freqs=8):
+    def __init__(self, width, heads, num_freqs=8, qk_norm=False):
         super().__init__()
         nn = torch.nn
         self.fourier_embedder = nn.Module()
@@ -258,7 +258,9 @@ class _Hy3dLikeDecoder(torch.nn.Module):
         blk.attn.c_q, blk.attn.c_kv, blk.attn.c_proj = nn.Linear(width, width, bias=False), nn.Linear(width, 2 * width, bias=False), nn.Linear(width, width)
         blk.attn.attention = nn.Module()
         blk.attn.attention.heads = heads
-        blk.attn.attention.q_norm, blk.attn.attention.k_norm = nn.Identity(), nn.Identity()
+        d = width // heads     # qk_norm: LayerNorm over the head dimension on q and k (the released ShapeVAE config switches it on)
+        blk.attn.attention.q_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
+        blk.attn.attention.k_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
         blk.mlp = nn.Module()
         blk.mlp.c_fc, blk.mlp.c_proj = nn.Linear(width, 4 * width), nn.Linear(4 * width, width)
         self.cross_attn_decoder = blk
@@ -274,6 +276,7 @@ class _Hy3dLikeDecoder(torch.nn.Module):
         q = b.attn.c_q(b.ln_1(x)).view(B, N, self.heads, -1)
         kv = b.attn.c_kv(b.ln_2(latents)).view(B, latents.shape[1], self.heads, -1)
         k, v = torch.split(kv, C // self.heads, dim=-1)
+        q, k = b.attn.attention.q_norm(q), b.attn.attention.k_norm(k)
         a = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(B, N, C)
         x = x + b.attn.c_proj(a)
         x = x + b.mlp.c_proj(torch.nn.functional.gelu(b.mlp.c_fc(b.ln_3(x))))
@@ -281,16 +284,22 @@ class _Hy3dLikeDecoder(torch.nn.Module):
 
 
 @gpu
-def test_decoder_adopts_a_module_laid_out_like_hy3dgen():
+@pytest.mark.parametrize("qk_norm", [False, True])
+def test_decoder_adopts_a_module_laid_out_like_hy3dgen(qk_norm):
     """geo_decode._parts on the hy3dgen layout: bias-free c_q / c_kv, K and V interleaved per head in c_kv's rows, frequencies
-    without pi, no analytic prior -- forward and latent gradient against the module itself."""
+    without pi, no analytic prior, with and without qk_norm (LayerNorm over the head dimension of q -- in the q GEMM's epilogue --
+    and of k) -- forward and latent gradient against the module itself."""
     from followmyhold_amd.geo_decode import HipGeoDecoder
     from followmyhold_amd import _lib as L
     torch.manual_seed(4)
-    dec = _Hy3dLikeDecoder(256, 4).cuda().eval()
+    dec = _Hy3dLikeDecoder(256, 4, qk_norm=qk_norm).cuda().eval()
     with torch.no_grad():
         for p in dec.parameters():
             p.copy_(p.half().float())
+        if qk_norm:
+            for nrm in (dec.cross_attn_decoder.attn.attention.q_norm, dec.cross_attn_decoder.attn.attention.k_norm):
+                nrm.weight.add_(0.2 * torch.randn_like(nrm.weight))
+                nrm.bias.add_(0.2 * torch.randn_like(nrm.bias))
     g = torch.Generator().manual_seed(9)
     lat = torch.randn(1, 384, 256, generator=g).half().cuda()
     q = (torch.rand(1, 3000, 3, generator=g) * 2.0 - 1.0).half().cuda()
@@ -307,6 +316,10 @@ def test_decoder_adopts_a_module_laid_out_like_hy3dgen():
     gh, gr = lat_h.grad.float(), lat_r.grad
     cos = torch.nn.functional.cosine_similarity(gh.flatten(), gr.flatten(), dim=0).item()
     assert (gh - gr).abs().max().item() <= 1e-2 * gr.abs().max().item() and cos >= 1 - 1e-4, ((gh - gr).abs().max().item(), gr.abs().max().item(), cos)
-    dec.cross_attn_decoder.attn.attention.q_norm = torch.nn.LayerNorm(64).cuda()                # qk_norm decoders: refused, not mis-decoded
+    # the no-gradient route (foho_geo_prepare normalises K itself) gives the same logits as the autograd route
+    with torch.no_grad():
+        out_ng = hip(q.float(), lat)
+    assert (out_ng.float() - out.detach().float()).abs().max().item() <= 2e-3 * max(scale, 1.0)
+    dec.cross_attn_decoder.attn.attention.q_norm = torch.nn.GroupNorm(4, 64).cuda()             # another kind of norm: refused, not mis-decoded
     with pytest.raises(L.FohoError):
         HipGeoDecoder.from_module(dec)
