@@ -229,7 +229,7 @@ def _build_pipeline(device):
         import torch
         from followmyhold_amd import standins
         _PIPELINE = standins.make_standin_pipeline(device=device, dtype=torch.float32)
-        return _PIPELINE
+        return _PIPELINE        # (the tiny stand-in decoder -- width 32 -- is outside the shapes of the HIP geometry decoder)
     try:
         from hy3dgen.shapegen import Hunyuan3DDiTFlowMatchingPipeline
     except ImportError as e:
@@ -240,7 +240,9 @@ def _build_pipeline(device):
                            "to run the full guided pipeline on random-initialised stand-ins, FOHO_MESH_LEVEL_GUIDANCE=1 "
                            "to run phases A/B/C on the fixed Hunyuan mesh, or use followmyhold_amd.pipeline / "
                            "followmyhold_amd.engine directly.") from e
-    _PIPELINE = GuidedShapePipeline.from_hy3dgen(Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("tencent/Hunyuan3D-2"))
+    # FOHO_HIP_GEO_DECODER=0 keeps the ShapeVAE's geometry decoder on its torch module (default: foho_geo_decode_fwd / _bwd)
+    _PIPELINE = GuidedShapePipeline.from_hy3dgen(Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("tencent/Hunyuan3D-2"),
+                                                 hip_geo_decoder=os.environ.get("FOHO_HIP_GEO_DECODER", "1") != "0")
     return _PIPELINE
 
 

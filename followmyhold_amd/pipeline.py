@@ -82,12 +82,19 @@ class GuidedShapePipeline:
         self.to(device, dtype)
 
     @classmethod
-    def from_hy3dgen(cls, pipe):
-        """Adopt the networks of an (unpatched) hy3dgen `Hunyuan3DDiTFlowMatchingPipeline` object."""
+    def from_hy3dgen(cls, pipe, hip_geo_decoder=True):
+        """Adopt the networks of an (unpatched) hy3dgen `Hunyuan3DDiTFlowMatchingPipeline` object.  The ShapeVAE's geometry
+        decoder -- the 65^3-point decode and its backward inside every inner iteration, PL:292-313, 1391-1393, 1507-1509 -- is
+        taken over by the matrix-core kernels (`geo_decode.install`); a decoder outside the shapes they take raises `FohoError`
+        here, `hip_geo_decoder=False` keeps the torch module."""
         from .scheduler import FlowMatchEulerDiscreteScheduler
         sch = FlowMatchEulerDiscreteScheduler(num_train_timesteps=pipe.scheduler.config.num_train_timesteps,
                                               shift=getattr(pipe.scheduler.config, "shift", 1.0))
-        return cls(pipe.vae, pipe.model, sch, pipe.conditioner, pipe.image_processor, device=pipe.device, dtype=pipe.dtype)
+        self = cls(pipe.vae, pipe.model, sch, pipe.conditioner, pipe.image_processor, device=pipe.device, dtype=pipe.dtype)
+        if hip_geo_decoder:
+            from . import geo_decode
+            geo_decode.install(self.vae, device=self.device)
+        return self
 
     def to(self, device=None, dtype=None):
         if device is not None:
