@@ -323,3 +323,25 @@ def test_decoder_adopts_a_module_laid_out_like_hy3dgen(qk_norm):
     dec.cross_attn_decoder.attn.attention.q_norm = torch.nn.GroupNorm(4, 64).cuda()             # another kind of norm: refused, not mis-decoded
     with pytest.raises(L.FohoError):
         HipGeoDecoder.from_module(dec)
+
+
+@gpu
+def test_from_hy3dgen_installs_the_hip_decoder():
+    """GuidedShapePipeline.from_hy3dgen (what the guidance stage builds from an installed Hunyuan3D-2 pipeline) hands the ShapeVAE's
+    geometry decoder to the HIP kernels by default, keeps the torch module on request, and fails loudly for a decoder outside the
+    kernels' shapes instead of quietly staying on torch."""
+    import types
+    from followmyhold_amd import _lib as L, standins
+    from followmyhold_amd.pipeline import GuidedShapePipeline
+
+    def fake(width, heads):
+        vae = standins.StandInShapeVAE(num_latents=128, embed_dim=8, width=width, heads=heads, layers=1, num_freqs=8)
+        sch = types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000, shift=1.0))
+        return types.SimpleNamespace(vae=vae, model=standins.StandInDiT(embed_dim=8), scheduler=sch, conditioner=standins.StandInConditioner(),
+                                     image_processor=standins.StandInImageProcessor(), device="cuda", dtype=torch.float32)
+
+    pipe = GuidedShapePipeline.from_hy3dgen(fake(128, 2))
+    assert getattr(pipe.vae, "hip_geo", None) is not None
+    assert getattr(GuidedShapePipeline.from_hy3dgen(fake(128, 2), hip_geo_decoder=False).vae, "hip_geo", None) is None
+    with pytest.raises(L.FohoError):
+        GuidedShapePipeline.from_hy3dgen(fake(96, 2))          # head dimension 48
