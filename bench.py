@@ -678,8 +678,36 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     # activations are kept: nothing else is recomputed)
     flops_bwd = n * (4 * W * F + 2 * W * W + 8 * NL * W)
     gerr = (fb["hip"][1] - fb["torch"][1]).abs().max().item() / fb["torch"][1].abs().max().item()
+    # the same decode with the module laid out like hy3dgen's CrossAttentionDecoder as the released ShapeVAE configures it
+    # (bias-free c_q / c_kv with K and V interleaved per head, qk_norm: LayerNorm over the head dimension of q and k, no prior)
+    torch.manual_seed(1)
+    dech3 = standins.Hy3dgenLayoutDecoder(W, NH, qk_norm=True).to(dev).eval()
+    hip3 = HipGeoDecoder.from_module(dech3, device=dev)
+    def hip3_f():
+        hip3._prepared = None
+        with torch.no_grad():
+            return hip3(q32, lat)
+    def hip3_fb():
+        l = lat.clone().requires_grad_(True)
+        (hip3(q32, l).float() * go).sum().backward()
+    h3 = {}
+    for name, fn in (("fwd_ms", hip3_f), ("fwd_bwd_ms", hip3_fb)):
+        fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        h3[name] = min(ts) * 1e3
+    with torch.no_grad():
+        r3 = torch.cat([dech3.half()(xyz[s0:s0 + 8000].half().unsqueeze(0), lat) for s0 in range(0, n, 8000)], 1)
+    h3["max_abs_diff_vs_torch_fp16"] = (hip3_f().float() - r3.float()).abs().max().item()
+    h3["logit_scale"] = r3.float().abs().max().item()
+    del hip3, dech3, r3
     pipes, pipes_src = geo_pipe_busy()
-    return {"pipe_busy_by_kernel": pipes, "pipe_busy_source": pipes_src, "fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
+    return {"hy3dgen_layout_qk_norm": h3, "pipe_busy_by_kernel": pipes, "pipe_busy_source": pipes_src, "fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
             "fwd_bwd_tflops": (flops + flops_bwd) / fb["hip"][0] / 1e12, "grad_rel_diff_vs_torch_fp16": gerr,
             "queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
             "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops / 1e12,

@@ -239,48 +239,7 @@ def test_latent2sdf_uses_the_hip_decoder_with_and_without_gradients():
     assert err <= 2e-2 * lat_r.grad.abs().max().item(), (err, lat_r.grad.abs().max().item())
 
 
-class _Hy3dLikeDecoder(torch.nn.Module):
-    """A module laid out like hy3dgen's CrossAttentionDecoder (hy3dgen/shapegen/models/autoencoders/attention_blocks.py, not in
-    the reference tree; restated from its published structure): FourierEmbedder.frequencies, query_proj,
-    cross_attn_decoder = ResidualCrossAttentionBlock{ln_1 (queries), ln_2 (latents), ln_3, attn{c_q, c_kv, c_proj,
-    attention{heads, q_norm, k_norm}}, mlp{c_fc, c_proj}}, ln_post, output_proj -- c_kv's output is viewed as (tokens, heads, 2 d)
-    and split into K and V per head, i.e. K and V rows INTERLEAVE head by head."""
-
-    def __init__(self, width, heads, num_freqs=8, qk_norm=False):
-        super().__init__()
-        nn = torch.nn
-        self.fourier_embedder = nn.Module()
-        self.fourier_embedder.register_buffer("frequencies", 2.0 ** torch.arange(num_freqs, dtype=torch.float32))      # include_pi=False
-        self.query_proj = nn.Linear(3 * (2 * num_freqs + 1), width)
-        blk = nn.Module()
-        blk.ln_1, blk.ln_2, blk.ln_3 = nn.LayerNorm(width), nn.LayerNorm(width), nn.LayerNorm(width)
-        blk.attn = nn.Module()
-        blk.attn.c_q, blk.attn.c_kv, blk.attn.c_proj = nn.Linear(width, width, bias=False), nn.Linear(width, 2 * width, bias=False), nn.Linear(width, width)
-        blk.attn.attention = nn.Module()
-        blk.attn.attention.heads = heads
-        d = width // heads     # qk_norm: LayerNorm over the head dimension on q and k (the released ShapeVAE config switches it on)
-        blk.attn.attention.q_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
-        blk.attn.attention.k_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
-        blk.mlp = nn.Module()
-        blk.mlp.c_fc, blk.mlp.c_proj = nn.Linear(width, 4 * width), nn.Linear(4 * width, width)
-        self.cross_attn_decoder = blk
-        self.ln_post, self.output_proj = nn.LayerNorm(width), nn.Linear(width, 1)
-        self.heads = heads
-
-    def forward(self, queries, latents):
-        q32 = queries.float()
-        emb = (q32[..., None] * self.fourier_embedder.frequencies).flatten(-2)
-        x = self.query_proj(torch.cat([q32, emb.sin(), emb.cos()], -1).to(latents.dtype))
-        b = self.cross_attn_decoder
-        B, N, C = x.shape
-        q = b.attn.c_q(b.ln_1(x)).view(B, N, self.heads, -1)
-        kv = b.attn.c_kv(b.ln_2(latents)).view(B, latents.shape[1], self.heads, -1)
-        k, v = torch.split(kv, C // self.heads, dim=-1)
-        q, k = b.attn.attention.q_norm(q), b.attn.attention.k_norm(k)
-        a = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(B, N, C)
-        x = x + b.attn.c_proj(a)
-        x = x + b.mlp.c_proj(torch.nn.functional.gelu(b.mlp.c_fc(b.ln_3(x))))
-        return self.output_proj(self.ln_post(x))
+from followmyhold_amd.standins import Hy3dgenLayoutDecoder as _Hy3dLikeDecoder   # the hy3dgen attribute layout, restated
 
 
 @gpu
