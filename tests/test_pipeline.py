@@ -207,6 +207,52 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
 
 
 @gpu
+def test_guided_pipeline_with_the_hip_geometry_decoder_in_the_loop(tmp_path):
+    """The short schedule again with a ShapeVAE whose decoder the matrix-core kernels take (width 128, 2 heads, 128 latent tokens),
+    `geo_decode.install`-ed: every decode of the loop -- with autograd in phases B / C (foho_geo_decode_fwd_keep / _bwd), without for
+    the per-step and final grids -- goes through the HIP decoder and the run completes like the one on the torch module: same
+    iteration counts, finite closed surfaces, the object where the similarity puts it, and the latent's gradient doing something."""
+    from PIL import Image
+    from followmyhold_amd import facade as p3d, geo_decode
+    sc = _scene_for_pipeline()
+    paths = _write(tmp_path, sc)
+    img = Image.open(paths["cropped_obj_img_path"])
+    kw = dict(num_latents=128, embed_dim=8, width=128, heads=2, layers=1, num_freqs=8)
+    T = sc["T_h2m"].astype(np.float64)
+    centre = (sc["obj_verts"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).mean(0)
+    out = {}
+    for name in ("torch", "hip"):
+        pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1, **kw)
+        if name == "hip":
+            dec = geo_decode.install(pipe.vae)
+            calls = {"keep": 0, "fwd": 0, "bwd": 0}
+            for attr, key in (("decode_keep", "keep"), ("decode", "fwd"), ("decode_bwd", "bwd")):
+                fn = getattr(dec, attr)
+                setattr(dec, attr, (lambda f, k: (lambda *a, **b: (calls.__setitem__(k, calls[k] + 1), f(*a, **b))[1]))(fn, key))
+
+        def run(cfg):
+            return pipe(image=[img], mc_algo="mc", generator=torch.manual_seed(2), config=cfg, renderer=_renderer(sc["fov"]), sil_renderer=None,
+                        J_regressor=sc["J_regressor"], guidance_octree_resolution=24, final_octree_resolution=40, callback=lambda *a: None,
+                        callback_steps=1, **paths)
+
+        obj, hand = run(_short_config())
+        assert isinstance(obj, p3d.Meshes) and pipe.stats == {"inner_iterations": 10 + 3 + 2 * 2, "skipped_empty": 0}
+        ov, of = obj.verts_packed(), obj.faces_packed()
+        # closed surface(s): V - F / 2 = 2 per component (this random decoder adds a small second blob to the sphere)
+        assert ov.shape[0] > 1000 and (2 * ov.shape[0] - of.shape[0]) in (4, 8, 12) and torch.isfinite(ov).all() and torch.isfinite(hand.verts_packed()).all()
+        assert np.abs(ov.mean(0).cpu().numpy() - centre).max() < 0.12
+        obj0, _ = run(_short_config(noise_lr=0.0))
+        v0 = obj0.verts_packed()
+        assert v0.shape != ov.shape or not torch.allclose(v0, ov, atol=1e-6)           # the gradient reached the latent
+        out[name] = ov
+    # 3 + 2 x 2 latent iterations under autograd per run (two runs), each one kept forward + one backward; the no-gradient decodes besides
+    assert calls["keep"] == calls["bwd"] and calls["keep"] >= 7 and calls["fwd"] >= 5, calls
+    # same decoded object as with the torch decoder up to what a chaotic 17-iteration trajectory does to it (DESIGN.md section 8)
+    assert abs(out["hip"].shape[0] - out["torch"].shape[0]) <= 0.2 * out["torch"].shape[0]
+    assert (out["hip"].mean(0) - out["torch"].mean(0)).abs().max().item() < 0.05
+
+
+@gpu
 def test_latent_to_loss_chain_matches_the_oracle_chain():
     """One phase-C iteration exactly as the pipeline runs it (PL:1505-1601): noise prediction -> step_final -> VAE ->
     SDF grid -> FlexiCubes -> joint loss, and dL/d(noise prediction).  HIP chain vs the CPU chain through the oracle
