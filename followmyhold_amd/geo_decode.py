@@ -16,6 +16,7 @@ There is no CPU path: the constructor raises when the module's shape is outside 
 64, width % 128 == 0 and <= 1024, n_latents % 64 == 0, hidden % 128 == 0).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -239,10 +240,12 @@ class HipGeoDecoder:
             raise L.FohoError("HipGeoDecoder: one set of latent tokens per call")
         if torch.is_grad_enabled() and latents.requires_grad:
             return _GeoDecodeFn.apply(self.kv_of(latents), queries, self).to(latents.dtype).reshape(1, -1, 1)
-        key = (latents.data_ptr(), latents._version, tuple(latents.shape))
-        if self._prepared != key:
+        # K / V are reused only for the very same tensor OBJECT at the same version: an address is no identity (the allocator hands
+        # a freed latent's block to the next one, version 0 again)
+        hit = self._prepared is not None and self._prepared[0]() is latents and self._prepared[1] == latents._version
+        if not hit:
             self.prepare(latents)
-            self._prepared = key
+            self._prepared = (weakref.ref(latents), latents._version)
         return self.decode(queries).to(latents.dtype).reshape(1, -1, 1)
 
 

@@ -157,6 +157,22 @@ def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk)
     # a second call on the same tokens reuses K / V; new tokens are projected again
     out2 = hip(q.float(), lat)
     assert torch.equal(out, out2)
+    # ... also when they live where the old ones did (the caching allocator reuses a freed latent's block: no reuse by address)
+    lat_b = lat.clone()
+    out_b = hip(q.float(), lat_b)
+    ptr = lat_b.data_ptr()
+    del lat_b
+    lat_c = (lat.float() * 0.5).half()
+    if lat_c.data_ptr() == ptr:                       # what the allocator usually does
+        with torch.no_grad():
+            ref_c = dec(q, lat_c.float())
+        assert (hip(q.float(), lat_c).float() - ref_c).abs().max().item() <= 2e-3 * max(learned.abs().max().item(), 1.0) * dec.gain + 1e-3 * ref_c.abs().max().item()
+    lat_d = lat.clone()
+    hip(q.float(), lat_d)
+    lat_d.mul_(1.25)                                  # same object, new version: projected again
+    with torch.no_grad():
+        ref_d = dec(q, lat_d.float())
+    assert (hip(q.float(), lat_d).float() - ref_d).abs().max().item() <= 2e-3 * max(learned.abs().max().item(), 1.0) * dec.gain + 1e-3 * ref_d.abs().max().item()
     lat2 = (lat.float() * 1.5).half()
     out3 = hip(q.float(), lat2)
     with torch.no_grad():
