@@ -207,8 +207,9 @@ template <int EP>
 __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                      const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                      h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                     int ldc2) {
+                                                     int ldc2, const int* __restrict__ Mdev) {
     __shared__ uint4 lds[2][2][GM * GK * 2 / 16];  // [buffer][A | W][128 rows x 8 chunks] = 64 KB
+    if (Mdev) M = min(M, *Mdev);   // device-resident row count (foho_geo_decode_bwd_rows): tiles beyond it leave at once
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     // XCD-aware tile order: the blocks of one XCD (L mod 8) sweep N inside one row panel of A, eight panels (one per XCD) at a time
     const int ntn = N / GN, ntm = (M + GM - 1) / GM;
@@ -322,8 +323,9 @@ template <int EP>
 __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                         h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                        int ldc2) {
+                                                        int ldc2, const int* __restrict__ Mdev) {
     __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
+    if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int ntn = N / HN, ntm = (M + HM - 1) / HM;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
@@ -444,8 +446,9 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
-                                                     int heads, float* __restrict__ nlse) {
+                                                     int heads, float* __restrict__ nlse, const int* __restrict__ Mdev) {
     __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
+    if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     int head, qblk;
     if ((heads & 7) == 0) {  // an XCD (block id mod 8) keeps heads/8 heads: their K and V stay in its L2
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         head = blockIdx.x % heads;
         qblk = blockIdx.x / heads;
     }
+    if (qblk * AQ >= M) return;   // (only with a device-resident row count: the grid is sized for the capacity)
     const int q0 = qblk * AQ + w * 64;
 
     half8 qf[2][4];  // B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16 kk + 8 hi .. + 7]
@@ -704,7 +708,9 @@ __device__ __forceinline__ f32x16 cat16(f32x4 a, f32x4 b, f32x4 c, f32x4 d) {
 __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__ Qs, const h16* __restrict__ QsT, const h16* __restrict__ dO,
                                                          const h16* __restrict__ dOT, int ldt, const float* __restrict__ nlse,
                                                          const float* __restrict__ ndelta, const h16* __restrict__ KV, int ldkv, int width,
-                                                         int heads, int M, int splits, int L, int accumulate, float* __restrict__ part) {
+                                                         int heads, int M, int splits, int L, int accumulate, float* __restrict__ part,
+                                                         const int* __restrict__ Mdev) {
+    if (Mdev) M = max(min(M, *Mdev), 0);   // 0 rows: the first block of a call still writes its (zero) partial sums
     __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
     __shared__ float lsd[2][2][BQ];       // [buffer][-lse | -delta]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -937,7 +943,8 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce(const float* __restrict_
 // ndelta[q][head] = - sum_d dO[q][head, d] O[q][head, d] (negated: the backward attention starts its dP accumulators there); one
 // wave per row, 8 lanes per head and half row; rows M .. the next multiple of 64 (the padding of the last query tile) get 0
 __global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, const h16* __restrict__ O, int width, int heads, int M,
-                                                   float* __restrict__ ndelta) {
+                                                   float* __restrict__ ndelta, const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= ((M + 63) & ~63)) return;
@@ -962,7 +969,9 @@ __global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, c
 template <int MODE>
 __global__ __launch_bounds__(256) void k_geo_ln_bwd(const h16* __restrict__ X, const float* __restrict__ gamma, const h16* __restrict__ DY,
                                                     const h16* __restrict__ DR, const float* __restrict__ gvec, float gain,
-                                                    const float* __restrict__ w_out, h16* __restrict__ DX, int M, int width, float eps) {
+                                                    const float* __restrict__ w_out, h16* __restrict__ DX, int M, int width, float eps,
+                                                    const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -1043,7 +1052,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_geo_ln(const h16* __restrict__ X, int ldx, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, h16* __restrict__ Y, int ldy, int M, int width,
                                                 float eps, const float* __restrict__ w_out, float b_out, const float* __restrict__ queries,
-                                                float radius, float sharpness, float gain, float* __restrict__ logits) {
+                                                float radius, float sharpness, float gain, float* __restrict__ logits,
+                                                const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -1112,7 +1123,8 @@ __global__ __launch_bounds__(256) void k_geo_ln(const h16* __restrict__ X, int l
 // Fourier embedding of the query points, [x, sin(x f_j), cos(x f_j)] flattened as (coordinate, frequency) like the
 // reference's FourierEmbedder, rounded to fp16 and zero-padded to 64 columns (the K of the query projection GEMM).
 __global__ __launch_bounds__(256) void k_geo_embed(const float* __restrict__ queries, int M, int n_freqs, const float* __restrict__ freqs,
-                                                   h16* __restrict__ E) {
+                                                   h16* __restrict__ E, const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int row = gid >> 3, ch = gid & 7;
     if (row >= M) return;
@@ -1136,7 +1148,85 @@ __global__ __launch_bounds__(256) void k_geo_embed(const float* __restrict__ que
     *reinterpret_cast<half8*>(E + (size_t)row * 64 + ch * 8) = out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compaction of the rows whose logit gradient is not zero (foho_geo_decode_bwd_rows), in row order: k_geo_rows_count leaves the number
+// of such rows of every 2048-row segment, k_geo_rows_compact turns them into offsets (every workgroup sums the counts in front of it:
+// at most a few hundred values) and writes the survivors' index, query point and gradient; the last workgroup publishes the total,
+// the rows dropped for lack of capacity and the row count of every row block of the chain (the kernels' Mdev).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {   // sum over the 256 threads, known to all of them
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_geo_rows_count(const float* __restrict__ g, int64_t n, int* __restrict__ counts) {
+    __shared__ int sh[4];
+    const int64_t r0 = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8;
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (r0 + e < n && g[r0 + e] != 0.0f) c++;
+    c = block_sum_256(c, sh);
+    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(256) void k_geo_rows_compact(const float* __restrict__ g, const float* __restrict__ queries, int64_t n, const int* __restrict__ counts,
+                                                          int nscan, int64_t cap, int chunk, int nblk, int* __restrict__ mblk, float* __restrict__ q_out,
+                                                          float* __restrict__ g_out, int* __restrict__ idx_out, int* __restrict__ stats_out) {
+    __shared__ int sh[4], wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int before = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) before += counts[i];
+    before = block_sum_256(before, sh);
+    const int64_t r0 = (int64_t)blockIdx.x * 2048 + tid * 8;
+    float gv[8];
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        gv[e] = (r0 + e < n) ? g[r0 + e] : 0.0f;
+        c += gv[e] != 0.0f;
+    }
+    int incl = c;   // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int pos = before + incl - c;
+    for (int i = 0; i < wv; i++) pos += wsum[i];
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (gv[e] != 0.0f) {
+            if (pos < cap) {
+                const int64_t r = r0 + e;
+                idx_out[pos] = (int)r;
+                g_out[pos] = gv[e];
+                q_out[3 * (size_t)pos] = queries[3 * r], q_out[3 * (size_t)pos + 1] = queries[3 * r + 1], q_out[3 * (size_t)pos + 2] = queries[3 * r + 2];
+            }
+            pos++;
+        }
+    if ((int)blockIdx.x == nscan - 1 || nscan == 0) {
+        const int total = before + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const int kept = (int)min((int64_t)total, cap);
+        for (int cblk = tid; cblk < nblk; cblk += 256) mblk[2 + cblk] = max(min(kept - cblk * chunk, chunk), 0);
+        if (tid == 0) {
+            mblk[0] = total, mblk[1] = total - kept;
+            if (stats_out) stats_out[0] = total, stats_out[1] = total - kept;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_geo_zero16(uint4* __restrict__ p, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
+// eps of one of the chain's LayerNorms: its own field when set, else ln_eps (callers of ABI 103 filled only that one)
+static inline float eps_of(const foho_geo_weights* w, float own) { return own > 0.0f ? own : w->ln_eps; }
 static bool launch_ok(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1149,15 +1239,16 @@ static bool launch_ok(const char* what) {
 static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
 template <int EP>
 static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
-                        h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2) {
-    if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2);
-    else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2);
+                        h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
+    if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
 }
 
 // ep: bit mask of EP_*.  R: the residual (EP_RESID) or the saved pre-activation (EP_GELUBWD); C2: the pre-activation output
-// (EP_SAVEZ, leading dimension ldc2) or the transposed copy (EP_TRANS, row length ldc2)
+// (EP_SAVEZ, leading dimension ldc2) or the transposed copy (EP_TRANS, row length ldc2).  Mdev: optional DEVICE row count (the
+// launch is sized for M, the kernel works on min(M, *Mdev) rows)
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
-                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0) {
+                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr) {
     if (M <= 0) return FOHO_OK;
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & EP_QNORM) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
     if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
@@ -1166,7 +1257,7 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
-#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(big, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2); break
+#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(big, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev); break
     switch (ep) {
         GEO_GEMM_CASE(0);
         GEO_GEMM_CASE(EP_GELU);
@@ -1241,13 +1332,54 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
     char* base = (char*)ws;
     h16 *kv = (h16*)(base + l.kv), *vt = (h16*)(base + l.vt), *ln = (h16*)(base + l.a);
     const int W = w->width, Lr = w->n_latents;
-    hipLaunchKernelGGL(k_geo_ln<0>, dim3((Lr + 3) / 4), dim3(256), 0, s, (const h16*)latents, W, w->ln_kv_g, w->ln_kv_b, ln, W, Lr, W, w->ln_eps,
-                       (const float*)nullptr, 0.0f, (const float*)nullptr, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+    hipLaunchKernelGGL(k_geo_ln<0>, dim3((Lr + 3) / 4), dim3(256), 0, s, (const h16*)latents, W, w->ln_kv_g, w->ln_kv_b, ln, W, Lr, W, eps_of(w, w->ln_kv_eps),
+                       (const float*)nullptr, 0.0f, (const float*)nullptr, 0.0f, 0.0f, 0.0f, (float*)nullptr, (const int*)nullptr);
     if (!launch_ok("k_geo_ln(kv)")) return FOHO_ERR_LAUNCH;
     if (int rc = gemm(0, ln, W, (const h16*)w->w_kv, W, w->b_kv, nullptr, 0, kv, 2 * W, Lr, 2 * W, W, 1.0f, s)) return rc;
     if (w->k_norm) hipLaunchKernelGGL(k_geo_knorm, dim3((Lr * w->heads + 255) / 256), dim3(256), 0, s, kv, 2 * W, Lr, w->heads, w->k_norm);
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
     return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
+// ---- the forward chain in two halves: what depends only on the query points (Fourier embedding -> query projection -> ln_q ->
+// c_q [+ q_norm], scaled for the exp2 softmax), and what depends on the latent tokens.  The first half is the same for every
+// decode of one grid (foho_geo_prepare_queries caches it: X0 and Qs of all rows, 4 KB per query at width 1024).
+static int chain_query_side(const foho_geo_weights* w, const float* q, int M, h16* E, h16* X0, h16* Xn, h16* Qs, h16* QsT, int ldt, hipStream_t s,
+                            const int* Mdev = nullptr) {
+    const int W = w->width;
+    const float qscale = 1.4426950408889634f * 0.125f;  // log2(e) / sqrt(64): the attention kernel exponentiates with exp2
+    const float* nof = nullptr;
+    hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), dim3(256), 0, s, q, M, w->n_freqs, w->freqs, E, Mdev);
+    if (!launch_ok("k_geo_embed")) return FOHO_ERR_LAUNCH;
+    if (int rc = gemm(0, E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, X0, W, M, W, 64, 1.0f, s, nullptr, 0, Mdev)) return rc;
+    hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, X0, W, w->ln_q_g, w->ln_q_b, Xn, W, M, W, eps_of(w, w->ln_q_eps), nof, 0.0f, nof, 0.0f, 0.0f, 0.0f,
+                       (float*)nullptr, Mdev);
+    if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
+    return gemm((QsT ? EP_TRANS : 0) | (w->q_norm ? EP_QNORM : 0), Xn, W, (const h16*)w->w_q, W, w->b_q, (const h16*)w->q_norm, 0, Qs, W, M, W, W, qscale, s, QsT,
+                ldt, Mdev);
+}
+
+// attention over the latent tokens -> c_proj + residual -> ln_2 -> fc1 + GELU -> fc2 + residual.  Z != NULL keeps the MLP's
+// pre-activation, lse != NULL the attention's log-sum-exp (both for a backward).  X0 / Qs: the query side's outputs for these rows.
+static int chain_latent_side(const foho_geo_weights* w, int M, const h16* X0, const h16* Qs, h16* At, h16* X1, h16* Xn, h16* Z, h16* H, h16* X2, float* lse,
+                             const h16* kv, const h16* vt, hipStream_t s, const int* Mdev = nullptr) {
+    const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
+    const float* nof = nullptr;
+    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), dim3(256), 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse, Mdev);
+    if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
+    if (int rc = gemm(EP_RESID, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s, nullptr, 0, Mdev)) return rc;
+    hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, X1, W, w->ln_2_g, w->ln_2_b, Xn, W, M, W, eps_of(w, w->ln_2_eps), nof, 0.0f, nof, 0.0f, 0.0f, 0.0f,
+                       (float*)nullptr, Mdev);
+    if (!launch_ok("k_geo_ln(2)")) return FOHO_ERR_LAUNCH;
+    if (int rc = gemm(Z ? (EP_GELU | EP_SAVEZ) : EP_GELU, Xn, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, H, F, M, F, W, 1.0f, s, Z, Z ? F : 0, Mdev)) return rc;
+    return gemm(EP_RESID, H, F, (const h16*)w->w_fc2, F, w->b_fc2, X1, W, X2, W, M, W, F, 1.0f, s, nullptr, 0, Mdev);
+}
+
+// logits = output_proj(ln_post(x2)) (+ the stand-in's analytic prior)
+static int chain_logits(const foho_geo_weights* w, const float* q, int M, const h16* X2, float* logits, hipStream_t s) {
+    hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, X2, w->width, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, w->width, w->ln_eps, w->w_out,
+                       w->b_out, q, w->prior_radius, w->prior_sharpness, w->out_gain, logits, (const int*)nullptr);
+    return launch_ok("k_geo_ln(post)") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
 extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
@@ -1260,36 +1392,72 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
     char* base = (char*)ws;
     const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
     h16 *E = (h16*)(base + l.e), *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
-    const int W = w->width, Lr = w->n_latents, F = w->hidden;
-    const float qscale = 1.4426950408889634f * 0.125f;  // log2(e) / sqrt(64): the attention kernel exponentiates with exp2
-    const float* nof = nullptr;
     for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
         const float* q = queries + 3 * r0;
-        hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), dim3(256), 0, s, q, M, w->n_freqs, w->freqs, E);
-        if (!launch_ok("k_geo_embed")) return FOHO_ERR_LAUNCH;
-        // x0 = query_proj(embed)                                                     -> A
-        if (int rc = gemm(0, E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, bA, W, M, W, 64, 1.0f, s)) return rc;
-        // q = c_q(ln_q(x0)) * log2(e) / 8                                             B -> C
-        hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_q_g, w->ln_q_b, bB, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f,
-                           0.0f, (float*)nullptr);
-        if (!launch_ok("k_geo_ln(q)")) return FOHO_ERR_LAUNCH;
-        if (int rc = gemm(w->q_norm ? EP_QNORM : 0, bB, W, (const h16*)w->w_q, W, w->b_q, (const h16*)w->q_norm, 0, bC, W, M, W, W, qscale, s)) return rc;
-        // attention over the latent tokens                                           C -> B
-        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * w->heads), dim3(256), 0, s, bC, W, kv, 2 * W, vt, Lr, bB, W, M, w->heads, (float*)nullptr);
-        if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
-        // x1 = x0 + c_proj(attn)                                                      B (+A) -> C
-        if (int rc = gemm(EP_RESID, bB, W, (const h16*)w->w_proj, W, w->b_proj, bA, W, bC, W, M, W, W, 1.0f, s)) return rc;
-        // x2 = x1 + fc2(gelu(fc1(ln_2(x1))))                                          C -> B -> H -> A
-        hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, bC, W, w->ln_2_g, w->ln_2_b, bB, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f,
-                           0.0f, (float*)nullptr);
-        if (!launch_ok("k_geo_ln(2)")) return FOHO_ERR_LAUNCH;
-        if (int rc = gemm(EP_GELU, bB, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, bH, F, M, F, W, 1.0f, s)) return rc;
-        if (int rc = gemm(EP_RESID, bH, F, (const h16*)w->w_fc2, F, w->b_fc2, bC, W, bA, W, M, W, F, 1.0f, s)) return rc;
-        // logits = output_proj(ln_post(x2)) (+ the stand-in's analytic prior)
-        hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, bA, W, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, W, w->ln_eps, w->w_out,
-                           w->b_out, q, w->prior_radius, w->prior_sharpness, w->out_gain, logits + r0);
-        if (!launch_ok("k_geo_ln(post)")) return FOHO_ERR_LAUNCH;
+        // x0 -> A, ln_q(x0) -> B, q -> C;  attention C -> B;  x1 = x0 + c_proj: B (+A) -> C;  ln_2: C -> B;  fc1: B -> H;  x2 = x1 + fc2: H (+C) -> A
+        if (int rc = chain_query_side(w, q, M, E, bA, bB, bC, nullptr, 0, s)) return rc;
+        if (int rc = chain_latent_side(w, M, bA, bC, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s)) return rc;
+        if (int rc = chain_logits(w, q, M, bA, logits + r0, s)) return rc;
+    }
+    return FOHO_OK;
+}
+
+// ---- the query side, cached (PL:1125-1143, 298-308: the grid of a guidance run never changes -- 65^3 points for all 550 inner
+// iterations of every image): X0 = query_proj(embed(q)) and Qs = c_q(ln_q(X0)) [q_norm] log2(e) / 8 of ALL rows, fp16.
+struct CacheLayout {
+    size_t x0, qs, total;
+};
+static CacheLayout cache_layout(const foho_geo_weights* w, int64_t n) {
+    CacheLayout l{};
+    const size_t rows = ((size_t)std::max<int64_t>(n, 1) * w->width * 2 + 255) & ~(size_t)255;
+    l.x0 = 0, l.qs = rows, l.total = 2 * rows;
+    return l;
+}
+extern "C" size_t foho_geo_query_cache_bytes(const foho_geo_weights* w, int64_t n_queries) {
+    if (check_weights(w) != FOHO_OK || n_queries < 0) return 0;
+    return cache_layout(w, n_queries).total;
+}
+
+extern "C" int foho_geo_prepare_queries(const foho_geo_weights* w, const float* queries, int64_t n_queries, int32_t chunk_rows, void* ws, size_t ws_bytes,
+                                        void* cache, size_t cache_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!queries || !ws || !cache || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_prepare_queries: null argument");
+    const Layout l = layout(w, chunk_rows);
+    const CacheLayout c = cache_layout(w, n_queries);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_prepare_queries: workspace too small");
+    if (cache_bytes < c.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_prepare_queries: cache too small (foho_geo_query_cache_bytes)");
+    hipStream_t s = (hipStream_t)stream_;
+    char* base = (char*)ws;
+    h16 *E = (h16*)(base + l.e), *bB = (h16*)(base + l.b);
+    h16 *X0 = (h16*)((char*)cache + c.x0), *Qs = (h16*)((char*)cache + c.qs);
+    const size_t W = w->width;
+    for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
+        const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
+        if (int rc = chain_query_side(w, queries + 3 * r0, M, E, X0 + r0 * W, bB, Qs + r0 * W, nullptr, 0, s)) return rc;
+    }
+    return FOHO_OK;
+}
+
+extern "C" int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float* queries, int64_t n_queries, const void* cache, size_t cache_bytes,
+                                          float* logits, int32_t chunk_rows, void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = check_weights(w)) return rc;
+    if (!queries || !cache || !logits || !ws || chunk_rows <= 0 || n_queries < 0) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_fwd_cached: null argument");
+    const Layout l = layout(w, chunk_rows);
+    const CacheLayout c = cache_layout(w, n_queries);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd_cached: workspace too small");
+    if (cache_bytes < c.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd_cached: cache too small");
+    hipStream_t s = (hipStream_t)stream_;
+    char* base = (char*)ws;
+    const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
+    h16 *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
+    const h16 *X0 = (const h16*)((const char*)cache + c.x0), *Qs = (const h16*)((const char*)cache + c.qs);
+    const size_t W = w->width;
+    for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
+        const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
+        // attention Qs -> B;  x1 = x0 + c_proj: B (+X0) -> C;  ln_2: C -> B;  fc1: B -> H;  x2 = x1 + fc2: H (+C) -> A
+        if (int rc = chain_latent_side(w, M, X0 + r0 * W, Qs + r0 * W, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s)) return rc;
+        if (int rc = chain_logits(w, queries + 3 * r0, M, bA, logits + r0, s)) return rc;
     }
     return FOHO_OK;
 }
@@ -1391,42 +1559,29 @@ struct ChunkPtrs {
 };
 
 // the forward chain of one row block with everything its backward needs kept (P.Qs .. P.lse)
-static int chain_fwd_keep(const foho_geo_weights* w, const float* q, int M, const ChunkPtrs& P, const h16* kv, const h16* vt, hipStream_t s) {
-    const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
-    const float qscale = 1.4426950408889634f * 0.125f;
-    const float* nof = nullptr;
-    const dim3 rows((M + 3) / 4), blk(256);
-    hipLaunchKernelGGL(k_geo_embed, dim3((M * 8 + 255) / 256), blk, 0, s, q, M, w->n_freqs, w->freqs, P.E);
-    if (int rc = gemm(0, P.E, 64, (const h16*)w->w_qproj, 64, w->b_qproj, nullptr, 0, P.X0, W, M, W, 64, 1.0f, s)) return rc;
-    hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X0, W, w->ln_q_g, w->ln_q_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
-    if (int rc = gemm(EP_TRANS | (w->q_norm ? EP_QNORM : 0), P.Xn, W, (const h16*)w->w_q, W, w->b_q, (const h16*)w->q_norm, 0, P.Qs, W, M, W, W, qscale, s,
-                      P.QsT, P.ldt))
-        return rc;
-    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), blk, 0, s, P.Qs, W, kv, 2 * W, vt, Lr, P.At, W, M, NH, P.lse);
-    if (int rc = gemm(EP_RESID, P.At, W, (const h16*)w->w_proj, W, w->b_proj, P.X0, W, P.X1, W, M, W, W, 1.0f, s)) return rc;
-    hipLaunchKernelGGL(k_geo_ln<0>, rows, blk, 0, s, P.X1, W, w->ln_2_g, w->ln_2_b, P.Xn, W, M, W, w->ln_eps, nof, 0.0f, nof, 0.0f, 0.0f, 0.0f, (float*)nullptr);
-    if (int rc = gemm(EP_GELU | EP_SAVEZ, P.Xn, W, (const h16*)w->w_fc1, W, w->b_fc1, nullptr, 0, P.H, F, M, F, W, 1.0f, s, P.Z, F)) return rc;
-    if (int rc = gemm(EP_RESID, P.H, F, (const h16*)w->w_fc2, F, w->b_fc2, P.X1, W, P.X2, W, M, W, F, 1.0f, s)) return rc;
-    return launch_ok("geometry decoder forward chain") ? FOHO_OK : FOHO_ERR_LAUNCH;
+static int chain_fwd_keep(const foho_geo_weights* w, const float* q, int M, const ChunkPtrs& P, const h16* kv, const h16* vt, hipStream_t s,
+                          const int* Mdev = nullptr) {
+    if (int rc = chain_query_side(w, q, M, P.E, P.X0, P.Xn, P.Qs, P.QsT, P.ldt, s, Mdev)) return rc;
+    return chain_latent_side(w, M, P.X0, P.Qs, P.At, P.X1, P.Xn, P.Z, P.H, P.X2, P.lse, kv, vt, s, Mdev);
 }
 
 // ... and backwards: logits -> ln_post -> fc2 -> GELU -> fc1 -> ln_2 (+ residual) -> c_proj -> attention (K, V partial sums)
 static int chain_bwd(const foho_geo_weights* w, const float* grad_logits, int M, const ChunkPtrs& P, const h16* kv, int splits, int accumulate, float* part,
-                     hipStream_t s) {
+                     hipStream_t s, const int* Mdev = nullptr) {
     const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
     const float* nof = nullptr;
     const dim3 rows((M + 3) / 4), blk(256);
     hipLaunchKernelGGL(k_geo_ln_bwd<1>, rows, blk, 0, s, P.X2, w->ln_post_g, (const h16*)nullptr, (const h16*)nullptr, grad_logits, w->out_gain, w->w_out, P.dX2,
-                       M, W, w->ln_eps);
-    if (int rc = gemm(EP_GELUBWD, P.dX2, W, (const h16*)w->w_fc2_t, W, w->zeros, P.Z, F, P.H, F, M, F, W, 1.0f, s)) return rc;                // dZ -> H
-    if (int rc = gemm(0, P.H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, P.Xn, W, M, W, F, 1.0f, s)) return rc;                       // d ln_2 out -> Xn
-    hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, P.X1, w->ln_2_g, P.Xn, P.dX2, nof, 0.0f, nof, P.X0, M, W, w->ln_eps);                // dX1 -> X0
-    if (int rc = gemm(EP_TRANS, P.X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, P.dX2, W, M, W, W, 1.0f, s, P.dAT, P.ldt)) return rc;  // dO -> dX2
-    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), blk, 0, s, P.dX2, P.At, W, NH, M, P.delta);
+                       M, W, w->ln_eps, Mdev);
+    if (int rc = gemm(EP_GELUBWD, P.dX2, W, (const h16*)w->w_fc2_t, W, w->zeros, P.Z, F, P.H, F, M, F, W, 1.0f, s, nullptr, 0, Mdev)) return rc;          // dZ -> H
+    if (int rc = gemm(0, P.H, F, (const h16*)w->w_fc1_t, F, w->zeros, nullptr, 0, P.Xn, W, M, W, F, 1.0f, s, nullptr, 0, Mdev)) return rc;                 // d ln_2 out -> Xn
+    hipLaunchKernelGGL(k_geo_ln_bwd<0>, rows, blk, 0, s, P.X1, w->ln_2_g, P.Xn, P.dX2, nof, 0.0f, nof, P.X0, M, W, eps_of(w, w->ln_2_eps), Mdev);                    // dX1 -> X0
+    if (int rc = gemm(EP_TRANS, P.X0, W, (const h16*)w->w_proj_t, W, w->zeros, nullptr, 0, P.dX2, W, M, W, W, 1.0f, s, P.dAT, P.ldt, Mdev)) return rc;    // dO -> dX2
+    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), blk, 0, s, P.dX2, P.At, W, NH, M, P.delta, Mdev);
     if (!launch_ok("geometry decoder backward chain (row kernels)")) return FOHO_ERR_LAUNCH;
     const int nkb = Lr / 128;
     hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((NH * splits + 7) / 8) * nkb), blk, 0, s, P.Qs, P.QsT, P.dX2, P.dAT, P.ldt, P.lse, P.delta, kv, 2 * W, W, NH, M, splits, Lr,
-                       accumulate, part);
+                       accumulate, part, Mdev);
     return launch_ok("k_geo_attn_bwd") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
@@ -1469,17 +1624,13 @@ extern "C" int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* 
     if (!saved || saved_bytes < foho_geo_saved_bytes(w, chunk_rows, n_queries)) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_fwd_keep: buffer for the activations too small");
     hipStream_t s = (hipStream_t)stream_;
     const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
-    const float* nof = nullptr;
-    (void)nof;
     for (int64_t r0 = 0, c = 0; r0 < n_queries; r0 += chunk_rows, c++) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
         const ChunkPtrs P = chunk_ptrs(b, (char*)bws, sl, (char*)saved + c * sl.total);
         // columns of Qs^T beyond a ragged block's rows meet P = 0 in the backward and must be finite
         if ((M & 63) && hipMemsetAsync(P.QsT, 0, (size_t)w->width * b.ldt * 2, s) != hipSuccess) return fail(FOHO_ERR_LAUNCH, "foho_geo_decode_fwd_keep: memset failed");
         if (int rc = chain_fwd_keep(w, queries + 3 * r0, M, P, kv, vt, s)) return rc;
-        hipLaunchKernelGGL(k_geo_ln<1>, dim3((M + 3) / 4), dim3(256), 0, s, P.X2, w->width, w->ln_post_g, w->ln_post_b, (h16*)nullptr, 0, M, w->width, w->ln_eps,
-                           w->w_out, w->b_out, queries + 3 * r0, w->prior_radius, w->prior_sharpness, w->out_gain, logits + r0);
-        if (!launch_ok("k_geo_ln(post)")) return FOHO_ERR_LAUNCH;
+        if (int rc = chain_logits(w, queries + 3 * r0, M, P.X2, logits + r0, s)) return rc;
     }
     return FOHO_OK;
 }
@@ -1515,6 +1666,82 @@ extern "C" int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queri
     return launch_ok("k_geo_dkv_reduce") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
+// ---- backward over the ACTIVE rows only.  The gradient that reaches latent2sdf comes out of FlexiCubes (PL:1507-1509, 1600): it is
+// non-zero on the end points of the grid edges the iso-surface crosses -- 5-10 % of the 65^3 rows.  A row whose logit gradient is zero
+// contributes exactly zero to dK / dV, so the rows with grad_logits != 0 are compacted ON THE DEVICE (in row order: deterministic),
+// the forward chain is recomputed for them and the backward runs on them.  The count stays in device memory: every launch is sized
+// for a row block of the capacity and works on min(block, what is left of the count) rows -- blocks beyond the count leave at once --
+// so there is no host synchronisation and the call can be captured in a hipGraph.
+struct RowsLayout {
+    size_t counts, mblk, q, g, idx, total;
+    int nscan, nblk;
+};
+constexpr int ROWS_PER_WG = 2048;
+static RowsLayout rows_layout(int64_t n, int64_t cap, int chunk) {
+    RowsLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    l.nscan = (int)((n + ROWS_PER_WG - 1) / ROWS_PER_WG);
+    l.nblk = (int)std::max<int64_t>((cap + chunk - 1) / chunk, 1);
+    l.counts = take((size_t)std::max(l.nscan, 1) * 4);
+    l.mblk = take((size_t)(std::max(l.nblk, 1) + 2) * 4);     // [0]: the count, [1]: rows dropped for lack of capacity, [2 + c]: rows of block c
+    l.q = take((size_t)std::max<int64_t>(cap, 1) * 12);
+    l.g = take((size_t)std::max<int64_t>(cap, 1) * 4);
+    l.idx = take((size_t)std::max<int64_t>(cap, 1) * 4);
+    l.total = off;
+    return l;
+}
+
+extern "C" size_t foho_geo_rows_workspace_bytes(int64_t n_queries, int64_t row_cap, int32_t chunk_rows) {
+    if (n_queries < 0 || chunk_rows <= 0) return 0;
+    if (row_cap <= 0 || row_cap > n_queries) row_cap = n_queries;
+    return rows_layout(n_queries, row_cap, chunk_rows).total;
+}
+
+extern "C" int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+                                        int64_t row_cap, int32_t chunk_rows, void* ws, size_t ws_bytes, void* bws, size_t bws_bytes, void* rows_ws,
+                                        size_t rows_ws_bytes, int32_t* stats_out, void* stream_) {
+    if (int rc = bwd_args("foho_geo_decode_bwd_rows", w, queries, grad_logits, ws, bws, chunk_rows, n_queries, true)) return rc;
+    if (!grad_kv || !rows_ws) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd_rows: null argument");
+    if (n_queries >= ((int64_t)1 << 31)) return fail(FOHO_ERR_BAD_ARG, "foho_geo_decode_bwd_rows: row indices are 32-bit");
+    if (row_cap <= 0 || row_cap > n_queries) row_cap = n_queries;
+    const Layout l = layout(w, chunk_rows);
+    const BwdLayout b = bwd_layout(w, chunk_rows);
+    const SavedLayout sl = saved_layout(w, chunk_rows);
+    const RowsLayout rl = rows_layout(n_queries, row_cap, chunk_rows);
+    if (ws_bytes < l.total || bws_bytes < b.total || rows_ws_bytes < rl.total) return fail(FOHO_ERR_WORKSPACE, "foho_geo_decode_bwd_rows: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const h16 *kv = (const h16*)((char*)ws + l.kv), *vt = (const h16*)((char*)ws + l.vt);
+    char *base = (char*)bws, *rb = (char*)rows_ws;
+    const int W = w->width, Lr = w->n_latents;
+    int *counts = (int*)(rb + rl.counts), *mblk = (int*)(rb + rl.mblk), *idx = (int*)(rb + rl.idx);
+    float *qa = (float*)(rb + rl.q), *ga = (float*)(rb + rl.g);
+    // the transposed copies' columns beyond a ragged block's rows must be finite (they meet P = 0): cleared by a kernel (memset nodes
+    // of a captured graph are not reliably ordered on this stack)
+    const size_t n16 = (size_t)W * b.ldt * 2 / 16;
+    hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)(base + b.dat), n16);
+    hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)(base + b.qst), n16);
+    hipLaunchKernelGGL(k_geo_rows_count, dim3(std::max(rl.nscan, 1)), dim3(256), 0, s, grad_logits, n_queries, counts);
+    hipLaunchKernelGGL(k_geo_rows_compact, dim3(std::max(rl.nscan, 1)), dim3(256), 0, s, grad_logits, queries, n_queries, counts, rl.nscan, row_cap, chunk_rows, rl.nblk,
+                       mblk, qa, ga, idx, stats_out);
+    if (!launch_ok("k_geo_rows_compact")) return FOHO_ERR_LAUNCH;
+    float* part = (float*)(base + b.part);
+    const ChunkPtrs P = chunk_ptrs(b, base, sl, nullptr);
+    for (int64_t r0 = 0, c = 0; c < std::max(rl.nblk, 1); r0 += chunk_rows, c++) {
+        const int M = (int)std::max<int64_t>(std::min<int64_t>(chunk_rows, row_cap - r0), 1);
+        const int* Mdev = mblk + 2 + c;
+        if (int rc = chain_fwd_keep(w, qa + 3 * r0, M, P, kv, vt, s, Mdev)) return rc;
+        if (int rc = chain_bwd(w, ga + r0, M, P, kv, b.splits, c > 0 ? 1 : 0, part, s, Mdev)) return rc;
+    }
+    const size_t n4 = (size_t)Lr * 2 * W / 4;
+    hipLaunchKernelGGL(k_geo_dkv_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, b.splits, n4, grad_kv);
+    return launch_ok("k_geo_dkv_reduce") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
 extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
                              int32_t gelu, float scale, void* stream) {
@@ -1536,6 +1763,6 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
-                       n_latents, (h16*)O, W, M, heads, (float*)nullptr);
+                       n_latents, (h16*)O, W, M, heads, (float*)nullptr, (const int*)nullptr);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }

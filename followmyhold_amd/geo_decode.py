@@ -30,7 +30,8 @@ class FohoGeoWeights(ctypes.Structure):
                 ("ln_2_g", L.vp), ("ln_2_b", L.vp), ("w_fc1", L.vp), ("b_fc1", L.vp), ("w_fc2", L.vp), ("b_fc2", L.vp),
                 ("ln_post_g", L.vp), ("ln_post_b", L.vp), ("w_out", L.vp), ("b_out", L.c_f), ("ln_eps", L.c_f),
                 ("prior_radius", L.c_f), ("prior_sharpness", L.c_f), ("out_gain", L.c_f),
-                ("w_fc2_t", L.vp), ("w_fc1_t", L.vp), ("w_proj_t", L.vp), ("zeros", L.vp), ("q_norm", L.vp), ("k_norm", L.vp)]
+                ("w_fc2_t", L.vp), ("w_fc1_t", L.vp), ("w_proj_t", L.vp), ("zeros", L.vp), ("q_norm", L.vp), ("k_norm", L.vp),
+                ("ln_q_eps", L.c_f), ("ln_kv_eps", L.c_f), ("ln_2_eps", L.c_f), ("reserved2", L.c_f)]
 
 
 def _bias(lin, n, device):
@@ -46,6 +47,13 @@ def _parts(m):
         return dict(freqs=m.freqs, query_proj=m.query_proj, ln_q=b.ln_q, ln_kv=b.ln_kv, ln_2=b.ln_2, q=b.q, kv=b.kv, proj=b.proj, fc1=b.fc1,
                     fc2=b.fc2, ln_post=m.ln_post, out=m.out, heads=b.heads, kv_interleaved=False,
                     prior=(float(m.radius), float(m.sharpness), float(m.gain)))
+    # what this decoder does not implement is refused, never adopted silently
+    if getattr(m, "latents_proj", None) is not None and not isinstance(m.latents_proj, torch.nn.Identity):
+        raise L.FohoError("HipGeoDecoder: a decoder with latents_proj (downsample_ratio != 1) is not supported")
+    if getattr(m, "ln_post", None) is None or not isinstance(m.ln_post, torch.nn.LayerNorm):
+        raise L.FohoError("HipGeoDecoder: a decoder without ln_post (enable_ln_post=False) is not supported")
+    if m.output_proj.out_features != 1:
+        raise L.FohoError(f"HipGeoDecoder: output_proj of {m.output_proj.out_features} channels (one occupancy logit is supported)")
     blk = m.cross_attn_decoder
     att = blk.attn
     qk = {}
@@ -118,13 +126,25 @@ class HipGeoDecoder:
             if name in t:
                 setattr(w, name, t[name].data_ptr())
         w.b_out = float(p["out"].bias.detach().reshape(-1)[0]) if p["out"].bias is not None else 0.0
-        w.ln_eps = float(p["ln_post"].eps)
+        # one eps per LayerNorm: hy3dgen builds the block's ln_1 / ln_2 / ln_3 with 1e-6 and ln_post with torch's default
+        w.ln_eps, w.ln_q_eps, w.ln_kv_eps, w.ln_2_eps = float(p["ln_post"].eps), float(p["ln_q"].eps), float(p["ln_kv"].eps), float(p["ln_2"].eps)
         w.prior_radius, w.prior_sharpness, w.out_gain = p["prior"]
         self.w = w
         self.chunk = int(chunk_rows or self.CHUNK)
         self.workspace = None
         self.bwd_workspace = None
-        self.keep_activations = True      # forward under autograd keeps what the backward needs (False: recompute, no memory)
+        # How a decode under autograd gets its backward:
+        #   "rows"      (default) plain forward, nothing kept; the backward compacts the rows whose logit gradient is not zero on the
+        #               device, recomputes the chain for them and back-propagates them only (foho_geo_decode_bwd_rows) -- exact, and
+        #               the guidance loop's gradient (out of FlexiCubes) is non-zero on 5-10 % of the grid
+        #   "keep"      the forward keeps the activations of ALL rows (18 KB per query), the backward is dense: the fastest route for a
+        #               dense gradient
+        #   "recompute" dense backward, the forward recomputed per row block (no memory)
+        self.backward_mode = "rows"
+        self.row_cap = None               # upper bound on the active rows a caller can vouch for (None: all rows -- cannot overflow)
+        self.last_row_stats = None        # device int32[2] of the last "rows" backward: active rows, rows dropped for lack of capacity
+        self.query_cache_limit = 4 << 30  # bytes: grids whose cached query side (4 KB per point at width 1024) fits are cached
+        self._qcache = None               # (weakref to the query tensor, its version, shape, cache buffer)
         self._prepared = None
         for fn in (self.lib.foho_geo_workspace_bytes, self.lib.foho_geo_bwd_workspace_bytes):
             fn.restype = ctypes.c_size_t
@@ -166,7 +186,7 @@ class HipGeoDecoder:
         differentiates itself (3072 tokens; the 274 625 query rows are foho_geo_decode_bwd's)."""
         t = self.t
         lat = latents.reshape(-1, latents.shape[-1]).to(self.device)
-        x = torch.nn.functional.layer_norm(lat.float(), (self.w.width,), t["ln_kv_g"], t["ln_kv_b"], self.w.ln_eps)
+        x = torch.nn.functional.layer_norm(lat.float(), (self.w.width,), t["ln_kv_g"], t["ln_kv_b"], self.w.ln_kv_eps)
         kv = x.half() @ t["w_kv"].t() + t["b_kv"].half()
         if "k_norm" in t:                                 # qk_norm on the key side, differentiable like the rest of this function
             W, kn = self.w.width, t["k_norm"]
@@ -184,6 +204,14 @@ class HipGeoDecoder:
         self._check(self.lib.foho_geo_set_kv(ctypes.byref(self.w), L.vp(kv.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
                                              ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_set_kv")
         self._prepared = None
+
+    @property
+    def keep_activations(self):
+        return self.backward_mode == "keep"
+
+    @keep_activations.setter
+    def keep_activations(self, keep):       # the switch of rounds 3-4: True = "keep", False = "recompute"
+        self.backward_mode = "keep" if keep else "recompute"
 
     def _bwd_ws(self):
         if self.bwd_workspace is None:
@@ -224,11 +252,88 @@ class HipGeoDecoder:
                                                  ctypes.c_size_t(saved.numel() if saved is not None else 0), L.vp(stream)), "foho_geo_decode_bwd")
         return out
 
+    def decode_bwd_rows(self, queries, grad_logits, row_cap=None):
+        """decode_bwd over the rows whose logit gradient is not zero (foho_geo_decode_bwd_rows): no kept activations, no host
+        synchronisation; `last_row_stats` (device int32[2]) holds the number of active rows and of rows dropped because they
+        exceeded `row_cap` (None: all rows, nothing can be dropped)."""
+        q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
+        g = grad_logits.reshape(-1).to(self.device, torch.float32).contiguous()
+        if g.shape[0] != q.shape[0]:
+            raise L.FohoError(f"HipGeoDecoder: {q.shape[0]} queries, {g.shape[0]} logit gradients")
+        n = q.shape[0]
+        cap = int(row_cap or self.row_cap or n)
+        cap = n if cap <= 0 or cap > n else cap
+        self.lib.foho_geo_rows_workspace_bytes.restype = ctypes.c_size_t
+        need = int(self.lib.foho_geo_rows_workspace_bytes(ctypes.c_int64(n), ctypes.c_int64(cap), ctypes.c_int32(self.chunk)))
+        if getattr(self, "_rows_ws", None) is None or self._rows_ws.numel() < need:
+            self._rows_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        bws = self._bwd_ws()
+        out = torch.empty(self.w.n_latents, 2 * self.w.width, dtype=torch.float32, device=self.device)
+        stats = torch.zeros(2, dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_decode_bwd_rows(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(n), L.vp(g.data_ptr()), L.vp(out.data_ptr()),
+                                                      ctypes.c_int64(cap), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
+                                                      ctypes.c_size_t(self.workspace.numel()), L.vp(bws.data_ptr()), ctypes.c_size_t(bws.numel()),
+                                                      L.vp(self._rows_ws.data_ptr()), ctypes.c_size_t(self._rows_ws.numel()), L.vp(stats.data_ptr()),
+                                                      L.vp(stream)), "foho_geo_decode_bwd_rows")
+        self.last_row_stats = stats
+        return out
+
+    def prepare_queries(self, queries):
+        """Cache the latent-independent half of the chain (embedding -> query_proj -> ln_1 -> c_q) for this query tensor: decodes of the
+        same tensor object (same version) skip it (foho_geo_decode_fwd_cached; logits bitwise equal).  The guidance loop decodes the
+        same 65^3 grid 550 times per image (PL:1125-1143)."""
+        q = queries.reshape(-1, 3)
+        if q.device.type != self.device.type or q.dtype != torch.float32 or not queries.is_contiguous():
+            raise L.FohoError("HipGeoDecoder.prepare_queries: a contiguous float32 tensor on the decoder's device (it is cached by identity)")
+        if self.workspace is None:
+            self._size_for(self.w.n_latents)
+        self.lib.foho_geo_query_cache_bytes.restype = ctypes.c_size_t
+        need = int(self.lib.foho_geo_query_cache_bytes(ctypes.byref(self.w), ctypes.c_int64(q.shape[0])))
+        buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.foho_geo_prepare_queries(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), ctypes.c_int32(self.chunk),
+                                                      L.vp(self.workspace.data_ptr()), ctypes.c_size_t(self.workspace.numel()), L.vp(buf.data_ptr()),
+                                                      ctypes.c_size_t(need), L.vp(stream)), "foho_geo_prepare_queries")
+        # keyed by storage address + version + size, with the tensor kept alive (so the address cannot be handed to another one)
+        self._qcache = (queries, queries._version, buf)
+        return buf
+
+    def _cached_queries(self, queries):
+        c = self._qcache
+        if (c is not None and torch.is_tensor(queries) and queries.dtype == torch.float32 and queries.data_ptr() == c[0].data_ptr()
+                and queries._version == c[1] == c[0]._version and queries.numel() == c[0].numel() and queries.is_contiguous()):
+            return c[2]
+        return None
+
+    def grid_queries(self, xyz):
+        """The query tensor latent2sdf hands to the decoder for the grid positions `xyz` (N, 3): on the device, rounded to fp16 like
+        PL:303, float32, shape (1, N, 3) -- built once per `xyz` tensor (same object, same version) and, when the cached query side fits
+        `query_cache_limit`, with the latent-independent half of the chain prepared (prepare_queries)."""
+        g = getattr(self, "_grid", None)
+        if g is not None and g[0] is xyz and g[1] == xyz._version:
+            return g[2]
+        q = xyz.to(self.device).half().float().reshape(1, -1, 3).contiguous()
+        self.lib.foho_geo_query_cache_bytes.restype = ctypes.c_size_t
+        if int(self.lib.foho_geo_query_cache_bytes(ctypes.byref(self.w), ctypes.c_int64(q.shape[1]))) <= self.query_cache_limit:
+            self.prepare_queries(q)
+        else:
+            self._qcache = None
+        self._grid = (xyz, xyz._version, q)
+        return q
+
     def decode(self, queries):
         """queries (N, 3) -> logits (N,) float32, against the tokens of the last prepare()."""
+        cache = self._cached_queries(queries)
         q = queries.reshape(-1, 3).to(self.device, torch.float32).contiguous()
         out = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if cache is not None:
+            self._check(self.lib.foho_geo_decode_fwd_cached(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(cache.data_ptr()),
+                                                            ctypes.c_size_t(cache.numel()), L.vp(out.data_ptr()), ctypes.c_int32(self.chunk),
+                                                            L.vp(self.workspace.data_ptr()), ctypes.c_size_t(self.workspace.numel()), L.vp(stream)),
+                        "foho_geo_decode_fwd_cached")
+            return out
         self._check(self.lib.foho_geo_decode_fwd(ctypes.byref(self.w), L.vp(q.data_ptr()), ctypes.c_int64(q.shape[0]), L.vp(out.data_ptr()),
                                                  ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()), ctypes.c_size_t(self.workspace.numel()),
                                                  L.vp(stream)), "foho_geo_decode_fwd")
@@ -250,18 +355,22 @@ class HipGeoDecoder:
 
 
 class _GeoDecodeFn(torch.autograd.Function):
-    """logits(kv): forward = foho_geo_set_kv + foho_geo_decode_fwd_keep (the activations the backward needs stay in HBM, 5 GB
-    per 65^3 grid; `dec.keep_activations = False`: foho_geo_decode_fwd, and the backward recomputes the forward per row block),
-    backward = foho_geo_decode_bwd."""
+    """logits(kv), by `dec.backward_mode`: "rows" -- forward = foho_geo_set_kv + foho_geo_decode_fwd[_cached], backward =
+    foho_geo_decode_bwd_rows over the rows with a non-zero gradient; "keep" -- forward = foho_geo_decode_fwd_keep (the activations
+    the backward needs stay in HBM, 5 GB per 65^3 grid), backward = foho_geo_decode_bwd; "recompute" -- plain forward, dense
+    backward with the forward recomputed per row block."""
 
     @staticmethod
     def forward(ctx, kv, queries, dec):
         dec.set_kv(kv)
         ctx.dec = dec
-        if dec.keep_activations:
+        ctx.mode = dec.backward_mode
+        if ctx.mode == "keep":
             out, saved = dec.decode_keep(queries)
             ctx.save_for_backward(kv.detach(), queries, saved)
             return out
+        if ctx.mode not in ("rows", "recompute"):
+            raise L.FohoError(f"HipGeoDecoder.backward_mode {ctx.mode!r}: 'rows', 'keep' or 'recompute'")
         ctx.save_for_backward(kv.detach(), queries)
         return dec.decode(queries)
 
@@ -269,6 +378,8 @@ class _GeoDecodeFn(torch.autograd.Function):
     def backward(ctx, grad):
         kv, queries, *saved = ctx.saved_tensors
         ctx.dec.set_kv(kv)                    # the workspace may have served another decode since
+        if ctx.mode == "rows":
+            return ctx.dec.decode_bwd_rows(queries, grad).to(kv.dtype), None, None
         return ctx.dec.decode_bwd(queries, grad, saved[0] if saved else None).to(kv.dtype), None, None
 
 

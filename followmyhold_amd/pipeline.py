@@ -44,7 +44,7 @@ def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     if hip is not None:
         # all grid points in one call, no 8000-query chunks; under autograd (PL:1391-1393, 1507-1509) the gradient reaches
         # `pred` through foho_geo_decode_bwd
-        grid_logits = hip(xyz_samples.to(device).half().float().unsqueeze(0), pred)      # fp16 query points like PL:303
+        grid_logits = hip(hip.grid_queries(xyz_samples), pred)      # fp16 query points like PL:303; the query side is cached per grid
         return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
     logits = []
     for start in range(0, xyz_samples.shape[0], num_chunks):
@@ -216,7 +216,7 @@ class GuidedShapePipeline:
             hip = getattr(self.vae, "hip_geo", None)
             for b in range(x1.shape[0]):
                 if hip is not None:          # geo_decode.install(vae): all points in one call, gradients through foho_geo_decode_bwd
-                    out.append(-hip(xyz.to(device).half().float().unsqueeze(0), pred[b:b + 1]).view(-1).float())
+                    out.append(-hip(hip.grid_queries(xyz), pred[b:b + 1]).view(-1).float())
                     continue
                 logits = [self.vae.geo_decoder(xyz[s0:s0 + num_chunks].half().unsqueeze(0), pred[b:b + 1]) for s0 in range(0, xyz.shape[0], num_chunks)]
                 out.append(-torch.cat(logits, dim=1).view(-1).float())

@@ -74,7 +74,7 @@ class Hy3dgenLayoutDecoder(nn.Module):
         self.fourier_embedder.register_buffer("frequencies", 2.0 ** torch.arange(num_freqs, dtype=torch.float32))      # include_pi=False
         self.query_proj = nn.Linear(3 * (2 * num_freqs + 1), width)
         blk = nn.Module()
-        blk.ln_1, blk.ln_2, blk.ln_3 = nn.LayerNorm(width), nn.LayerNorm(width), nn.LayerNorm(width)
+        blk.ln_1, blk.ln_2, blk.ln_3 = nn.LayerNorm(width, eps=1e-6), nn.LayerNorm(width, eps=1e-6), nn.LayerNorm(width, eps=1e-6)   # hy3dgen's eps
         blk.attn = nn.Module()
         blk.attn.c_q, blk.attn.c_kv, blk.attn.c_proj = nn.Linear(width, width, bias=False), nn.Linear(width, 2 * width, bias=False), nn.Linear(width, width)
         blk.attn.attention = nn.Module()

@@ -406,7 +406,7 @@ typedef struct {
     const float *ln_post_g, *ln_post_b;
     const float* w_out;              /* (width) fp32: output_proj (one occupancy logit)                         */
     float b_out;
-    float ln_eps;                    /* 1e-5 (torch default) unless the model says otherwise                    */
+    float ln_eps;                    /* eps of ln_post (and of the other LayerNorms while their own fields below are 0) */
     float prior_radius, prior_sharpness, out_gain;  /* logits = sharpness (radius - |x|) + gain * learned.  A trained decoder:
                                         0, 0, 1.  (The random-initialised stand-in of the tests adds an analytic sphere.) */
     /* backward only (foho_geo_decode_bwd; may be NULL for forward-only use): the three matrices the gradient flows back
@@ -420,9 +420,12 @@ typedef struct {
      * normalises K; K / V handed to foho_geo_set_kv are expected normalised already (the caller's autograd owns that).     */
     const float* q_norm;
     const float* k_norm;
+    /* version 104: eps of the three LayerNorms in front of the attention / the MLP (hy3dgen builds the block's ln_1 / ln_2 / ln_3
+     * with eps 1e-6 and ln_post with torch's default 1e-5); 0 = the same as ln_eps, which stays ln_post's                      */
+    float ln_q_eps, ln_kv_eps, ln_2_eps, reserved2;
 } foho_geo_weights;
 
-/* sizeof(foho_geo_weights) of the loaded build (version 103): the Python side compares it with its ctypes mirror before the
+/* sizeof(foho_geo_weights) of the loaded build (version 104): the Python side compares it with its ctypes mirror before the
  * first call, like foho_abi_sizes does for the step's structs */
 int64_t foho_geo_abi_size(void);
 /* workspace for row blocks of `chunk_rows` queries: K / V of the latent tokens + the block's activations (14.5 KB per
@@ -459,6 +462,31 @@ int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* queries, in
 int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
                         int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
                         const void* saved, size_t saved_bytes, void* stream);
+/* The query side, cached.  The grid the latent is decoded on never changes during a guidance run (PL:1125-1143: 65^3 points for
+ * all 550 inner iterations of every image) and a quarter of the forward chain depends on nothing else: Fourier embedding ->
+ * query_proj -> ln_1 -> c_q (-> q_norm) (PL:298-308 runs it again per chunk and per decode).  foho_geo_prepare_queries computes
+ * x0 = query_proj(embed(q)) and the scaled attention queries of all rows once into `cache` (foho_geo_query_cache_bytes: 4 KB per
+ * query at width 1024 -- 1.1 GB per 65^3 grid); foho_geo_decode_fwd_cached is foho_geo_decode_fwd from there on: the same kernels
+ * on the same numbers, logits bitwise equal. */
+size_t foho_geo_query_cache_bytes(const foho_geo_weights* w, int64_t n_queries);
+int foho_geo_prepare_queries(const foho_geo_weights* w, const float* queries, int64_t n_queries, int32_t chunk_rows, void* workspace,
+                             size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream);
+int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float* queries, int64_t n_queries, const void* cache, size_t cache_bytes,
+                               float* logits, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+/* foho_geo_decode_bwd over the ACTIVE rows only.  The gradient that reaches latent2sdf in the guidance loop comes out of the
+ * FlexiCubes backward (PL:1507-1509, 1600) and is non-zero only at the end points of the grid edges the iso-surface crosses
+ * (5-10 % of a 65^3 grid); a row with a zero logit gradient adds exactly zero to dK / dV.  The rows with grad_logits != 0 are
+ * compacted on the device (in row order: the result is bitwise repeatable), the forward chain is recomputed for them and the
+ * backward runs on them -- the forward in front of it is plain foho_geo_decode_fwd[_cached]: nothing is kept.  The number of
+ * active rows stays in device memory: launches are sized for row blocks of the capacity, each kernel works on
+ * min(block, what is left of the count) rows and row blocks beyond the count leave at once: no host synchronisation, capturable in
+ * a hipGraph.  row_cap: the caller's upper bound on the number of active rows (<= 0 or > n_queries: n_queries, which can never
+ * overflow); rows beyond it are dropped and COUNTED.  stats_out: optional DEVICE int32[2] = {active rows, rows dropped}.
+ * rows_workspace: foho_geo_rows_workspace_bytes(n_queries, row_cap, chunk_rows); workspace / bwd_workspace as for foho_geo_decode_bwd. */
+size_t foho_geo_rows_workspace_bytes(int64_t n_queries, int64_t row_cap, int32_t chunk_rows);
+int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+                             int64_t row_cap, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace,
+                             size_t bwd_workspace_bytes, void* rows_workspace, size_t rows_workspace_bytes, int32_t* stats_out, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.

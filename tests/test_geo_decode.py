@@ -275,6 +275,10 @@ def test_decoder_adopts_a_module_laid_out_like_hy3dgen(qk_norm):
             for nrm in (dec.cross_attn_decoder.attn.attention.q_norm, dec.cross_attn_decoder.attn.attention.k_norm):
                 nrm.weight.add_(0.2 * torch.randn_like(nrm.weight))
                 nrm.bias.add_(0.2 * torch.randn_like(nrm.bias))
+    # one eps per LayerNorm (hy3dgen: 1e-6 in the block, torch's default on ln_post); made large and distinct here so that a decoder
+    # which applied one eps to all four would miss the tolerance
+    blk = dec.cross_attn_decoder
+    blk.ln_1.eps, blk.ln_2.eps, blk.ln_3.eps, dec.ln_post.eps = 3e-2, 1e-1, 5e-2, 2e-1
     g = torch.Generator().manual_seed(9)
     lat = torch.randn(1, 384, 256, generator=g).half().cuda()
     q = (torch.rand(1, 3000, 3, generator=g) * 2.0 - 1.0).half().cuda()
@@ -298,6 +302,17 @@ def test_decoder_adopts_a_module_laid_out_like_hy3dgen(qk_norm):
     dec.cross_attn_decoder.attn.attention.q_norm = torch.nn.GroupNorm(4, 64).cuda()             # another kind of norm: refused, not mis-decoded
     with pytest.raises(L.FohoError):
         HipGeoDecoder.from_module(dec)
+    # ... and so are the decoder variants these kernels do not implement
+    for spoil in ("latents_proj", "no_ln_post", "two_channels"):
+        d2 = _Hy3dLikeDecoder(256, 4, qk_norm=False).cuda().eval()
+        if spoil == "latents_proj":
+            d2.latents_proj = torch.nn.Linear(256, 256).cuda()
+        elif spoil == "no_ln_post":
+            d2.ln_post = None
+        else:
+            d2.output_proj = torch.nn.Linear(256, 2).cuda()
+        with pytest.raises(L.FohoError):
+            HipGeoDecoder.from_module(d2)
 
 
 @gpu
@@ -320,3 +335,157 @@ def test_from_hy3dgen_installs_the_hip_decoder():
     assert getattr(GuidedShapePipeline.from_hy3dgen(fake(128, 2), hip_geo_decoder=False).vae, "hip_geo", None) is None
     with pytest.raises(L.FohoError):
         GuidedShapePipeline.from_hy3dgen(fake(96, 2))          # head dimension 48
+
+
+@gpu
+@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk,fill", [(256, 4, 256, 5000, 2048, 0.07), (256, 4, 128, 4097, 4096, 0.5), (256, 4, 256, 9000, 2048, 1.0),
+                                                              (256, 4, 128, 3000, 2048, 0.0), (1024, 16, 3072, 30000, 16384, 0.08)])
+def test_active_row_backward_equals_the_dense_backward(width, heads, n_lat, n_q, chunk, fill):
+    """foho_geo_decode_bwd_rows (device-side compaction of the rows with grad != 0, chain recomputed and back-propagated for them
+    only) against foho_geo_decode_bwd over all rows: a zero row adds exactly zero, so the two agree to the accumulation order of
+    the partial sums; with every row active the compaction is the identity and the results are bitwise equal.  No atomics in the
+    compaction or the chain: bitwise repeatable.  The device-resident statistics report the number of active rows."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(width, heads, n_lat)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, n_lat, width, generator=g).half().cuda()
+    q = (torch.rand(1, n_q, 3, generator=g) * 2.2 - 1.1).half().float().cuda()
+    go = torch.randn(n_q, generator=g)
+    keep = torch.rand(n_q, generator=g) < fill
+    if 0.0 < fill < 1.0:
+        keep[-1] = True                       # the very last row of a ragged block is active
+        keep[:chunk // 2] = False             # ... and a long stretch of leading zeros
+    go = torch.where(keep, go, torch.zeros(())).cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=chunk)
+    hip.set_kv(hip.kv_of(lat).detach())
+    dense = hip.decode_bwd(q, go)
+    rows = hip.decode_bwd_rows(q, go)
+    stats = hip.last_row_stats.cpu().tolist()
+    assert stats == [int(keep.sum()), 0]
+    assert torch.isfinite(rows).all()
+    assert torch.equal(rows, hip.decode_bwd_rows(q, go))
+    if fill == 1.0:
+        assert torch.equal(rows, dense)
+    elif fill == 0.0:
+        assert not rows.any() and not dense.any()
+    else:
+        scale = dense.abs().max().item()
+        cos = torch.nn.functional.cosine_similarity(rows.flatten().double(), dense.flatten().double(), dim=0).item()
+        assert scale > 0 and (rows - dense).abs().max().item() <= 1e-3 * scale and cos >= 1 - 1e-6, ((rows - dense).abs().max().item(), scale, cos)
+        # a capacity below the number of active rows drops the rows beyond it and says so (never silently)
+        n_act = int(keep.sum())
+        cap = n_act - 5
+        short = hip.decode_bwd_rows(q, go, row_cap=cap)
+        assert hip.last_row_stats.cpu().tolist() == [n_act, 5]
+        last5 = torch.nonzero(go).flatten()[-5:]
+        go2 = go.clone()
+        go2[last5] = 0.0
+        assert torch.equal(short, hip.decode_bwd_rows(q, go2))
+    # through autograd: "rows" is the default route of a decode whose latents require grad; "keep" and "recompute" give the same gradient
+    grads = {}
+    for mode in ("rows", "keep", "recompute"):
+        hip.backward_mode = mode
+        lat_m = lat.clone().requires_grad_(True)
+        (hip(q.unsqueeze(0) if q.dim() == 2 else q, lat_m).float().reshape(-1) * go).sum().backward()
+        grads[mode] = lat_m.grad.float() if lat_m.grad is not None else torch.zeros_like(lat).float()
+    sc = grads["recompute"].abs().max().item()
+    for mode in ("rows", "keep"):
+        assert (grads[mode] - grads["recompute"]).abs().max().item() <= 2e-3 * sc + 1e-12, mode
+
+
+@gpu
+def test_cached_query_side_gives_bitwise_equal_logits():
+    """foho_geo_prepare_queries + foho_geo_decode_fwd_cached: the latent-independent half of the chain (embedding -> query_proj -> ln_1 ->
+    c_q) computed once per grid; the same kernels on the same numbers => logits bitwise equal to foho_geo_decode_fwd, for several
+    latents, with a ragged last block; a query tensor that changes (new version) or another tensor is not served from the cache."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(256, 4, 256)
+    g = torch.Generator().manual_seed(2)
+    q = (torch.rand(1, 5001, 3, generator=g) * 2.2 - 1.1).half().float().cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)
+    lats = [torch.randn(1, 256, 256, generator=g).half().cuda() for _ in range(2)]
+    plain = [hip(q, lat).clone() for lat in lats]
+    plain_g = hip(q, lats[0].clone().requires_grad_(True)).detach().clone()      # the autograd route (K / V by torch: not bitwise the no-grad route's)
+    assert hip._cached_queries(q) is None
+    hip.prepare_queries(q)
+    assert hip._cached_queries(q) is not None and hip._cached_queries(q.clone()) is None
+    for lat, ref in zip(lats, plain):
+        assert torch.equal(hip(q, lat), ref)
+    # under autograd, too (the "rows" route's forward is the cached forward)
+    lat_g = lats[0].clone().requires_grad_(True)
+    assert torch.equal(hip(q, lat_g).detach(), plain_g)
+    q.mul_(0.5)                                    # same object, new version: the cache no longer applies
+    assert hip._cached_queries(q) is None
+    with torch.no_grad():
+        ref = dec(q.half(), lats[0].float())
+    assert (hip(q, lats[0]).float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 2e-3
+    # grid_queries: latent2sdf's way in -- one fp16-rounded device copy and one cache per grid tensor
+    xyz = (torch.rand(3000, 3, generator=g) * 2.2 - 1.1)
+    q1 = hip.grid_queries(xyz)
+    assert hip.grid_queries(xyz) is q1 and hip._cached_queries(q1) is not None
+    assert torch.equal(q1.reshape(-1, 3).cpu(), xyz.half().float())
+    hip.query_cache_limit = 1000                   # a grid whose cache would not fit: decoded without one
+    q2 = hip.grid_queries(xyz.clone())
+    assert hip._cached_queries(q2) is None and torch.equal(hip(q2, lats[0]), hip(q1.clone(), lats[0]))
+
+
+@gpu
+def test_full_grid_forward_and_backward_against_fp32_torch_and_sparse_against_dense():
+    """The Hunyuan3D-2 shape on the whole 65^3 grid (274 625 queries, 3072 x 1024 tokens, 16 heads, hidden 4096):
+    (a) forward and dense backward against the float32 torch module (autograd chunk by chunk, PL:298-308's chunks of 8000);
+    (b) with the gradient the guidance loop really produces -- dL/dSDF out of the FlexiCubes backward (PL:1507-1509, 1600), non-zero at
+        the end points of the crossed grid edges only -- the active-row backward against the dense one and against fp32 autograd."""
+    from followmyhold_amd import ops
+    from followmyhold_amd.facade import generate_dense_grid_points
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(1024, 16, 3072)
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 3072, 1024, generator=g).half().cuda()
+    xyz_np, gsz, _ = generate_dense_grid_points(np.full(3, -1.10), np.full(3, 1.10), octree_depth=5, octree_resolution=64, indexing="ij")
+    xyz = torch.as_tensor(xyz_np, dtype=torch.float32, device="cuda")
+    N = xyz.shape[0]
+    assert N == 65 ** 3
+    hip = HipGeoDecoder.from_module(dec)
+    q = hip.grid_queries(xyz)
+
+    def torch_fwd_bwd(go):
+        lat_r = lat.float().requires_grad_(True)
+        outs = []
+        for s0 in range(0, N, 8000):
+            o = dec(q[:, s0:s0 + 8000].half(), lat_r)
+            (o.reshape(-1) * go[s0:s0 + 8000]).sum().backward()
+            outs.append(o.detach().reshape(-1))
+        return torch.cat(outs), lat_r.grad
+
+    def hip_grad(go, mode):
+        hip.backward_mode = mode
+        lat_h = lat.clone().requires_grad_(True)
+        out = hip(q, lat_h)
+        (out.float().reshape(-1) * go).sum().backward()
+        return out.detach().float().reshape(-1), lat_h.grad.float()
+
+    # (a) dense random gradient
+    go = torch.randn(N, generator=g).cuda()
+    ref, gref = torch_fwd_bwd(go)
+    out, gh = hip_grad(go, "keep")
+    learned = (ref - (dec.radius - q.reshape(-1, 3).norm(dim=-1)) * dec.sharpness) / dec.gain
+    assert (out - ref).abs().max().item() <= 2.5e-3 * max(learned.abs().max().item(), 1.0) * dec.gain + 1e-3 * ref.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(gh.flatten(), gref.flatten(), dim=0).item()
+    assert (gh - gref).abs().max().item() <= 1e-2 * gref.abs().max().item() and cos >= 1 - 1e-4, ((gh - gref).abs().max().item(), gref.abs().max().item(), cos)
+    # (b) the gradient of the loop: SDF = -logits -> FlexiCubes -> a loss on the vertices -> dL/dSDF
+    sdf = (-out).clone().requires_grad_(True)
+    verts, faces, _ = ops.flexicubes(xyz, sdf, 64)
+    assert verts.shape[0] > 1000
+    (verts * torch.randn(verts.shape, generator=g).cuda()).sum().backward()
+    go_s = -sdf.grad
+    n_act = int((go_s != 0).sum())
+    assert 0 < n_act < 0.2 * N                               # the surface touches a small part of the grid
+    _, g_rows = hip_grad(go_s, "rows")
+    assert hip.last_row_stats.cpu().tolist() == [n_act, 0]
+    _, g_dense = hip_grad(go_s, "recompute")
+    _, gref_s = torch_fwd_bwd(go_s)
+    sc = g_dense.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(g_rows.flatten().double(), g_dense.flatten().double(), dim=0).item()
+    assert (g_rows - g_dense).abs().max().item() <= 1e-3 * sc and cos >= 1 - 1e-6, ((g_rows - g_dense).abs().max().item(), sc, cos)
+    cos = torch.nn.functional.cosine_similarity(g_rows.flatten(), gref_s.flatten(), dim=0).item()
+    assert (g_rows - gref_s).abs().max().item() <= 1e-2 * gref_s.abs().max().item() and cos >= 1 - 1e-4
