@@ -11,7 +11,9 @@ vector at the end of the batch).
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Besides the contract's fields:
+Prints ONE JSON line on rank 0 (stdout): the contract's fields + `roofline` + `cpu_baseline` + `parity`, kept under 1 900 characters
+so that it survives whole in a log tail (`roofline.secondary` carries the headline numbers of the side records).  The DETAIL
+record -- everything below -- goes to stderr as one line prefixed `bench-detail: ` and to gpurun_out/bench_detail.json:
   roofline            the dominant kernel: algorithmic bytes per launch / hipEvent-timed duration on the launch stream
   kernels             every launch of the step the same way
   step_roofline_frac  SURVEY 8(d)'s B_step x steps/s / HBM peak;  step_traffic_frac: the MEASURED bytes per step;
@@ -433,7 +435,7 @@ def main():
         achieved = kb * ipb / (acc[dom] * 1e-3) / 1e9
         pmc, pmc_src = pmc_table(workload)
         ea, ea_src = ea_table(workload)
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "roof": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom),
                            "traffic_source": f"{pmc_src} (2*FETCH_SIZE+WRITE_SIZE, KiB)" if pmc_src else None,
                            "traffic_by_request_size": ea.get(dom), "traffic_by_request_size_source": ea_src,
@@ -450,6 +452,11 @@ def main():
             hb, vf = out["roofline"]["frac"], vr.get(dom, {}).get("valu_frac") or 0.0
             # what binds: neither roof is near at one image per launch -- the kernels wait (wait_frac) on chains of dependent
             # round trips; the record says so instead of letting "bound": "hbm" stand alone
+            # `bound` names what binds: at one image per launch neither roof does (the HBM figures are quoted against `roof`)
+            if hb < 0.25 and vf < 0.5:
+                out["roofline"]["bound"] = "latency"
+            elif vf >= 0.5:
+                out["roofline"]["bound"] = "valu-issue"
             out["roofline"]["binding"] = (f"latency: {dom} uses {hb:.3f} of the HBM roof and {vf:.3f} of the VALU-issue roof, "
                                           f"its waves wait {vr.get(dom, {}).get('wait_frac') or 0:.2f} of their life (SQ_WAIT_ANY)")
         out["kernel_ms"] = {k: round(v, 5) for k, v in acc.items()}
@@ -479,6 +486,8 @@ def main():
                             ("closeup", lambda: closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("geo_decode", lambda: geo_decode_record(torch, dev)),
+                            ("icp", lambda: icp_record(torch, np, dev)),
+                            ("lbs", lambda: lbs_record(torch, np, synthetic, dev)),
                             ("pipeline_iteration", lambda: pipeline_iteration_record(E, torch, scenes[0], dev)),
                             ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
                             ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
@@ -491,10 +500,99 @@ def main():
             out["cpu_baseline"] = base
             out["parity"] = parity_record(E, torch, np, scenes[0], dev, first)
             out["cpu_baseline_1t"] = cpu_baseline(scenes[0], 5, threads=1, budget_s=20.0)[0]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _r(x, nd=4):
+    return None if x is None else float(f"{float(x):.{nd}g}")
+
+
+def headline(out):
+    """The ONE stdout line: the contract's fields, `roofline` (the dominant kernel + `secondary`: the side records' headline numbers),
+    `cpu_baseline`, `parity` -- short enough (< 1 900 characters) to survive in a 2 000-character log tail."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    line["value"], line["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 5)
+    c = out["config"]
+    line["config"] = {"workload": "configs[1]: 512x512 frame/GPU, 778-vert hand + 10242-vert/20480-face object, joint step (phase C)"
+                      if "10242-vert/20480-face" in c["workload"] and "512x512" in c["workload"] else c["workload"],
+                      "images_per_gpu": c["images_per_gpu"], "global_images": c["global_images"], "parallelism": c["parallelism"],
+                      "steps_per_graph": c["steps_per_graph"]}
+    line["repeats"], line["rccl_ranks"] = out.get("repeats"), out.get("rccl_ranks")
+    rf = out.get("roofline")
+    if rf:
+        r2 = {k: rf.get(k) for k in ("bound", "roof", "kernel", "unit")}
+        r2.update(achieved=_r(rf["achieved"]), peak=rf["peak"], frac=_r(rf["frac"]), traffic=rf.get("traffic"), kernel_us=_r(rf["kernel_ms"] * 1e3),
+                  alg_bytes=rf.get("algorithmic_bytes_per_launch"))
+        if "roofline_valu" in out:
+            r2["valu_frac"] = _r(out["roofline_valu"].get("frac"), 3)
+        sec = {}
+        def get(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        g = out.get("geo_decode") or {}
+        if "fwd_ms" in g:
+            sec["geo_decode"] = {"fwd_ms": _r(g["fwd_ms"]), "mfma_frac": _r(get(g, "roofline", "frac"), 3), "fwd_bwd_rows_ms": _r(g.get("fwd_bwd_rows_ms")),
+                                 "fwd_bwd_dense_ms": _r(g.get("fwd_bwd_ms"))}
+        pi = out.get("pipeline_iteration") or {}
+        if "hip_decoder" in pi:
+            sec["pipeline_iteration"] = {"ms": _r(get(pi, "hip_decoder", "iteration_ms")), "bwd_ms": _r(get(pi, "hip_decoder", "backward_ms")),
+                                         "torch_ms": _r(get(pi, "torch_decoder", "iteration_ms")), "active_rows": _r(pi.get("active_row_frac"), 3)}
+        cu = out.get("closeup") or {}
+        if "one_image" in cu:
+            sec["closeup"] = {"b1": _r(get(cu, "one_image", "value")), "b32": _r(get(cu, "in_flight_32", "value"))}
+        if "value" in (out.get("batched") or {}):
+            sec["batched_b8"] = _r(out["batched"]["value"])
+        if "value" in (out.get("obj_40k") or {}):
+            sec["obj_40k"] = _r(out["obj_40k"]["value"])
+        if "ms_per_step" in (out.get("topology_changing") or {}):
+            sec["topology_ms"] = _r(out["topology_changing"]["ms_per_step"])
+        jb = out.get("job") or {}
+        if "in_flight_16" in jb:
+            sec["job_img_s"] = {k.replace("in_flight_", "f"): _r(v["images_per_s"], 3) for k, v in jb.items() if k.startswith("in_flight_")}
+        if "images_per_s" in (out.get("driver_on_files") or {}):
+            sec["driver_img_s"] = _r(out["driver_on_files"]["images_per_s"], 3)
+        ic = out.get("icp") or {}
+        if "hip_ms" in ic:
+            sec["icp"] = {"ms": _r(ic["hip_ms"]), "cpu_ms": _r(ic.get("cpu_ms_extrapolated"))}
+        lb = out.get("lbs") or {}
+        if "b8192" in lb:
+            sec["lbs"] = {"b1_us": _r(get(lb, "b1", "fwd_bwd_us")), "b8192_frac": _r(get(lb, "b8192", "poseblend_frac_of_fp32_matrix_peak"), 3)}
+        for k in ("geo_decode", "pipeline_iteration", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs"):
+            if isinstance(out.get(k), dict) and "error" in out[k]:
+                sec[k] = {"error": out[k]["error"][:60]}
+        if sec:
+            r2["secondary"] = sec
+        line["roofline"] = r2
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"].split(" of the same")[0] + " of the same scene, oracle/step_ref.py"}
+        if "cpu_baseline_1t" in out:
+            line["cpu_baseline"]["value_1_thread"] = _r(out["cpu_baseline_1t"]["value"])
+    pr = out.get("parity")
+    if pr:
+        line["parity"] = {"loss_rel_err": _r(pr["loss_rel_err_vs_oracle"], 2), "p2f_mismatch": pr["pix_to_face_mismatch"]}
+    return line
+
+
+def emit(out):
+    """Detail record -> stderr (one line) and gpurun_out/bench_detail.json; headline -> stdout, the contract's ONE JSON line."""
+    detail = json.dumps(out)
+    print("bench-detail: " + detail, file=sys.stderr, flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail.json"), "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    line = json.dumps(headline(out), separators=(",", ":"))
+    print(line, flush=True)
 
 
 def spawn_ranks(n):
@@ -623,17 +721,27 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     flop_q = 2 * 64 * W + 2 * W * W + 4 * NL * W + 2 * W * W + 4 * W * F + 2 * W
     flops = n * flop_q + NL * (2 * W * 2 * W)
     hip = HipGeoDecoder.from_module(dec, device=dev)
-    q32 = xyz.half().float().unsqueeze(0)
-    out = hip(q32, lat)
-    torch.cuda.synchronize(dev)
-    ts = []
-    for _ in range(reps):
-        hip._prepared = None                       # K / V projection of the tokens is part of every decode
-        t0 = time.perf_counter()
-        out = hip(q32, lat)
+    q_plain = xyz.half().float().unsqueeze(0)
+
+    def time_fwd(q):
+        out_ = hip(q, lat)
         torch.cuda.synchronize(dev)
-        ts.append(time.perf_counter() - t0)
-    t_hip = min(ts)
+        ts_ = []
+        for _ in range(reps):
+            hip._prepared = None                   # K / V projection of the tokens is part of every decode
+            t0_ = time.perf_counter()
+            out_ = hip(q, lat)
+            torch.cuda.synchronize(dev)
+            ts_.append(time.perf_counter() - t0_)
+        return min(ts_), out_
+
+    t_plain, out_plain = time_fwd(q_plain)         # foho_geo_decode_fwd: the whole chain
+    # what latent2sdf runs: the grid's latent-independent half (embedding -> query_proj -> ln_1 -> c_q) cached once per grid
+    # (foho_geo_prepare_queries, PL:1125-1143: the same 65^3 points for every decode) -- same kernels, logits bitwise equal
+    q32 = hip.grid_queries(xyz)
+    t_hip, out = time_fwd(q32)
+    cached_equal = bool(torch.equal(out, out_plain))
+    flops_cached = flops - n * (2 * 64 * W + 2 * W * W)
     dech = vae.geo_decoder.half()
     def torch_decode():
         outs = []
@@ -654,6 +762,7 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     # forward + backward to the latent tokens (the decodes of PL:1391-1393 / 1507-1509): foho_geo_decode_fwd + foho_geo_decode_bwd
     # (which recomputes the chain) beside torch autograd through the same 35 chunks
     go = torch.randn(1, n, 1, device=dev)
+    hip.backward_mode = "keep"                     # a DENSE gradient's fastest route: activations kept (18 KB per query)
     def hip_fb():
         l = lat.clone().requires_grad_(True)
         (hip(q32, l).float() * go).sum().backward()
@@ -678,11 +787,50 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     # activations are kept: nothing else is recomputed)
     flops_bwd = n * (4 * W * F + 2 * W * W + 8 * NL * W)
     gerr = (fb["hip"][1] - fb["torch"][1]).abs().max().item() / fb["torch"][1].abs().max().item()
+    # the gradient the guidance loop really sends back (PL:1507-1509, 1600): dL/dSDF out of the FlexiCubes backward, non-zero at the end
+    # points of the crossed grid edges only -> foho_geo_decode_bwd_rows (default route): rows compacted on the device, chain recomputed
+    # and back-propagated for them alone, nothing kept by the forward
+    from followmyhold_amd import ops as _ops
+    sdf = (-out.detach().float().reshape(-1)).clone().requires_grad_(True)
+    fv, ff, _ = _ops.flexicubes(xyz, sdf, res)
+    (fv * torch.randn_like(fv)).sum().backward()
+    go_s = (-sdf.grad).reshape(1, n, 1)
+    hip.backward_mode = "rows"
+    def hip_fb_rows():
+        l = lat.clone().requires_grad_(True)
+        (hip(q32, l).float() * go_s).sum().backward()
+        return l.grad
+    g_rows = hip_fb_rows()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        g_rows = hip_fb_rows()
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t_rows = min(ts)
+    row_stats = hip.last_row_stats.cpu().tolist()
+    hip.backward_mode = "keep"
+    l_ = lat.clone().requires_grad_(True)
+    (hip(q32, l_).float() * go_s).sum().backward()
+    rows_vs_dense = (g_rows.float() - l_.grad.float()).abs().max().item() / max(l_.grad.float().abs().max().item(), 1e-30)
+    hip.set_kv(hip.kv_of(lat).detach())
+    hip.decode_bwd_rows(q32, go_s)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        hip.decode_bwd_rows(q32, go_s)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t_rows_bwd = min(ts)
     # the same decode with the module laid out like hy3dgen's CrossAttentionDecoder as the released ShapeVAE configures it
     # (bias-free c_q / c_kv with K and V interleaved per head, qk_norm: LayerNorm over the head dimension of q and k, no prior)
     torch.manual_seed(1)
     dech3 = standins.Hy3dgenLayoutDecoder(W, NH, qk_norm=True).to(dev).eval()
     hip3 = HipGeoDecoder.from_module(dech3, device=dev)
+    hip3.backward_mode = "keep"
+    hip3.prepare_queries(q32)
     def hip3_f():
         hip3._prepared = None
         with torch.no_grad():
@@ -707,15 +855,19 @@ def geo_decode_record(torch, dev, res=64, reps=5):
     h3["logit_scale"] = r3.float().abs().max().item()
     del hip3, dech3, r3
     pipes, pipes_src = geo_pipe_busy()
-    return {"hy3dgen_layout_qk_norm": h3, "pipe_busy_by_kernel": pipes, "pipe_busy_source": pipes_src, "fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
+    return {"fwd_uncached_ms": t_plain * 1e3, "cached_logits_bitwise_equal": cached_equal,
+            "fwd_bwd_rows_ms": t_rows * 1e3, "bwd_rows_ms": t_rows_bwd * 1e3, "active_rows": row_stats[0], "active_row_frac": row_stats[0] / n,
+            "rows_dropped": row_stats[1], "rows_vs_dense_grad_rel_diff": rows_vs_dense, "surface_faces": int(ff.shape[0]),
+            "hy3dgen_layout_qk_norm": h3, "pipe_busy_by_kernel": pipes, "pipe_busy_source": pipes_src, "fwd_bwd_ms": fb["hip"][0] * 1e3, "torch_fwd_bwd_ms": fb["torch"][0] * 1e3, "fwd_bwd_speedup_vs_torch": fb["torch"][0] / fb["hip"][0],
             "fwd_bwd_tflops": (flops + flops_bwd) / fb["hip"][0] / 1e12, "grad_rel_diff_vs_torch_fp16": gerr,
             "queries": n, "latent_tokens": NL, "width": W, "heads": NH, "hidden": F, "dtype": "f16 (fp32 accumulate)",
-            "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops / 1e12,
-            "tflops": flops / t_hip / 1e12, "roofline": {"bound": "mfma", "achieved": flops / t_hip / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                                                          "frac": flops / t_hip / 1e12 / 2500.0},
+            "fwd_ms": t_hip * 1e3, "torch_fwd_ms": t_torch * 1e3, "speedup_vs_torch": t_torch / t_hip, "tflop": flops_cached / 1e12,
+            "tflop_uncached": flops / 1e12, "tflops": flops_cached / t_hip / 1e12, "tflops_uncached": flops / t_plain / 1e12,
+            # the flops the cached forward EXECUTES (the query side's 2.3 MFLOP per row are not counted) over its duration
+            "roofline": {"bound": "mfma", "achieved": flops_cached / t_hip / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops_cached / t_hip / 1e12 / 2500.0},
             "max_abs_diff_vs_torch_fp16": err, "logit_scale": ref.float().abs().max().item(),
-            "backward": "foho_geo_decode_fwd_keep + foho_geo_decode_bwd: gradient to K / V of the latent tokens from kept activations "
-                        "(18 KB per query), no atomics"}
+            "backward": "fwd_bwd_ms: dense random gradient, foho_geo_decode_fwd_keep + foho_geo_decode_bwd (kept activations, 18 KB per query); "
+                        "fwd_bwd_rows_ms: the FlexiCubes gradient, foho_geo_decode_fwd_cached + foho_geo_decode_bwd_rows (active rows only, nothing kept); no atomics"}
 
 
 def obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg, steps=1000):
@@ -773,7 +925,8 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     geometry decoder on the 65^3 grid (`latent2sdf`) -> FlexiCubes -> new object installed -> fused guidance step -> backward
     through all of it to the noise prediction.  Stand-in networks of the Hunyuan3D-2 shape (3072 x 64 latents, width 1024, 16
     heads, 16 transformer layers, fp16; random weights -- no checkpoint on this box); the geometry decoder once as the torch
-    module in the reference's 35 chunks of 8000 queries, once through `geo_decode.install` (foho_geo_decode_fwd_keep / _bwd)."""
+    module in the reference's 35 chunks of 8000 queries, once through `geo_decode.install` (cached query side, foho_geo_decode_fwd_cached;
+    backward over the rows FlexiCubes sends a gradient to, foho_geo_decode_bwd_rows)."""
     import numpy as np
     from followmyhold_amd import geo_decode, pipeline as PLN, standins
     res = 64
@@ -815,6 +968,11 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         rec["grad_finite"] = bool(torch.isfinite(noise.grad).all())     # (fp16 leaf, random networks: its magnitude means nothing)
         out[name] = rec
     nv, nf, flags = obj.status()[0]
+    st_rows = vae.hip_geo.last_row_stats
+    if st_rows is not None:
+        out["active_rows"], out["rows_dropped"] = st_rows.cpu().tolist()
+        out["active_row_frac"] = out["active_rows"] / xyz.shape[0]
+    out["hip_decoder_backward_mode"] = vae.hip_geo.backward_mode
     out["faces"] = nf
     out["sdf_max_abs_diff_between_decoders"] = float((sdfs["torch_decoder"] - sdfs["hip_decoder"]).abs().max())
     out["sdf_abs_max"] = float(sdfs["torch_decoder"].abs().max())
@@ -822,6 +980,86 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     out["what"] = ("latent -> 16-layer VAE transformer (torch) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
                    "step -> backward to the noise prediction; stand-in networks of the Hunyuan3D-2 shape, fp16")
     return out
+
+
+def icp_record(torch, np, dev):
+    """the two-stage trimmed ICP with scale of `foho.alignment.h2m` at the reference's sizes (mesh_align.py:56-175,
+    h2m.py:12-21: coarse 50 iterations x 1000 source x 5000 target points, fine 100 x 5000 x 10000, 20 % outliers, scale in
+    [0.7, 3]) -- `foho_icp_run_batch`, device-resident float64 loop, one enqueue + one synchronisation per stage -- beside the numpy
+    restatement (oracle/icp_ref.py) timed on a bounded number of iterations of the same point sets."""
+    from followmyhold_amd import ops
+    from oracle import icp_ref
+    rng = np.random.default_rng(0)
+    def cloud(n):
+        p = rng.normal(size=(n, 3))
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        return p * np.array([1.0, 0.7, 0.5]) + 0.01 * rng.normal(size=(n, 3))
+    ang = 0.3
+    Rm = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    stages = {"coarse": (50, 1000, 5000), "fine": (100, 5000, 10000)}
+    rec, tot, cpu_tot = {"unit": "ms", "outliers": 0.2, "stages": {}}, 0.0, 0.0
+    for name, (n_iter, ns, nt) in stages.items():
+        tgt = cloud(nt)
+        src = (cloud(ns) * 0.8) @ Rm.T + np.array([0.05, -0.02, 0.03])
+        n_out = int(0.2 * ns)
+        ops.icp_points(src, tgt, n_iter=n_iter, n_outliers=n_out, min_scale=0.7, max_scale=3.0)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            T, c = ops.icp_points(src, tgt, n_iter=n_iter, n_outliers=n_out, min_scale=0.7, max_scale=3.0)
+            ts.append(time.perf_counter() - t0)
+        k = 4 if name == "coarse" else 2                   # bounded CPU sample: k iterations, scaled to the stage's count
+        t0 = time.perf_counter()
+        icp_ref.icp_points(src, tgt, n_iter=k, outliers=0.2, min_scale=0.7, max_scale=3.0)
+        t_cpu = (time.perf_counter() - t0) / k * n_iter
+        Tr, cr = icp_ref.icp_points(src, tgt, n_iter=2, outliers=0.2, min_scale=0.7, max_scale=3.0)
+        T2, c2 = ops.icp_points(src, tgt, n_iter=2, n_outliers=n_out, min_scale=0.7, max_scale=3.0)
+        rec["stages"][name] = {"iterations": n_iter, "source_points": ns, "target_points": nt, "hip_ms": min(ts) * 1e3, "cpu_ms_extrapolated": t_cpu * 1e3,
+                               "cpu_iterations_timed": k, "final_cost": float(c), "max_abs_diff_vs_oracle_after_2_iterations": float(np.abs(T2 - Tr).max())}
+        tot += min(ts)
+        cpu_tot += t_cpu
+    rec.update(hip_ms=tot * 1e3, cpu_ms_extrapolated=cpu_tot * 1e3, what="foho_icp_run_batch (float64, device-resident loop incl. upload and read-back) vs oracle/icp_ref.py (numpy, 1 process)")
+    return rec
+
+
+def lbs_record(torch, np, synthetic, dev):
+    """MANO linear blend skinning forward + backward (`foho_lbs_fwd/_bwd`) at the batch the pipeline uses (one hand) and
+    at batches where the pose-blend contraction (B x 135) . (135 x 2334) runs on `v_mfma_f32_16x16x4_f32`; the contraction's rate is
+    quoted against the dense fp32 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- negligible work at the pipeline's size, as
+    SURVEY 8(d) expects."""
+    from followmyhold_amd import ops
+    model = ops.LbsModel(synthetic.mano_like_model(1), device=dev)
+    rec = {"unit": "us", "verts": model.V}
+    for B in (1, 64, 1024, 8192):
+        betas = torch.randn(B, 10, device=dev).requires_grad_(True)
+        rot = torch.eye(3, device=dev).expand(B, 16, 3, 3).contiguous() + 0.05 * torch.randn(B, 16, 3, 3, device=dev)
+        rot.requires_grad_(True)
+        gv = torch.randn(B, model.V, 3, device=dev)
+        def fwd():
+            with torch.no_grad():
+                return ops.lbs(betas, rot, model, use_mfma=1 if B >= 16 else 0)
+        def fb():
+            betas.grad = rot.grad = None
+            v, j = ops.lbs(betas, rot, model, use_mfma=1 if B >= 16 else 0)
+            (v * gv).sum().backward()
+        out = {}
+        for name, fn in (("fwd_us", fwd), ("fwd_bwd_us", fb)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(dev)
+            out[name] = (time.perf_counter() - t0) / 20 * 1e6
+        out["hands_per_s_fwd"] = B / (out["fwd_us"] * 1e-6)
+        out["poseblend_tflops_if_forward_were_only_that"] = 2 * B * 136 * 2336 / (out["fwd_us"] * 1e-6) / 1e12
+        out["poseblend_frac_of_fp32_matrix_peak"] = out["poseblend_tflops_if_forward_were_only_that"] / 157.3
+        rec[f"b{B}"] = out
+    rec["note"] = ("fwd_us is the WHOLE forward (shape blend, joints, pose blend, kinematic chain, skinning; host wall clock over 20 calls), so the "
+                   "pose-blend rate is a lower bound; the kernel alone reached 59 TFLOP/s = 0.38 at B = 8192 under rocprofv3 (profiles/r01_lbs_mfma.md)")
+    return rec
 
 
 def topology_record(E, torch, scene, dev, steps=200):

@@ -18,6 +18,13 @@ def _line(stdout):
     return json.loads(lines[0])
 
 
+def _detail(text):
+    """The detail record bench.py writes to stderr beside the headline line."""
+    lines = [l for l in text.splitlines() if l.startswith("bench-detail: ")]
+    assert len(lines) == 1, text[-3000:]
+    return json.loads(lines[0][len("bench-detail: "):])
+
+
 def _env(**kw):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **kw)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -35,12 +42,15 @@ def test_bench_line_n1_and_two_ranks_gloo():
                         stderr=subprocess.PIPE, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-3000:]
     o1 = _line(r1.stdout)
+    assert len(r1.stdout.strip().splitlines()[-1]) < 1900          # the ONE line survives whole in a 2000-character log tail
+    assert o1["roofline"]["bound"] in ("latency", "hbm", "valu-issue") and o1["roofline"]["roof"] == "hbm" and o1["config"]["global_images"] == 1
+    o1 = _detail(r1.stderr)
     assert o1["n_gpus"] == 1 and o1["steps"] == 20 and o1["warmup"] == 5 and o1["scaling"] == "weak"
     assert o1["config"]["global_images"] == 1 and o1["higher_is_better"] is True and o1["vs_baseline"] is None
     assert o1["repeats"] >= 2 and o1["repeats"] * 20 * o1["ms_per_step"] * 1e-3 > 0.1     # short regions are repeated
     assert abs(o1["value"] - 1e3 / o1["ms_per_step"]) <= 1e-6 * o1["value"]
     rf = o1["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel"] in o1["kernels"]
+    assert rf["roof"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel"] in o1["kernels"]
     assert rf["kernel"] == max(o1["kernel_ms_median"], key=o1["kernel_ms_median"].get)     # chosen live
     assert o1["metrics"]["n_images"] == 1 and o1["nan_images"] == 0
 
@@ -50,6 +60,8 @@ def test_bench_line_n1_and_two_ranks_gloo():
                         text=True, timeout=900)
     assert r2.returncode == 0, r2.stdout[-4000:]
     o2 = _line(r2.stdout)
+    assert o2["n_gpus"] == 2 and o2["config"]["global_images"] == 2 and o2["rccl_ranks"] == 2
+    o2 = _detail(r2.stdout)
     assert o2["n_gpus"] == 2 and o2["config"]["global_images"] == 2 and o2["config"]["images_per_gpu"] == 1
     assert o2["steps"] == 20 and o2["scaling"] == "weak" and o2["metric"] == o1["metric"] and o2["unit"] == o1["unit"]
     assert abs(o2["value"] - 2 * 1e3 / o2["ms_per_step"]) <= 1e-6 * o2["value"]            # whole-job aggregate
@@ -69,7 +81,8 @@ def test_bench_line_n1_and_two_ranks_gloo():
     r3 = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + flags, env=_env(FOHO_BENCH_BACKEND="gloo"), cwd=ROOT,
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r3.returncode == 0, r3.stdout[-4000:]
-    o3 = _line(r3.stdout)
+    o3 = _detail(r3.stdout)
+    assert _line(r3.stdout)["n_gpus"] == 2
     assert o3["n_gpus"] == 2 and o3["rccl_ranks"] == 2 and o3["config"]["global_images"] == 2
     assert abs(o3["value"] - 2 * 1e3 / o3["ms_per_step"]) <= 1e-6 * o3["value"]
     assert o1["value"] <= 2.0 * o3["value"] and o3["value"] <= 4.0 * o1["value"], (o1["value"], o3["value"])
@@ -110,6 +123,44 @@ def test_bench_rccl_branch_runs_with_one_rank():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + flags, env=_env(FOHO_BENCH_FORCE_DIST="1"), cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    o = _line(r.stdout)
+    assert _line(r.stdout)["rccl_ranks"] == 1
+    o = _detail(r.stderr)
     assert o["n_gpus"] == 1 and o["rccl_ranks"] == 1 and o["collective_backend"] == "nccl"
     assert o["metrics"]["n_images"] == 1 and o["nan_images"] == 0 and o["value"] > 0
+
+
+def test_headline_line_stays_under_the_log_tail_with_every_side_record_present():
+    """bench.headline(): the stdout line carries the contract's fields, `roofline` (+ `secondary`: the side records' headline
+    numbers), `cpu_baseline` and `parity` in under 1 900 characters whatever the side records hold (no GPU needed)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    big = 123456.789012345
+    out = {"metric": "guidance-steps/sec (512x512, 778+20k verts)", "value": big, "unit": "guidance-steps/s", "n_gpus": 8, "steps": 2000, "warmup": 100,
+           "ms_per_step": 0.0549312345, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "repeats": 200,
+           "rccl_ranks": 8,
+           "config": {"workload": "configs[1]: single 512x512 synthetic frame per GPU, 778-vert hand + 10242-vert/20480-face object, joint guidance step (phase C)",
+                      "images_per_gpu": 1, "global_images": 8, "parallelism": "image-sharded x8", "hip_graph": True, "steps_per_graph": 50, "streams": 1, "restart_every": 50},
+           "roofline": {"bound": "latency", "roof": "hbm", "kernel": "k_pix_bwd", "achieved": 245.678912, "peak": 8000.0, "unit": "GB/s", "frac": 0.0307123, "traffic": 7100123.4,
+                        "kernel_ms": 0.0115471, "algorithmic_bytes_per_launch": 2836864, "binding": "x" * 300},
+           "roofline_valu": {"frac": 0.234567, "kernels": {"k": {"a": 1}}},
+           "geo_decode": {"fwd_ms": 9.3123, "roofline": {"frac": 0.39812}, "fwd_bwd_rows_ms": 11.3123, "fwd_bwd_ms": 24.6123},
+           "pipeline_iteration": {"hip_decoder": {"iteration_ms": 31.5123, "backward_ms": 14.2123}, "torch_decoder": {"iteration_ms": 116.123}, "active_row_frac": 0.04641},
+           "closeup": {"one_image": {"value": 10712.34}, "in_flight_32": {"value": 43123.4}}, "batched": {"value": 74812.3}, "obj_40k": {"value": 14512.3},
+           "topology_changing": {"ms_per_step": 0.14212}, "job": {f"in_flight_{k}": {"images_per_s": 200.123} for k in (1, 8, 16, 32)},
+           "driver_on_files": {"images_per_s": 112.345}, "icp": {"hip_ms": 74.123, "cpu_ms_extrapolated": 51234.5},
+           "lbs": {"b1": {"fwd_bwd_us": 61.234}, "b8192": {"poseblend_frac_of_fp32_matrix_peak": 0.3812}},
+           "cpu_baseline": {"value": 2.2812345, "unit": "guidance-steps/s", "cores": 32, "kind": "port",
+                            "sample": "30 joint steps (after 1 warm-up) of the same 512x512 / 20k-face scene, oracle/step_ref.py with OpenMP C rasteriser + torch CPU autograd, 32 thread(s)"},
+           "cpu_baseline_1t": {"value": 0.2012345}, "parity": {"loss_rel_err_vs_oracle": 1.2345e-7, "pix_to_face_mismatch": 0}}
+    line = json.dumps(bench.headline(out), separators=(",", ":"))
+    assert len(line) < 1900, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert set(back["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "secondary"}
+    assert set(back["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    # a side record that failed is named, not dropped
+    out["closeup"] = {"error": "FohoError: " + "y" * 500}
+    line = json.dumps(bench.headline(out), separators=(",", ":"))
+    assert len(line) < 1900 and "error" in json.loads(line)["roofline"]["secondary"]["closeup"]

@@ -307,14 +307,32 @@ def test_config2_eight_frames_per_gpu_full_size():
             assert np.array_equal(g2.region("p2f", torch.int32, (2, g2.B, P))[:, j].cpu().numpy(), p2f[:, b])
 
 
+def _f64_vertex_gradient(sct, p_k, aux, edges):
+    """The referee of a float32-vs-float32 disagreement: d total / d obj_verts of the joint step with the oracle's differentiable
+    part in FLOAT64, on the fragment selection of the float32 run (the C rasteriser's face ids / K-buffers are injected, so all
+    three sides differentiate the same fragments)."""
+    sc64 = {k: (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v) for k, v in sct.items()}
+    sels = [aux["hand"]["render"]["sel"], aux["render"]["sel"]]          # the order phase_c_loss asks for them
+    real = R.rasterize_select
+    R.rasterize_select = lambda *a, **kw: sels.pop(0)
+    try:
+        p64 = S.leafify({kk: v.double() for kk, v in p_k.items()}, S.PARAM_KEYS)
+        ov64 = sc64["obj_verts"].detach().clone().requires_grad_(True)
+        t64, _, _ = S.phase_c_loss(sc64, p64, ov64, edges, 19, 20, grid_res=64)
+        t64.backward()
+    finally:
+        R.rasterize_select = real
+    return ov64.grad.numpy()
+
+
 def _teacher_forced_joint_steps(E, sc, n_steps, max_flipped, max_conditioned=0, gv_outliers=0):
     """n_steps joint guidance steps of scene `sc`, HIP against the oracle with torch.optim.AdamW, TEACHER-FORCED: before every
     step the HIP path is given the oracle's parameters and optimiser moments, then both take the step.  At EVERY step: face
     ids of both renders bit-exact, flags clear; loss 1e-5, parameter gradients 1e-4, vertex gradients 2e-4, updated
     parameters 5e-6 -- on a step that holds a silhouette pixel on the BCE clamp (_clamp_flips) that pixel's own BCE value is
     replaced by the oracle's and everything is compared (_check_clamp_flip_step); with gv_outliers > 0 a step may exceed the
-    vertex-gradient tolerance on that many vertices (each within 1e-2 of its own gradient, everything else within 2e-4;
-    max_conditioned such steps)."""
+    vertex-gradient tolerance on that many vertices when a float64 run of the oracle says that the float32 ORACLE is the side
+    that is off there (max_conditioned such steps; see the comment at the assertion)."""
     sct = _t(sc)
     st = S.JointStepper(sct, S.make_params(), denoise_i=19, grid_res=64)
     gb = E.GuidanceBatch([sc])
@@ -348,22 +366,26 @@ def _teacher_forced_joint_steps(E, sc, n_steps, max_flipped, max_conditioned=0, 
         e_g, e_gv = rel(g, gref), rel(gb.grad_obj_verts(0).cpu().numpy(), grads["obj_verts"].numpy())
         if e_gv > 2e-4 and gv_outliers > 0:
             # Crop frames late in the loop: |grad obj_verts| has fallen from 1e5 to a few units and is carried by a handful of
-            # vertices; on up to `gv_outliers` of them the two implementations differ by a few 1e-4 of the vertex's own
-            # gradient (measured 1.1e-4 .. 1.4e-3 of the whole vector, up to 5e-3 of a single vertex's).  Two of them are the
-            # vertices that attain the object's bounding box in one axis: they receive half of the gradient of the similarity
-            # transform's CENTRE each (PL:111), (I - s R)^T sum_i g_i -- a sum over 10 k vertex gradients that cancel at
-            # convergence, times a matrix of norm ~0.02, i.e. float32 summation order at the 1e-3 level in EITHER
-            # implementation; the others carry the normal term's largest gradients (scripts/diag_closeup_terms.py; the sums
-            # through the normalisation extrema agree to 1e-8, scripts/diag_closeup_extrema.py) and are not understood further.
-            # Asserted: the excess IS confined to those vertices, and small on each of them.
+            # vertices; on 2-4 of them the two float32 implementations differ by up to 3e-3 of the vertex's own gradient.  Settled
+            # in round 5 with a float64 referee (scripts/diag_crop_grad_f64.py, NOTEBOOK round 5): the oracle's differentiable
+            # part in float64 on the same fragments puts the HIP path within 4e-4 of each such vertex's gradient and the float32
+            # torch-autograd ORACLE 5-100x further away -- the error is the oracle's, in the normal-alignment term
+            # (10 x normal_hoi: float32 autograd through normalize / cross / index_add on the vertices with the largest normal
+            # gradient), plus the two bounding-box extremum vertices that collect the similarity centre's gradient (PL:111).
+            # Asserted per such step: outside the outliers the float32 sides agree to 2e-4 as everywhere; ON each outlier the
+            # HIP path is within 1e-3 of the vertex's float64 gradient; and over the whole vector the HIP path is at least as
+            # close to float64 as the float32 oracle is.
             gh, gr = gb.grad_obj_verts(0).cpu().numpy().astype(np.float64), grads["obj_verts"].numpy().astype(np.float64)
+            g64 = _f64_vertex_gradient(sct, p_k, aux, st.edges)
             dv = np.linalg.norm(gh - gr, axis=1)
             worst_v = np.argsort(-dv)[:gv_outliers]
             keep = np.ones(len(dv), bool)
             keep[worst_v] = False
             assert np.linalg.norm((gh - gr)[keep]) <= 2e-4 * np.linalg.norm(gr), (k, e_gv, np.linalg.norm((gh - gr)[keep]) / np.linalg.norm(gr))
-            assert (dv[worst_v] <= 1e-2 * np.maximum(np.linalg.norm(gr[worst_v], axis=1), 1e-3 * np.linalg.norm(gr))).all(), (k, worst_v, dv[worst_v])
-            assert e_gv <= 2e-3, (k, e_gv)
+            d64 = np.linalg.norm((gh - g64)[worst_v], axis=1)
+            assert (d64 <= np.maximum(1e-3 * np.linalg.norm(g64[worst_v], axis=1), 2e-4 * np.linalg.norm(g64))).all(), (k, worst_v, d64)
+            assert np.linalg.norm(gh - g64) <= 1.02 * np.linalg.norm(gr - g64), (k, rel(gh, g64), rel(gr, g64))
+            assert e_gv <= 5e-3, (k, e_gv)
             conditioned += 1
             e_gv = 2e-4
         worst["grad"] = max(worst["grad"], e_g)
