@@ -459,7 +459,7 @@ def test_full_grid_forward_and_backward_against_fp32_torch_and_sparse_against_de
 
     def hip_grad(go, mode):
         hip.backward_mode = mode
-        lat_h = lat.clone().requires_grad_(True)
+        lat_h = lat.float().clone().requires_grad_(True)      # a float32 leaf: its gradient is not rounded to fp16 (the values are ~1e-5)
         out = hip(q, lat_h)
         (out.float().reshape(-1) * go).sum().backward()
         return out.detach().float().reshape(-1), lat_h.grad.float()
@@ -487,5 +487,11 @@ def test_full_grid_forward_and_backward_against_fp32_torch_and_sparse_against_de
     sc = g_dense.abs().max().item()
     cos = torch.nn.functional.cosine_similarity(g_rows.flatten().double(), g_dense.flatten().double(), dim=0).item()
     assert (g_rows - g_dense).abs().max().item() <= 1e-3 * sc and cos >= 1 - 1e-6, ((g_rows - g_dense).abs().max().item(), sc, cos)
+    # ... and the K / V gradients themselves (float32, what the two routes compute): same rows' contributions, another order of partial sums
+    hip.set_kv(hip.kv_of(lat).detach())
+    kv_rows, kv_dense = hip.decode_bwd_rows(q, go_s), hip.decode_bwd(q, go_s)
+    sc = kv_dense.abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(kv_rows.flatten().double(), kv_dense.flatten().double(), dim=0).item()
+    assert sc > 0 and (kv_rows - kv_dense).abs().max().item() <= 1e-3 * sc and cos >= 1 - 1e-6, ((kv_rows - kv_dense).abs().max().item(), sc, cos)
     cos = torch.nn.functional.cosine_similarity(g_rows.flatten(), gref_s.flatten(), dim=0).item()
     assert (g_rows - gref_s).abs().max().item() <= 1e-2 * gref_s.abs().max().item() and cos >= 1 - 1e-4

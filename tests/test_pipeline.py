@@ -209,7 +209,7 @@ def test_guided_pipeline_end_to_end_on_files(tmp_path, monkeypatch):
 @gpu
 def test_guided_pipeline_with_the_hip_geometry_decoder_in_the_loop(tmp_path):
     """The short schedule again with a ShapeVAE whose decoder the matrix-core kernels take (width 128, 2 heads, 128 latent tokens),
-    `geo_decode.install`-ed: every decode of the loop -- with autograd in phases B / C (foho_geo_decode_fwd_keep / _bwd), without for
+    `geo_decode.install`-ed: every decode of the loop -- with autograd in phases B / C (foho_geo_decode_fwd_cached / _bwd_rows), without for
     the per-step and final grids -- goes through the HIP decoder and the run completes like the one on the torch module: same
     iteration counts, finite closed surfaces, the object where the similarity puts it, and the latent's gradient doing something."""
     from PIL import Image
@@ -225,8 +225,8 @@ def test_guided_pipeline_with_the_hip_geometry_decoder_in_the_loop(tmp_path):
         pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1, **kw)
         if name == "hip":
             dec = geo_decode.install(pipe.vae)
-            calls = {"keep": 0, "fwd": 0, "bwd": 0}
-            for attr, key in (("decode_keep", "keep"), ("decode", "fwd"), ("decode_bwd", "bwd")):
+            calls = {"keep": 0, "fwd": 0, "bwd": 0, "rows": 0}
+            for attr, key in (("decode_keep", "keep"), ("decode", "fwd"), ("decode_bwd", "bwd"), ("decode_bwd_rows", "rows")):
                 fn = getattr(dec, attr)
                 setattr(dec, attr, (lambda f, k: (lambda *a, **b: (calls.__setitem__(k, calls[k] + 1), f(*a, **b))[1]))(fn, key))
 
@@ -245,8 +245,10 @@ def test_guided_pipeline_with_the_hip_geometry_decoder_in_the_loop(tmp_path):
         v0 = obj0.verts_packed()
         assert v0.shape != ov.shape or not torch.allclose(v0, ov, atol=1e-6)           # the gradient reached the latent
         out[name] = ov
-    # 3 + 2 x 2 latent iterations under autograd per run (two runs), each one kept forward + one backward; the no-gradient decodes besides
-    assert calls["keep"] == calls["bwd"] and calls["keep"] >= 7 and calls["fwd"] >= 5, calls
+    # 3 + 2 x 2 latent iterations under autograd per run (two runs), each one plain forward (cached query side) + one backward over the
+    # rows FlexiCubes sent a gradient to (the default route; nothing kept, no dense backward); the no-gradient decodes besides
+    assert calls["keep"] == calls["bwd"] == 0 and calls["rows"] >= 7 and calls["fwd"] >= calls["rows"] + 5, calls
+    assert dec._qcache is not None                                  # the guidance grid's query side was cached
     # same decoded object as with the torch decoder up to what a chaotic 17-iteration trajectory does to it
     assert abs(out["hip"].shape[0] - out["torch"].shape[0]) <= 0.2 * out["torch"].shape[0]
     assert (out["hip"].mean(0) - out["torch"].mean(0)).abs().max().item() < 0.05
