@@ -448,7 +448,10 @@ def run(project_root: str, cropped_obj_img_dir: str, mask_dir: str, moge_out_dir
                     aligned_mano_dir=aligned_mano_dir, guidance_out_dir=guidance_out_dir)
         if _mesh_level_batched():
             _run_batched(assigned_imgs, dirs, config, device)
-        elif _pipeline_batch_size() > 1 and len(assigned_imgs) > 1 and _networks_available() and _build_pipeline(device) is not None:
+        elif (_pipeline_batch_size() > 1 and len(assigned_imgs) > 1 and not os.environ.get("FOHO_DEBUG_DIR") and _networks_available()
+              and _build_pipeline(device) is not None):
+            # (FOHO_DEBUG_DIR: the per-image dumps -- losses.txt, params.json, per-step renders and meshes, PL:1076-1091, 1664-1675 --
+            # are `__call__`'s, so a debug run goes one image at a time like the reference)
             _run_pipeline_batched(assigned_imgs, dirs, config, device, _pipeline_batch_size())
         else:
             _run_one_by_one(assigned_imgs, dirs, config)
@@ -480,15 +483,15 @@ def _networks_available() -> bool:
 def _pipeline_batch_size() -> int:
     """Images per pass of the schedule when the networks are in the loop (GuidedShapePipeline.call_batch): FOHO_PIPELINE_BATCH,
     default 4; 1 = the reference's one image at a time (guid_config.py:9)."""
-    return max(1, int(os.environ.get("FOHO_PIPELINE_BATCH", "4")))
+    return max(1, int(os.environ.get("FOHO_PIPELINE_BATCH", "4")))      # (a set FOHO_DEBUG_DIR overrides it: see run())
 
 
 def _run_pipeline_batched(assigned_imgs, dirs, config, device, batch) -> None:
     """RUN:208-259 with the networks in the loop, `batch` images per pass of the 20-step schedule: DiT and ShapeVAE on `batch`
     latents, one capacity-mode GuidanceBatch of `batch` slots (GuidedShapePipeline.call_batch).  Skip rules, messages,
-    post-processing and the per-image error isolation are the one-image loop's; a group that leaves the batch's fast path
-    (BatchLeftFastPath: empty / non-manifold / over-capacity iso-surface, NaN loss) or fails as a whole is redone one
-    image at a time through run_hunyuan_w_guid."""
+    post-processing and the per-image error isolation are the one-image loop's; an image that leaves the batch (its entry of
+    call_batch's result is a BatchLeftFastPath: non-manifold / over-capacity iso-surface, NaN loss) is redone on its own through
+    run_hunyuan_w_guid while the rest of its group keeps the batched result; a group that fails as a whole is redone image by image."""
     import torch
     from followmyhold_amd.pipeline import BatchLeftFastPath
     pipeline = _build_pipeline(device)
@@ -526,10 +529,20 @@ def _run_pipeline_batched(assigned_imgs, dirs, config, device, batch) -> None:
         except Exception as e:  # noqa: BLE001 -- a failure of the whole pass must not cost the group its images
             print(f"Batch of {[p['index'] for _, p, _ in group]} failed as a whole ({e}); one image at a time")
             return [one(*g) for g in group]
-        _tally(sharding.local_metrics(pipeline.guidance_batch, n_steps=int(pipeline.stats["inner_iterations"]), wall_ms=0.0).cpu().numpy())
-        for (name, p, _), res in zip(group, out):
+        # the batch's images that stayed in it (an image that left is tallied by its own run below)
+        gbt = pipeline.guidance_batch
+        rows, fls = gbt.losses.detach().cpu().numpy(), gbt.flags.detach().cpu().numpy()
+        for b_, res in enumerate(out):
+            if not isinstance(res, BatchLeftFastPath):
+                _tally(np.asarray(sharding.image_metrics(rows[b_], int(fls[b_]), int(pipeline.stats["inner_iterations"])), np.float64))
+        for g, res in zip(group, out):
+            (name, p, _) = g
+            if isinstance(res, BatchLeftFastPath):
+                print(f"Image {p['index']} left the batched path ({res}); on its own")
+                one(*g)
+                continue
             try:
-                obj_mesh, hand_mesh = res       # None: no decode of this image ever gave a surface
+                obj_mesh, hand_mesh = res       # (None, hand): no decode of this image ever gave a surface
                 obj_mesh, hand_mesh = _postprocess_and_save(obj_mesh, hand_mesh, p["cropped_obj_img_path"], p["save_path_obj"], p["save_path_hand"])
                 print(f"Error in reconstruction for {p['index']}" if obj_mesh is None or hand_mesh is None else f"Reconstructed object {p['index']}")
             except Exception as e:  # noqa: BLE001

@@ -77,55 +77,7 @@ static thread_local ProfState* g_prof = nullptr;
         }                                                                                    \
     } while (0)
 
-// ------------------------------------------------------------------------------------------------
-// optional in-kernel time stamps (make STAMPS=1): DBG(i) stores the 100 MHz wall clock of thread 0 into slot i;
-// foho_debug_stamps() copies the 1024 slots to the host.  Compiled out of the production library.
-// ------------------------------------------------------------------------------------------------
-#ifdef FOHO_STAMPS
-__device__ unsigned long long g_dbg[1024];
-#define DBG(i)                                                  \
-    do {                                                        \
-        if (threadIdx.x == 0) g_dbg[i] = wall_clock64();        \
-    } while (0)
-#define DBGW(i)                                  \
-    do {                                         \
-        __builtin_amdgcn_s_waitcnt(0);           \
-        DBG(i);                                  \
-    } while (0)
-extern "C" void foho_debug_clear(void) {
-    static unsigned long long z[1024];
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z));
-}
-extern "C" void foho_debug_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 1024 * 8); }
-// KSPAN(k): device-side span of a launch -- every workgroup stores its own start / end stamp (plain stores, own slots);
-// foho_debug_spans() copies the table: [kernel][workgroup][2], KS_WG workgroups per kernel
-constexpr int KS_K = 6, KS_WG = 8192;
-__device__ unsigned long long g_span[KS_K * KS_WG * 2];
-struct KSpan {
-    unsigned long long* p;
-    __device__ __forceinline__ explicit KSpan(int k) {
-        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        p = &g_span[((size_t)k * KS_WG + (lin < KS_WG ? lin : KS_WG - 1)) * 2];
-        if (threadIdx.x == 0) p[0] = wall_clock64();
-    }
-    __device__ __forceinline__ ~KSpan() {
-        if (threadIdx.x == 0) p[1] = wall_clock64();
-    }
-};
-extern "C" void foho_debug_spans(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(g_span)); }
-extern "C" void foho_debug_spans_clear(void) { (void)hipMemset((void*)nullptr, 0, 0); void* d = nullptr; (void)hipGetSymbolAddress(&d, HIP_SYMBOL(g_span)); (void)hipMemset(d, 0, sizeof(g_span)); }
-#define KSPAN(k) KSpan kspan_(k)
-#else
-#define DBG(i) \
-    do {       \
-    } while (0)
-#define DBGW(i) \
-    do {        \
-    } while (0)
-#define KSPAN(k) \
-    do {         \
-    } while (0)
-#endif
+#include "foho_stamps.h"   // development instrumentation (time stamps, ablation switches): nothing in the product build
 
 // ------------------------------------------------------------------------------------------------
 // constants
@@ -222,10 +174,9 @@ static inline void raster_blocks(const foho_dims& d, int& rf_h, int& rf_o, int& 
     rf_h = std::max(2, raster_faces_per_block(Fh_max, d.B) / 2);
     if (hand_faces > 0) rf_h = std::max(RF_H_MIN, std::min(hand_faces, RF));  // foho_step_desc.hand_faces_per_block
     rf_o = raster_faces_per_block(Fo_max, d.B);
-#ifdef FOHO_STAMPS  // development build: faces per raster workgroup from the environment (sweeps)
-    if (const char* e = getenv("FOHO_DEBUG_RFH")) rf_h = std::max(1, std::min(atoi(e), RF));
-    if (const char* e = getenv("FOHO_DEBUG_RFO")) rf_o = std::max(1, std::min(atoi(e), RF));
-#endif
+    // development build: faces per raster workgroup from the environment (sweeps; foho_stamps.h)
+    if (const char* e = FOHO_DEV_ENV("FOHO_DEBUG_RFH")) rf_h = std::max(1, std::min(atoi(e), RF));
+    if (const char* e = FOHO_DEV_ENV("FOHO_DEBUG_RFO")) rf_o = std::max(1, std::min(atoi(e), RF));
     nRh = cdiv(Fh_max, rf_h);
     nRo = cdiv(Fo_max, rf_o);
 }

@@ -185,6 +185,15 @@ def morton_order(points):
 _WARMED_DEVICES = set()     # GPUs on which this process has launched the step once (GuidanceBatch.capture)
 
 
+def _same_regressor(jr, first_scene, b):
+    """A batch shares ONE joint regressor (foho_step_desc.J_regressor): an image that brings another one would silently be
+    regressed with the first image's."""
+    j0 = np.asarray(first_scene["J_regressor"], np.float32)
+    if jr.shape != j0.shape or not np.array_equal(jr, j0):
+        raise L.FohoError(f"GuidanceBatch: image {b} has a J_regressor that differs from image 0's; a batch shares one "
+                          "(put images of different hand models into different batches)")
+
+
 class GuidanceBatch:
     """Device-resident state of B guidance loops.
 
@@ -232,6 +241,7 @@ class GuidanceBatch:
             im.v_off, im.Vh, im.Vo, im.f_off, im.Fh, im.Fo = v_off, Vh, Vo, f_off, Fh, Fo
             im.n_edges = 0
             jr = np.asarray(s["J_regressor"], np.float32)
+            _same_regressor(jr, scenes[0], len(images))
             im.jcols = jr.shape[1]
             im.k00, im.k11 = fov_focal(float(s["fov"]))
             R = np.asarray(s.get("cam_R", np.diag([-1.0, 1.0, -1.0])), np.float32).reshape(-1)  # RUN:84-90
@@ -365,6 +375,7 @@ class GuidanceBatch:
             if n:
                 tab[b, :n] = morton_order(hv) - np.arange(n)
         self._hand_order = tab
+        self._desc = None                 # hand_order_valid / hand_faces_per_block are derived fields of the descriptor
         self._upload_hand_order()
 
     def _upload_hand_order(self):
@@ -543,8 +554,12 @@ class GuidanceBatch:
             up("tgt_disp", self.tgt_disp, per_image(lambda s: s["moge_disp"]))
         up("mask", self.mask, per_image(lambda s: np.asarray(s["hand_mask"]).astype(np.uint8) | (np.asarray(s["obj_mask"]).astype(np.uint8) << 1)))
         up("kps", self.kps_2d, per_image(lambda s: s["kps_2d"]))
-        # the joint regressor is shared by the batch (foho_step_desc.J_regressor): the new image set's, not the first set's
+        # the joint regressor is shared by the batch (foho_step_desc.J_regressor; MANO's is a constant of the hand model): the new
+        # image set's, not the first set's -- and one for all of its images, or the set is refused
+        for b, s in enumerate(scenes):
+            _same_regressor(np.asarray(s["J_regressor"], np.float32), scenes[0], b)
         up("J", self.J, put(np.asarray(scenes[0]["J_regressor"], np.float32)))
+        self._desc = None                 # the descriptor's derived fields (faces per raster workgroup: by field of view) follow the new set
         up("params", self.params, put(np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0] * 2, np.float32), (self.B, 1))))
         vh_max = max(int(self.dims.Vh_max), 1)
 
@@ -727,14 +742,18 @@ class GuidanceBatch:
         l = self.losses[b].detach().cpu().tolist()
         return dict(zip(L.LOSS_NAMES, l))
 
-    def raise_on_flags(self, strict_k=True):
+    def raise_on_flags(self, strict_k=True, ignore_images=()):
         """bit1: fractional-fragment list overflow; bit2: the K = 100 buffer of a pixel with 100 fractional-coverage fragments
         or more could not be re-built on the device (more than 1024 fragments on the pixel, or more than 32 such pixels in a
         render): the silhouette over all fragments may then differ from the reference's 100 nearest ones; bits 4-6: capacity
         mode (foho_object_update).  (Bit 3 is retired: faces across the near plane are clipped like pytorch3d clips them.)
         Fails loudly instead of deviating; strict_k=False downgrades bit2 to a warning (a collapsing object -- thousands
-        of sub-pixel faces on one pixel -- is outside any regime where the K=100 cut-off is meaningful)."""
+        of sub-pixel faces on one pixel -- is outside any regime where the K=100 cut-off is meaningful).  ignore_images: slots whose
+        flags the caller has dealt with (images that left a batch and stay frozen)."""
         f = self.flags.detach().cpu().numpy()
+        if len(ignore_images):
+            f = f.copy()
+            f[list(ignore_images)] = 0
         if (f & 2).any():
             raise L.FohoError("fractional-coverage fragment list overflowed: raise frac_cap")
         if (f & 16).any():
@@ -943,7 +962,9 @@ class _SdfObjectiveFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        gs = ctx.obj.grad_sdf * g.reshape(-1, 1)
+        g = g.reshape(-1, 1)
+        # an image whose upstream gradient is zero gets exact zeros (its dL/dSDF may hold a NaN: call_batch masks images that way)
+        gs = torch.where(g != 0, ctx.obj.grad_sdf * g, torch.zeros((), device=g.device))
         return gs.reshape(ctx.shape), None, None, None
 
 

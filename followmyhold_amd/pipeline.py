@@ -68,8 +68,13 @@ def _cat_recursive(*parts, dtype):
 
 
 class BatchLeftFastPath(RuntimeError):
-    """An image of a `call_batch` batch needs the per-image handling of `__call__` (empty / non-manifold / over-capacity
-    iso-surface, NaN loss)."""
+    """An image of a `call_batch` batch needs the per-image handling of `__call__` (a non-manifold or over-capacity iso-surface, a
+    NaN loss).  `call_batch` does not raise it: the image's entry of the result list IS an instance (with `.phase`, `.step`,
+    `.iteration`, `.flags`), the other images of the batch carry on, and the caller re-runs that image through `__call__`."""
+
+    def __init__(self, msg, phase=None, step=None, iteration=None, flags=0):
+        super().__init__(msg)
+        self.phase, self.step, self.iteration, self.flags = phase, step, iteration, flags
 
 
 class GuidedShapePipeline:
@@ -164,13 +169,17 @@ class GuidedShapePipeline:
         view in degrees (default: the renderer's camera for all, else each image's fov.json -- what RUN:228-230 hands to its
         camera).  All images must share H x W.  -> list of B (object Meshes, hand Meshes) in the MoGe world.
 
-        Raises BatchLeftFastPath when an image needs what only the one-image path offers -- an empty / non-manifold /
-        over-capacity iso-surface (PL:1394-1397, 1511-1513) or a NaN loss (PL:1442-1444, 1590-1592), whose handling is per
-        image in the reference: the caller re-runs the batch's images through `__call__`."""
+        Events the reference handles per image are handled per image here, too, with ONE read-back of the B flag words per
+        iteration (the reference's NaN test is one as well): an EMPTY iso-surface skips that image's iteration -- no optimiser
+        step for its noise prediction, none for its pose (PL:1394-1397, 1511-1513; `stats["skipped_empty"]`); an image whose
+        surface is not a closed manifold or exceeds the capacity, or whose loss is NaN (PL:1442-1444, 1590-1592), LEAVES the batch:
+        its slot is frozen, the other images carry on, and its entry of the result list is a `BatchLeftFastPath` instance -- the
+        caller re-runs that image through `__call__`, which handles all of these the reference's way."""
         B = len(images)
         device, dtype = self.device, self.dtype
         cfg0 = config() if config is not None else E.OptimizationConfig()
-        self.stats = stats = {"inner_iterations": 0, "images": B}
+        self.stats = stats = {"inner_iterations": 0, "images": B, "skipped_empty": 0}
+        left = {}                 # image -> BatchLeftFastPath: frozen slots
         do_cfg = guidance_scale >= 0 and not (getattr(self.model, "guidance_embed", False) is True)
         img, msk = self.prepare_image(list(images))
         cond = self.encode_cond(image=img, mask=msk, do_classifier_free_guidance=do_cfg, dual_guidance=False)
@@ -215,6 +224,9 @@ class GuidedShapePipeline:
             out = []
             hip = getattr(self.vae, "hip_geo", None)
             for b in range(x1.shape[0]):
+                if b in left:                # a frozen slot is not decoded any more (an all-positive field: no surface)
+                    out.append(torch.ones(xyz.shape[0], device=device))
+                    continue
                 if hip is not None:          # geo_decode.install(vae): all points in one call, gradients through foho_geo_decode_bwd
                     out.append(-hip(hip.grid_queries(xyz), pred[b:b + 1]).view(-1).float())
                     continue
@@ -222,25 +234,48 @@ class GuidedShapePipeline:
                 out.append(-torch.cat(logits, dim=1).view(-1).float())
             return torch.stack(out, 0)
 
+        LEAVE, EMPTY = 1 | 16 | 32, 64      # flag bits: NaN loss, capacity overflow, not a closed manifold | empty iso-surface
+
         def latent_phase(phase, iters, i, t, noise_pred, lr):
             cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
             gb.set_n_renders(n_renders)
             gb.reset_optimizer()
-            noise_pred = noise_pred.clone().detach().requires_grad_(True)
-            opt = torch.optim.AdamW([{"params": [noise_pred], "lr": lr}], eps=1e-4)
+            for b in left:                # reset_optimizer cleared the sticky bits: a slot that left stays frozen
+                gb.flags[b] |= 16
+            # one leaf and one parameter group per image: torch.optim.AdamW then keeps a step count per image and skips an image
+            # whose gradient is None -- the reference's `continue` in front of its optimiser step, image by image
+            noise = [noise_pred[b:b + 1].clone().detach().requires_grad_(True) for b in range(B)]
+            opt = torch.optim.AdamW([{"params": [n], "lr": lr} for n in noise], eps=1e-4)
             for k in range(int(iters)):
-                opt.zero_grad()
-                x1 = self.scheduler.step_final(noise_pred, t, latents)
+                opt.zero_grad(set_to_none=True)
+                x1 = self.scheduler.step_final(torch.cat(noise, 0), t, latents)
                 sdf = sdf_of(x1, xyz_samples, grid_size)
                 loss = fobj(sdf, cfg)                                   # (B,): one replay for all images
-                bad = [b for b, (_, _, fl) in enumerate(fobj.status()) if fl & (16 | 32 | 64)]
-                if bad or bool(torch.isnan(loss).any()):
-                    raise BatchLeftFastPath(f"phase {phase}, denoising step {i}, iteration {k}: images {bad or 'with a NaN loss'}")
-                loss.sum().backward()
+                fl = gb.flags.cpu().tolist()                            # the iteration's one read-back (NaN is bit 0 of the flags)
+                go = torch.zeros(B, device=device)
+                for b in range(B):
+                    if b in left:
+                        continue
+                    if fl[b] & LEAVE:
+                        what = "a NaN loss" if fl[b] & 1 else ("an iso-surface beyond the capacity" if fl[b] & 16 else "an iso-surface that is not a closed manifold")
+                        left[b] = BatchLeftFastPath(f"phase {phase}, denoising step {i}, iteration {k}: {what}", phase, i, k, fl[b])
+                        gb.flags[b] |= 16                               # frozen from here on (the step leaves flagged slots alone)
+                    elif fl[b] & EMPTY:
+                        print("Invalid mesh detected, aborting step!")  # PL:1396, 1512
+                        stats["skipped_empty"] += 1
+                        gb.flags[b] &= ~EMPTY
+                    else:
+                        go[b] = 1.0
+                if len(left) == B:
+                    break
+                (loss * go).sum().backward()         # _SdfObjectiveFn.backward returns exact zeros for go = 0 (also past a NaN)
+                for b in range(B):
+                    if go[b] == 0:
+                        noise[b].grad = None
                 opt.step()
                 stats["inner_iterations"] += 1
-            gb.raise_on_flags(strict_k=False)
-            return noise_pred.detach().clone()
+            gb.raise_on_flags(strict_k=False, ignore_images=list(left))
+            return torch.cat([n.detach() for n in noise], 0).clone()
 
         results = [None] * B
         for i, t in enumerate(timesteps):
@@ -266,6 +301,8 @@ class GuidedShapePipeline:
                         stats["inner_iterations"] += n
                         torch.cuda.synchronize(device)
                         gb.raise_on_flags(strict_k=False)
+                    elif len(left) == B:
+                        pass                                             # nobody left to optimise: the caller re-runs them all
                     elif i == cfg0.handopt_start_step + 1:               # phase B (PL:1361-1453)
                         noise_pred = latent_phase("B", cfg0.optimization_steps_scale, i, t, noise_pred, cfg0.noise_obj_lr1)
                     else:                                                # phase C (PL:1455-1601)
@@ -278,23 +315,28 @@ class GuidedShapePipeline:
             xyz_d, gsz_d = grid(res) if res != guid_res else (xyz_samples, grid_size)
             sdf = sdf_of(self.scheduler.step_final(noise_pred, t, latents), xyz_d, gsz_d)
             for b in range(B):
-                verts, faces, _ = ops.flexicubes(xyz_d, sdf[b], res)
-                if verts.shape[0] == 0:
-                    print("Invalid mesh detected, aborting step!")
+                if b in left:
                     continue
                 p = gb.params[b]
-                obj_world = similarity_about_center(verts @ T_h2m[b][:3, :3].T + T_h2m[b][:3, 3], p[8], p[12:16], p[9:12])
-                tex = torch.zeros_like(obj_world)
-                tex[:, 2] = 1.0
-                obj = Meshes(verts=[obj_world], faces=[faces], textures=TexturesVertex(verts_features=[tex]))
-                hand = results[b][1] if results[b] is not None else None
-                if i >= cfg0.handopt_start_step:
-                    hv = similarity_about_center(hand_moge[b], p[0], p[4:8], p[1:4])
+                obj, hand = results[b] if results[b] is not None else (None, None)
+                if i >= cfg0.handopt_start_step:         # the hand of THIS step, whatever the decode gives (PL:1615-1619 come before the
+                    hv = similarity_about_center(hand_moge[b], p[0], p[4:8], p[1:4])       # empty-mesh test of PL:1644-1646)
                     tex_h = torch.zeros_like(hv)
                     tex_h[:, 1] = 1.0
                     hand = Meshes(verts=[hv], faces=[hand_faces[b]], textures=TexturesVertex(verts_features=[tex_h]))
+                verts, faces, _ = ops.flexicubes(xyz_d, sdf[b], res)
+                if verts.shape[0] == 0:
+                    print("Invalid mesh detected, aborting step!")
+                else:
+                    obj_world = similarity_about_center(verts @ T_h2m[b][:3, :3].T + T_h2m[b][:3, 3], p[8], p[12:16], p[9:12])
+                    tex = torch.zeros_like(obj_world)
+                    tex[:, 2] = 1.0
+                    obj = Meshes(verts=[obj_world], faces=[faces], textures=TexturesVertex(verts_features=[tex]))
                 results[b] = (obj, hand)
+        for b, why in left.items():
+            results[b] = why
         self.guidance_batch = gb
+        stats["left_batch"] = sorted(left)
         return results
 
     # ------------------------------------------------------------------ PL:1044-1679

@@ -285,3 +285,16 @@ def test_bench_traffic_tables_read_the_committed_profiles():
         tot_pmc, tot_ea = sum(pmc[k] for k in bench.STEP_KERNELS), sum(ea[k] for k in bench.STEP_KERNELS)
         assert abs(tot_pmc - tot_ea) <= 0.25 * tot_pmc, (tot_pmc, tot_ea)
     assert bench.pmc_table(("40k", 512, 1)) == ({}, None) and bench.ea_table(("ico4", 64, 1)) == ({}, None)
+
+
+def test_hy3dgen_layout_check_script_says_so_when_hy3dgen_is_absent():
+    """scripts/check_hy3dgen_layout.py -- the real-module readiness check a maintainer runs where Hunyuan3D-2 is installed -- exits 0
+    with a plain message on a machine without hy3dgen (this one) instead of failing."""
+    import importlib.util
+    import subprocess
+    import sys
+    if importlib.util.find_spec("hy3dgen") is not None:
+        pytest.skip("hy3dgen is installed here: run the script itself")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_hy3dgen_layout.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "hy3dgen not installed" in r.stdout, r.stdout[-2000:]

@@ -460,16 +460,68 @@ def test_call_batch_equals_two_single_image_calls(tmp_path):
         assert o1.faces_packed().shape == o2.faces_packed().shape and torch.allclose(o1.verts_packed(), o2.verts_packed(), atol=2e-4)
     ext = [(m[0].verts_packed().max(0)[0] - m[0].verts_packed().min(0)[0]).max().item() for m in both]
     assert abs(ext[0] - ext[1]) > 5e-3, ext                                              # two different images (object sizes)
-    # an iso-surface beyond the capacity is the one-image path's business: the batch says so instead of approximating
-    with pytest.raises(PLN.BatchLeftFastPath):
-        pipe.call_batch(imgs, paths, obj_capacity=(64, 128), **kw)
+    # an iso-surface beyond the capacity is the one-image path's business: the image LEAVES the batch (its result says why) instead of
+    # being approximated -- here both do, at the first iteration that decodes an object
+    gone = pipe.call_batch(imgs, paths, obj_capacity=(64, 128), **kw)
+    assert all(isinstance(r, PLN.BatchLeftFastPath) and r.phase == "B" and r.iteration == 0 and r.flags & 16 for r in gone), gone
+    assert pipe.stats["left_batch"] == [0, 1]
+
+
+@gpu
+def test_call_batch_handles_events_per_image(tmp_path, monkeypatch):
+    """One image of a batch meets what the reference handles per image; the other must not notice.  (a) An EMPTY iso-surface at one
+    iteration (PL:1394-1397, 1511-1513: `continue` -- no optimiser step for that image at that iteration): the other image's result
+    is its result from an undisturbed batch (tame learning rates as in the test above: at the reference's own rates two runs of ONE
+    image separate), the skip is counted and nobody leaves.  (b) A NaN loss (PL:1442-1444, 1590-1592): that image leaves the batch
+    -- its entry says so, with phase and iteration --, the other one's result is again the undisturbed one."""
+    from PIL import Image
+    from followmyhold_amd import engine as E
+    scs = [_scene_for_pipeline(), _scene_for_pipeline(radius=0.7)]
+    paths = [_write(tmp_path / f"img{b}", sc, index=str(7 + b)) for b, sc in enumerate(scs)]
+    cfg = _short_config()
+    for name in ("phase1_hand_lrs", "phase2_hand_lrs", "obj_lrs", "obj_2half_lrs"):
+        setattr(cfg, name, {k: v / 500.0 for k, v in getattr(cfg, name).items()})
+    cfg.noise_obj_lr1, cfg.noise_obj_lr2 = cfg.noise_obj_lr1 / 500.0, cfg.noise_obj_lr2 / 500.0
+    pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1)
+    imgs = [Image.open(p["cropped_obj_img_path"]) for p in paths]
+    kw = dict(config=cfg, renderer=_renderer(scs[0]["fov"]), J_regressor=scs[0]["J_regressor"], guidance_octree_resolution=24, final_octree_resolution=40)
+    clean = pipe.call_batch(imgs, paths, **kw)
+    assert pipe.stats["skipped_empty"] == 0 and pipe.stats["left_batch"] == []
+    orig = E.SdfObjective.run
+    for event in ("empty", "nan"):
+        n = {"calls": 0}
+
+        def run(self, sdf, cfg_, use_graph=True):
+            n["calls"] += 1
+            hit = n["calls"] == 2                        # the second latent iteration of phase B, image 1 only
+            if hit and event == "empty":
+                sdf = sdf.detach().clone()
+                sdf[1] = 1.0                             # positive everywhere: no surface
+            out = orig(self, sdf, cfg_, use_graph)
+            if hit and event == "nan":
+                self.gb.flags[1] |= 1                    # what the step reports for a NaN total loss (k_final.inc; tested on its own)
+            return out
+
+        monkeypatch.setattr(E.SdfObjective, "run", run)
+        got = pipe.call_batch(imgs, paths, **kw)
+        monkeypatch.setattr(E.SdfObjective, "run", orig)
+        (o0, h0), (c0, ch0) = got[0], clean[0]
+        assert o0.faces_packed().shape == c0.faces_packed().shape and torch.allclose(o0.verts_packed(), c0.verts_packed(), atol=2e-4)
+        assert torch.allclose(h0.verts_packed(), ch0.verts_packed(), atol=5e-5)
+        if event == "empty":
+            assert pipe.stats["skipped_empty"] == 1 and pipe.stats["left_batch"] == []
+            assert pipe.stats["inner_iterations"] == 10 + 3 + 2 * 2
+            o1, h1 = got[1]
+            assert torch.isfinite(o1.verts_packed()).all() and torch.isfinite(h1.verts_packed()).all()
+        else:
+            assert isinstance(got[1], PLN.BatchLeftFastPath) and got[1].phase == "B" and got[1].iteration == 1 and pipe.stats["left_batch"] == [1]
 
 
 @gpu
 def test_guidance_stage_driver_batches_images_with_the_networks_in_the_loop(tmp_path, monkeypatch, capsys):
     """`foho.guidance.run.run` over three images with FOHO_PIPELINE_BATCH=2: two go through ONE pass of the schedule
     (GuidedShapePipeline.call_batch), the third on its own; the reference's messages per image, six PLY files, metrics of
-    three images.  A batch that leaves the fast path (here: forced by a tiny object capacity) is redone one image at a time."""
+    three images.  Images that leave the batch (here: all, forced by a tiny object capacity) are redone one at a time."""
     from foho.guidance import run as G
     from followmyhold_amd import meshio, pipeline as PL_
     scs = [_scene_for_pipeline(), _scene_for_pipeline(radius=0.7), _scene_for_pipeline(radius=0.75)]
