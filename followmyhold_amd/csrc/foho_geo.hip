@@ -31,6 +31,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
+#include <stdlib.h>
 
 #include "../../include/foho_hip.h"
 
@@ -412,6 +413,252 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
         }
     }
 #undef GEO_RD6
+    __syncthreads();
+
+    h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, bias, R, ldr, C, ldc, C2, ldc2, M,
+                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 256 x 256 x 64 GEMM as a PHASED loop (round 5).  Same tile, same LDS image, same fragments and epilogue as k_geo_gemm256 --
+// another schedule.  k_geo_gemm256 has the two waves of every SIMD in lockstep: both issue their eight LDS-DMA pieces of a K tile at
+// once (650-1500 cycles of issue during which the SIMD's matrix pipe idles, NOTEBOOK round 4).  Here the two wave groups of the
+// workgroup (waves 0-3 and 4-7: one wave of each SIMD per group) run ONE BARRIER APART and a K tile is four phases of
+// {load segment | barrier | compute segment | barrier}: while a SIMD's one wave multiplies (8 matrix instructions = one quadrant
+// of its 128 x 64 tile, s_setprio 1) its other wave issues its fragment reads and TWO LDS-DMA pieces -- a load segment is as long
+// as the partner's compute segment instead of three times as long.  The next K tile arrives in quarters, in the order in which it
+// will be read (W columns 0-31 of every wave, A rows 0-63, A rows 64-127, W columns 32-63), each quarter issued three phases before
+// its first read; a wave waits for its own pieces with a COUNTED s_waitcnt vmcnt(2) at the end of every compute segment (everything
+// but the phase's own two pieces has landed -- the queue is never drained), the barriers publish them to the other waves.
+// Staging by buffer_load_dwordx4 ... lds: resource + scalar offset per piece (the addresses of all pieces of a wave differ by
+// scalars), rows beyond M read zeros (the resource's bound) instead of a clamped row.  The schedule is the "8-phase" form of
+// cdna_hip_programming.md section 5 (T3 + T4 + T5) laid over this kernel's 32 x 32 x 16 fragments.
+// ------------------------------------------------------------------------------------------------
+#ifdef P8_STAMPS
+__device__ unsigned long long g_p8[8][8];
+#endif
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int EP>
+__global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
+                                                       const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
+                                                       h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
+                                                       int ldc2, const int* __restrict__ Mdev) {
+    __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
+    if (Mdev) M = min(M, *Mdev);
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = N / HN, ntm = (M + HM - 1) / HM;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mp = (j / ntn) * 8 + xcd, nt = j % ntn;
+    if (mp >= ntm) return;
+    const int m0 = mp * HM, n0 = nt * HN;
+    const int wr = w >> 2, wc = w & 3;  // this wave's 128 (M) x 64 (N) part of the tile; wr = its group
+
+    // ---- LDS-DMA pieces of this wave: per K tile two pieces in each of four phases.  A piece = 8 rows x 128 bytes; a lane's 16 bytes
+    // land at (row0 + lane / 8, slot lane % 8), so it FETCHES chunk slot ^ swz(row); swz(row0 + r) depends on row0 only through
+    // the parity of row0 / 8, which is the parity of the piece's index in its quarter: pieces 2w (even) and 2w + 1 (odd).
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int va0 = (srow * lda + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, va1 = (srow * lda + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
+    const int vw0 = (srow * ldw + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, vw1 = (srow * ldw + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
+    // tile rows of the pieces, by quarter: W columns sub 0 (phase 0), A rows sub 0 (phase 1), A rows sub 1 (phase 2), W columns sub 1 (phase 3)
+    int rowq[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int Lp = 2 * w + e;
+        rowq[0][e] = 64 * (Lp >> 2) + 8 * (Lp & 3);
+        rowq[1][e] = 128 * (Lp >> 3) + 8 * (Lp & 7);
+        rowq[2][e] = 128 * (Lp >> 3) + 64 + 8 * (Lp & 7);
+        rowq[3][e] = 64 * (Lp >> 2) + 32 + 8 * (Lp & 3);
+    }
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, (short)0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+    int sq[4][2];   // scalar byte offsets of the pieces at K tile 0
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        sq[0][e] = (n0 + rowq[0][e]) * ldw * 2;
+        sq[1][e] = (m0 + rowq[1][e]) * lda * 2;
+        sq[2][e] = (m0 + rowq[2][e]) * lda * 2;
+        sq[3][e] = (n0 + rowq[3][e]) * ldw * 2;
+    }
+#ifndef P8_ABL
+#define P8_ABL 0
+#endif
+#ifdef P8_STAMPS   // development build: per-wave sums of the loop's segment durations (shader clocks), workgroup 0 -> foho_geo_p8_stamps()
+#define P8_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]))   /* (the wait: ~40 cycles per stamp, and it retires the LDS reads early) */
+#define P8_ACC()                                                                         \
+    do {                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; q_++) seg[q_] += (int)(long long)(ts[q_ + 1] - ts[q_]); \
+        ts[0] = ts[6];                                                                   \
+    } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#define P8_ACC() do { } while (0)
+#endif
+#define P8_DMA(q, nb, koff)                                                                                                        \
+    do {                                                                                                                           \
+        if ((P8_ABL & 1) && (koff) != 0) break;                                                                                    \
+        if ((q) == 0 || (q) == 3) {                                                                                                \
+            dma16(rw_, &lds[nb][1][rowq[q][0] * 8], vw0, sq[q][0] + (koff));                                                       \
+            dma16(rw_, &lds[nb][1][rowq[q][1] * 8], vw1, sq[q][1] + (koff));                                                       \
+        } else {                                                                                                                   \
+            dma16(ra_, &lds[nb][0][rowq[q][0] * 8], va0, sq[q][0] + (koff));                                                       \
+            dma16(ra_, &lds[nb][0][rowq[q][1] * 8], va1, sq[q][1] + (koff));                                                       \
+        }                                                                                                                          \
+    } while (0)
+
+    f32x16 acc[2][4];  // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const int ra = wr * 128 + l31, rw = wc * 64 + l31;
+    const unsigned base = lds_addr(&lds[0][0][0]);
+    unsigned aa[4], aw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        aa[kk] = base + ra * 128 + (((2 * kk + hi) ^ swz(ra)) << 4);
+        aw[kk] = base + rw * 128 + (((2 * kk + hi) ^ swz(rw)) << 4);
+    }
+    const int nk = K / GK;
+    half8 fa0[4][2], fa1[4][2], fw0[4], fw1[4];   // A rows sub 0 / sub 1 (two 32-row tiles each), W columns sub 0 / sub 1, by K step
+
+    // ---- prologue: K tile 0 whole and the three quarters of K tile 1 the steady state would have issued by now; then W columns sub 0
+    // of tile 0 into registers; the second group starts one barrier late
+#pragma unroll
+    for (int q = 0; q < 4; q++) P8_DMA(q, 0, 0);
+    P8_DMA(0, 1, GK * 2);
+    P8_DMA(1, 1, GK * 2);
+    P8_DMA(2, 1, GK * 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk], 32768);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();
+
+#define P8_DSR(dst, addr, off)                 \
+    do {                                        \
+        if (!(P8_ABL & 2)) GEO_DSR(dst, addr, off); \
+    } while (0)
+#if P8_ABL & 8
+#define P8_LGKM ""
+#else
+#define P8_LGKM "s_waitcnt lgkmcnt(0)"
+#endif
+#if P8_ABL & 16
+#define P8_WAIT(n) do { } while (0)
+#else
+#define P8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
+    // compute segment: prio 1, eight matrix instructions, prio 0, the counted wait for this wave's older DMA pieces, barrier
+#define P8_COMPUTE(ACC0, ACC1, FW, FA, WAITN)                                                                                       \
+    do {                                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        P8_STAMP(3);                                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
+            ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][0], ACC0, 0, 0, 0);                                        \
+            ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][1], ACC1, 0, 0, 0);                                        \
+        }                                                                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        P8_STAMP(4);                                                                                                                \
+        P8_WAIT(WAITN);                                                                                                             \
+        P8_STAMP(5);                                                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        P8_STAMP(6);                                                                                                                \
+        P8_ACC();                                                                                                                   \
+    } while (0)
+#define P8_SYNC8(F)                                                                                                                 \
+    do {                                                                                                                            \
+        P8_STAMP(1);                                                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        P8_STAMP(2);                                                                                                                \
+        asm volatile(P8_LGKM : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1])); \
+    } while (0)
+#define P8_SYNC4(F)                                                                                \
+    do {                                                                                           \
+        P8_STAMP(1);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                              \
+        P8_STAMP(2);                                                                               \
+        asm volatile(P8_LGKM : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]));                    \
+    } while (0)
+    // One K tile = four phases.  Which DMA quarter a phase issues: the one whose LDS region the workgroup has finished reading two
+    // phases earlier (both groups: the second group's reads of a region retire one barrier after the first's), SIX phases ahead of
+    // its own first read -- phase 0: W columns sub 1 of tile t + 1; phase 1: W columns sub 0 of t + 2; phase 2: A rows sub 0 of
+    // t + 2; phase 3: A rows sub 1 of t + 2 (tile t + 2 goes into THIS tile's buffer).  I0..I3: does the phase issue (the last two
+    // tiles issue less); W0..W3: pieces of this wave that may still be in flight at the end of the phase's compute segment =
+    // 2 x (issuing phases among the last four): everything older has landed, and two barriers later every wave knows it.
+#define P8_TILE(I0, I1, I2, I3, W0, W1, W2, W3)                                                                                     \
+    do {                                                                                                                            \
+        const unsigned bo = (unsigned)(t & 1) << 16, bn = bo ^ 0x10000u;   /* 64 KB per buffer */                                   \
+        const int cb = t & 1, nb = cb ^ 1, k1 = (t + 1) * GK * 2, k2 = (t + 2) * GK * 2;                                            \
+        /* phase 0: A rows sub 0 (x) W columns sub 0 (read in the previous phase 3) */                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
+            P8_DSR(fa0[kk][0], aa[kk] + bo, 0);                                                                                     \
+            P8_DSR(fa0[kk][1], aa[kk] + bo, 4096);                                                                                  \
+        }                                                                                                                           \
+        if (I0) P8_DMA(3, nb, k1);                                                                                                  \
+        P8_SYNC8(fa0);                                                                                                              \
+        P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0);                                                                             \
+        /* phase 1: A rows sub 1 (x) W columns sub 0 */                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
+            P8_DSR(fa1[kk][0], aa[kk] + bo, 8192);                                                                                  \
+            P8_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                                 \
+        }                                                                                                                           \
+        if (I1) P8_DMA(0, cb, k2);                                                                                                  \
+        P8_SYNC8(fa1);                                                                                                              \
+        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                                             \
+        /* phase 2: A rows sub 1 (x) W columns sub 1 */                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw1[kk], aw[kk] + bo, 32768 + 4096);                                \
+        if (I2) P8_DMA(1, cb, k2);                                                                                                  \
+        P8_SYNC4(fw1);                                                                                                              \
+        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                                             \
+        /* phase 3: A rows sub 0 (x) W columns sub 1; W columns sub 0 of the NEXT tile come in for its phase 0 */                   \
+        if (I0) {                                                                                                                   \
+            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw0[kk], aw[kk] + bn, 32768);                                   \
+        }                                                                                                                           \
+        if (I3) P8_DMA(2, cb, k2);                                                                                                  \
+        P8_SYNC4(fw0);                                                                                                              \
+        P8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3);                                                                             \
+    } while (0)
+
+#ifdef P8_STAMPS
+    unsigned long long ts[7];
+    int seg[6] = {0, 0, 0, 0, 0, 0};
+    P8_STAMP(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    int t = 0;
+    for (; t < nk - 2; t++) P8_TILE(1, 1, 1, 1, 8, 8, 8, 8);
+    P8_TILE(1, 0, 0, 0, 8, 6, 4, 2);   // t = nk - 2: only W columns sub 1 of the last tile is still to come
+    t++;
+    P8_TILE(0, 0, 0, 0, 0, 0, 0, 0);   // t = nk - 1
+#undef P8_TILE
+#undef P8_COMPUTE
+#undef P8_SYNC8
+#undef P8_SYNC4
+#undef P8_DMA
+#undef P8_WAIT
+#undef P8_DSR
+#ifdef P8_STAMPS
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int q_ = 0; q_ < 6; q_++) g_p8[w][q_] = (unsigned long long)(long long)seg[q_];
+        g_p8[w][6] = nk;
+    }
+#endif
+    if (wr == 0 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
     __syncthreads();
 
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
@@ -1237,10 +1484,19 @@ static bool launch_ok(const char* what) {
 }
 
 static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
+static bool g_force_lockstep = false;   // ... gelu | 4: the lock-step 256 x 256 kernel instead of the phased one
+// FOHO_GEO_GEMM=lockstep: the whole chain on k_geo_gemm256 (A/B measurements); read once
+static bool env_lockstep() {
+    static const bool v = [] { const char* e = getenv("FOHO_GEO_GEMM"); return e && std::string(e) == "lockstep"; }();
+    return v;
+}
 template <int EP>
 static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
-    if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    // the phased kernel addresses its operands through 32-bit buffer offsets
+    const bool phased = big && K / GK >= 2 && !g_force_lockstep && !env_lockstep() && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31);
+    if (phased) hipLaunchKernelGGL(k_geo_gemm8p<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    else if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
 }
 
@@ -1315,6 +1571,9 @@ static Layout layout(const foho_geo_weights* w, int chunk) {
 using namespace geo;
 
 extern "C" const char* foho_geo_last_error(void) { return g_err; }
+#ifdef P8_STAMPS
+extern "C" void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geo::g_p8), sizeof(geo::g_p8)); }
+#endif
 
 extern "C" int64_t foho_geo_abi_size(void) { return (int64_t)sizeof(foho_geo_weights); }
 
@@ -1748,7 +2007,8 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
     if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
     g_force128 = (gelu & 2) != 0;
-    struct Reset { ~Reset() { g_force128 = false; } } reset;
+    g_force_lockstep = (gelu & 4) != 0;
+    struct Reset { ~Reset() { g_force128 = g_force_lockstep = false; } } reset;
     gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
                 (hipStream_t)stream);

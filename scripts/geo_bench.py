@@ -37,21 +37,35 @@ if "--parts" in sys.argv:
     lib.foho_geo_last_error.restype = ctypes.c_char_p
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    M = 16384
-    for (N, K, gelu) in ((1024, 64, 0), (1024, 1024, 0), (4096, 1024, 1), (1024, 4096, 0)):
+    for M in (16384, 49152):
+      for (N, K, gelu) in ((1024, 1024, 0), (4096, 1024, 1), (4096, 1024, 0), (1024, 4096, 0)):
         A = torch.randn(M, K, device=dev).half(); W = (torch.randn(N, K, device=dev) / math.sqrt(K)).half(); b = torch.randn(N, device=dev)
         C = torch.empty(M, N, dtype=torch.float16, device=dev)
-        for _ in range(3):
-            lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, gelu, ctypes.c_float(1.0), st)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20):
-            lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, gelu, ctypes.c_float(1.0), st)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+        def run(flag, n=20):
+            for _ in range(3):
+                lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, gelu | flag, ctypes.c_float(1.0), st)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n):
+                lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, gelu | flag, ctypes.c_float(1.0), st)
+            torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+        # interleaved A/B rounds in one process: phased (default) vs lock-step (flag 4)
+        ts = {0: [], 4: []}
+        for _ in range(5):
+            for flag in (0, 4):
+                ts[flag].append(run(flag))
+        dt, dl = min(ts[0]), min(ts[4])
+        Cp = C.clone()
+        lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, gelu | 4, ctypes.c_float(1.0), st)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(Cp, C))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20):
             Ct = torch.nn.functional.linear(A, W, b.half())
         torch.cuda.synchronize(); dtt = (time.perf_counter() - t0) / 20
-        print(f"gemm M={M} N={N} K={K} gelu={gelu}: {dt * 1e6:.1f} us = {2 * M * N * K / dt / 1e12:.0f} TFLOP/s (torch linear {dtt * 1e6:.1f} us = {2 * M * N * K / dtt / 1e12:.0f})", flush=True)
+        fl = 2 * M * N * K
+        print(f"gemm M={M} N={N} K={K} gelu={gelu}: phased {dt * 1e6:.1f} us = {fl / dt / 1e12:.0f} TFLOP/s | lock-step {dl * 1e6:.1f} us = {fl / dl / 1e12:.0f} | "
+              f"torch linear {dtt * 1e6:.1f} us = {fl / dtt / 1e12:.0f} | phased == lock-step bitwise: {same}", flush=True)
+    M = 16384
     Lk, H = 3072, 16
     q = torch.randn(M, 1024, device=dev).half(); kv = torch.randn(Lk, 2048, device=dev).half()
     O = torch.empty(M, 1024, dtype=torch.float16, device=dev); vt = torch.empty(1024 * Lk, dtype=torch.float16, device=dev)
