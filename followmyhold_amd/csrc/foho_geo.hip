@@ -84,6 +84,33 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v + 0.5f * fabsf(v) * e;                                                   // v erf(v / sqrt 2) = |v| erf(|v| / sqrt 2)
 }
 
+// GELU of two values at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: one instruction per PAIR) -- the fc1 epilogue is
+// bound by exactly this vector work (a 256 x 256 tile's 65 536 GELUs with nothing to overlap them at one workgroup per CU) ...
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    // ... and with ONE transcendental per value instead of two (the reciprocal and the exponential of 7.1.26 were half of the
+    // epilogue's issue time: quarter-rate instructions): Abramowitz-Stegun 7.1.28, erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16 for
+    // x >= 0, |error| <= 3e-7 (1.8e-6 after the four squarings in fp32) -- gelu(v) = max(v, 0) - |v| / 2 (1 + ...)^-16, absolute
+    // error <= 8e-7: three orders below the fp16 rounding of the result, like 7.1.26's.  A huge |v| overflows the power to +inf,
+    // whose reciprocal is the right 0.
+    f32x2 av, mx;
+    av[0] = fabsf(v[0]), av[1] = fabsf(v[1]);
+    mx[0] = fmaxf(v[0], 0.0f), mx[1] = fmaxf(v[1], 0.0f);
+    const f32x2 x = av * 0.70710678118654752f;
+    f32x2 p = x * 0.0000430638f + 0.0002765672f;
+    p = p * x + 0.0001520143f;
+    p = p * x + 0.0092705272f;
+    p = p * x + 0.0422820123f;
+    p = p * x + 0.0705230784f;
+    f32x2 s = p * x + 1.0f;
+    s = s * s;
+    s = s * s;
+    s = s * s;
+    s = s * s;
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(s[0]), r[1] = __builtin_amdgcn_rcpf(s[1]);
+    return (av * -0.5f) * r + mx;
+}
+
 // Epilogue of both GEMM kernels for one 64 (M) x 64 (N) part of a wave's tile, accumulators t[n tile][m tile] in the transposed
 // C layout (D rows = n, D columns = m: a lane holds, for ONE m, 4 consecutive n per register group).  bias / GELU / scale in
 // fp32, rounded to fp16, through a wave-private LDS image (64 rows x CPAD halfs) to whole-row 16-byte stores; at read-back
@@ -128,12 +155,28 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                 for (int i = 0; i < 2; i++) {
                     const f32x16& t = jn == 0 ? (i == 0 ? t00 : t01) : (i == 0 ? t10 : t11);
                     half4 o;
+#ifdef GELU_SCALAR
+                    if (false) {
+#else
+                    if ((EP & EP_GELU) && pass == 1) {   // (scale is 1 on the GELU path: fc1)
+#endif
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float v = t[4 * g + q] + b4[q];
-                        if ((EP & EP_GELU) && pass == 1) v = gelu_erf(v);
-                        if (!(EP & EP_QNORM)) v *= scale;
-                        o[q] = (h16)v;
+                        for (int q = 0; q < 4; q += 2) {
+                            f32x2 v = {t[4 * g + q] + b4[q], t[4 * g + q + 1] + b4[q + 1]};
+                            v = gelu_erf2(v) * scale;
+                            const half2v h = __builtin_convertvector(v, half2v);
+                            o[q] = h[0], o[q + 1] = h[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float v = t[4 * g + q] + b4[q];
+#ifdef GELU_SCALAR
+                            if ((EP & EP_GELU) && pass == 1) v = gelu_erf(v);
+#endif
+                            if (!(EP & EP_QNORM)) v *= scale;
+                            o[q] = (h16)v;
+                        }
                     }
                     *reinterpret_cast<half4*>(img + (i * 32 + l31) * CPAD + nl) = o;
                     if ((EP & EP_TRANS) && !(EP & EP_QNORM) && pass == 1) {
@@ -489,6 +532,9 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 #ifndef P8_ABL
 #define P8_ABL 0
 #endif
+#ifndef P8_VAR
+#define P8_VAR 0
+#endif
 #ifdef P8_STAMPS   // development build: per-wave sums of the loop's segment durations (shader clocks), workgroup 0 -> foho_geo_p8_stamps()
 #define P8_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]))   /* (the wait: ~40 cycles per stamp, and it retires the LDS reads early) */
 #define P8_ACC()                                                                         \
@@ -562,7 +608,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 #define P8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #endif
     // compute segment: prio 1, eight matrix instructions, prio 0, the counted wait for this wave's older DMA pieces, barrier
-#define P8_COMPUTE(ACC0, ACC1, FW, FA, WAITN)                                                                                       \
+#define P8_COMPUTE(ACC0, ACC1, FW, FA, WAITN, MID)                                                                                  \
     do {                                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
         P8_STAMP(3);                                                                                                                \
@@ -570,6 +616,11 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][0], ACC0, 0, 0, 0);                                        \
             ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][1], ACC1, 0, 0, 0);                                        \
+            if (kk == 0) {                                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                                  \
+                MID;                                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                                  \
+            }                                                                                                                       \
         }                                                                                                                           \
         __builtin_amdgcn_s_setprio(0);                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
@@ -605,33 +656,36 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         const unsigned bo = (unsigned)(t & 1) << 16, bn = bo ^ 0x10000u;   /* 64 KB per buffer */                                   \
         const int cb = t & 1, nb = cb ^ 1, k1 = (t + 1) * GK * 2, k2 = (t + 2) * GK * 2;                                            \
         /* phase 0: A rows sub 0 (x) W columns sub 0 (read in the previous phase 3) */                                              \
+        if (P8_VAR == 1 && I0) P8_DMA(3, nb, k1);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             P8_DSR(fa0[kk][0], aa[kk] + bo, 0);                                                                                     \
             P8_DSR(fa0[kk][1], aa[kk] + bo, 4096);                                                                                  \
         }                                                                                                                           \
-        if (I0) P8_DMA(3, nb, k1);                                                                                                  \
+        if (P8_VAR == 0 && I0) P8_DMA(3, nb, k1);                                                                                   \
         P8_SYNC8(fa0);                                                                                                              \
-        P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0);                                                                             \
+        P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0, if (P8_VAR == 2 && I0) P8_DMA(3, nb, k1));                                                                             \
         /* phase 1: A rows sub 1 (x) W columns sub 0 */                                                                             \
+        if (P8_VAR == 1 && I1) P8_DMA(0, cb, k2);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             P8_DSR(fa1[kk][0], aa[kk] + bo, 8192);                                                                                  \
             P8_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                                 \
         }                                                                                                                           \
-        if (I1) P8_DMA(0, cb, k2);                                                                                                  \
+        if (P8_VAR == 0 && I1) P8_DMA(0, cb, k2);                                                                                   \
         P8_SYNC8(fa1);                                                                                                              \
-        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                                             \
+        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1, if (P8_VAR == 2 && I1) P8_DMA(0, cb, k2));                                                                             \
         /* phase 2: A rows sub 1 (x) W columns sub 1 */                                                                             \
+        if (P8_VAR == 1 && I2) P8_DMA(1, cb, k2);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw1[kk], aw[kk] + bo, 32768 + 4096);                                \
-        if (I2) P8_DMA(1, cb, k2);                                                                                                  \
+        if (P8_VAR == 0 && I2) P8_DMA(1, cb, k2);                                                                                   \
         P8_SYNC4(fw1);                                                                                                              \
-        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                                             \
+        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2, if (P8_VAR == 2 && I2) P8_DMA(1, cb, k2));                                                                             \
         /* phase 3: A rows sub 0 (x) W columns sub 1; W columns sub 0 of the NEXT tile come in for its phase 0 */                   \
         if (I0) {                                                                                                                   \
             _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw0[kk], aw[kk] + bn, 32768);                                   \
         }                                                                                                                           \
-        if (I3) P8_DMA(2, cb, k2);                                                                                                  \
+        if (P8_VAR != 2 && I3) P8_DMA(2, cb, k2);                                                                                   \
         P8_SYNC4(fw0);                                                                                                              \
-        P8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3);                                                                             \
+        P8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3, if (P8_VAR == 2 && I3) P8_DMA(2, cb, k2));                                                                             \
     } while (0)
 
 #ifdef P8_STAMPS
