@@ -541,7 +541,8 @@ def headline(out):
         pi = out.get("pipeline_iteration") or {}
         if "hip_decoder" in pi:
             sec["pipeline_iteration"] = {"ms": _r(get(pi, "hip_decoder", "iteration_ms")), "bwd_ms": _r(get(pi, "hip_decoder", "backward_ms")),
-                                         "torch_ms": _r(get(pi, "torch_decoder", "iteration_ms")), "active_rows": _r(pi.get("active_row_frac"), 3)}
+                                         "torch_ms": _r(get(pi, "torch_decoder", "iteration_ms")), "active_rows": _r(pi.get("active_row_frac"), 3),
+                                         "b4_ms": _r(get(pi, "batch_of_4", "iteration_ms"))}
         cu = out.get("closeup") or {}
         if "one_image" in cu:
             sec["closeup"] = {"b1": _r(get(cu, "one_image", "value")), "b32": _r(get(cu, "in_flight_32", "value"))}
@@ -941,6 +942,7 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     cfg, _ = E.phase_cfg("C", denoise_i=19, do_update=True)
     torch.manual_seed(0)
     vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=16, num_freqs=8).to(dev).half().eval()
+    vae.requires_grad_(False)      # as GuidedShapePipeline holds its networks: the guidance optimises no weight
     lat = torch.randn(1, 3072, 64, device=dev, dtype=torch.float16)
     gsz = (res + 1, res + 1, res + 1)
     out, sdfs = {}, {}
@@ -957,6 +959,8 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
             torch.cuda.synchronize(dev); t["latent2sdf_fwd_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
             sdfs[name] = sdf.detach()
             loss = obj(sdf.reshape(1, -1), cfg)
+            if name == "hip_decoder":      # what the pipeline does at its per-iteration read-back: the exact count of rows with a gradient
+                PLN._bound_active_rows(vae, obj.active_rows()[0])
             torch.cuda.synchronize(dev); t["flexicubes_step_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
             loss.sum().backward()
             torch.cuda.synchronize(dev); t["backward_ms"] = (time.perf_counter() - a) * 1e3
@@ -967,6 +971,34 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         rec["iteration_ms"] = sum(rec.values())
         rec["grad_finite"] = bool(torch.isfinite(noise.grad).all())     # (fp16 leaf, random networks: its magnitude means nothing)
         out[name] = rec
+    # ... and four images through one iteration the way GuidedShapePipeline.call_batch runs them ("batch the rank's images
+    # through each kernel launch"): the VAE transformer on four latents, the decoder per image on the shared cached query side, ONE
+    # replay of iso-surfacing + object install + fused step + iso-surface backward for all four, backward to the four noise predictions
+    try:
+        B4 = 4
+        gb4 = E.GuidanceBatch([scene] * B4, device=dev, obj_capacity=(32768, 65536))
+        obj4 = E.SdfObjective(gb4, xyz, res)
+        lat4 = torch.randn(B4, 3072, 64, device=dev, dtype=torch.float16)
+        noise4 = torch.zeros_like(lat4).requires_grad_(True)
+        hip = vae.hip_geo
+        def one4():
+            noise4.grad = None
+            torch.cuda.synchronize(dev); a = time.perf_counter()
+            pred = vae((1 / vae.scale_factor) * (lat4 + 0.1 * noise4))
+            sdf4 = torch.stack([-hip(hip.grid_queries(xyz), pred[b:b + 1]).view(-1).float() for b in range(B4)], 0)
+            loss = obj4(sdf4, cfg)
+            gb4.flags.cpu()
+            PLN._bound_active_rows(vae, max(obj4.active_rows()))
+            loss.sum().backward()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - a) * 1e3
+        one4(); one4()
+        t4 = float(np.median([one4() for _ in range(iters)]))
+        out["batch_of_4"] = {"iteration_ms": t4, "ms_per_image": t4 / B4, "vs_one_image": t4 / out["hip_decoder"]["iteration_ms"],
+                             "grad_finite": bool(torch.isfinite(noise4.grad).all())}
+        del gb4, obj4
+    except Exception as e:  # noqa: BLE001
+        out["batch_of_4"] = {"error": f"{type(e).__name__}: {e}"}
     nv, nf, flags = obj.status()[0]
     st_rows = vae.hip_geo.last_row_stats
     if st_rows is not None:

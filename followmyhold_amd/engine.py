@@ -945,6 +945,11 @@ class SdfObjective:
         f = self.gb.flags.cpu().numpy()
         return [(int(c[b, 0]), int(c[b, 1]), int(f[b])) for b in range(self.gb.B)]
 
+    def active_rows(self):
+        """Grid points per image that carry a gradient after the last run (non-zero entries of dL/dSDF: the end points of the grid edges
+        the iso-surface crosses) -- the exact row count the geometry decoder's active-row backward will meet (one host sync)."""
+        return torch.count_nonzero(self.grad_sdf, dim=1).cpu().tolist()
+
     def mesh(self, b=0):
         """(verts (Vo,3), faces (Fo,3) int64 mesh-local) of image b's current object (host sync for the counts)."""
         nv, nf, _ = self.status()[b]

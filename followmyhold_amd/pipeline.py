@@ -54,6 +54,26 @@ def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     return -grid_logits.view((1, grid_size[0], grid_size[1], grid_size[2])).float()
 
 
+def _bound_active_rows(vae, n_rows):
+    """The decoder's active-row backward (foho_geo_decode_bwd_rows) launches row blocks up to an upper bound of the rows that carry a
+    gradient; every block beyond the actual count is fourteen empty launches (4.5 us each).  In the guidance loop the gradient comes
+    out of the FlexiCubes backward, which has run by the time the iteration's flags are read back: `n_rows` = the exact count
+    (SdfObjective.active_rows(), or a surface's face count on the exact-size path: one quad per crossed edge).  Returns the decoder
+    (or None) so that the caller can check `rows_dropped` when the phase is over -- a safety net that never fires with an exact count."""
+    hip = getattr(vae, "hip_geo", None)
+    if hip is not None:
+        hip.row_cap = max(int(n_rows), 1)
+    return hip
+
+
+def _check_rows_dropped(hip):
+    if hip is not None and hip.last_row_stats is not None:
+        n_act, dropped = hip.last_row_stats.tolist()
+        if dropped:
+            raise E.L.FohoError(f"geometry decoder backward: {dropped} of {n_act} active rows exceeded row_cap = {hip.row_cap}: the gradient "
+                                "of this phase is incomplete (raise obj_capacity or set vae.hip_geo.row_cap = None)")
+
+
 def similarity_about_center(verts, scale, quat, trans):
     """transform_mesh_around_center_w_scale (PL:108-118): scale and rotate about the bounding-box centre, then shift."""
     center = (verts.min(dim=0)[0] + verts.max(dim=0)[0]) / 2.0
@@ -84,6 +104,12 @@ class GuidedShapePipeline:
     def __init__(self, vae, model, scheduler, conditioner, image_processor, device="cuda", dtype=torch.float16, **kwargs):
         self.vae, self.model, self.scheduler = vae, model, scheduler
         self.conditioner, self.image_processor = conditioner, image_processor
+        # The guidance optimises the noise prediction and fourteen pose parameters (PL:1318, 1384, 1478), never a network weight: with
+        # the weights' requires_grad left at torch's default the backward of every inner iteration would also form d loss / d W of
+        # the whole ShapeVAE transformer -- as much matrix work again as the gradient that is wanted -- into .grad buffers nobody reads.
+        for net in (vae, model, conditioner):
+            if isinstance(net, torch.nn.Module):
+                net.requires_grad_(False)
         self.to(device, dtype)
 
     @classmethod
@@ -214,6 +240,7 @@ class GuidedShapePipeline:
         cap = tuple(obj_capacity) if obj_capacity else (8 * guid_res * guid_res, 16 * guid_res * guid_res)
         gb = E.GuidanceBatch(scenes, device=device, grid_res=guid_res, n_renders=2, obj_capacity=cap)
         fobj = E.SdfObjective(gb, xyz_samples, guid_res)
+        hip_dec = getattr(self.vae, "hip_geo", None)
         T_h2m = [torch.as_tensor(sc["T_h2m"], dtype=torch.float32, device=device) for sc in scenes]
         hand_moge = [torch.as_tensor(sc["hand_verts"], dtype=torch.float32, device=device) for sc in scenes]
         hand_faces = [torch.as_tensor(sc["hand_faces"], dtype=torch.int64, device=device) for sc in scenes]
@@ -251,7 +278,9 @@ class GuidedShapePipeline:
                 x1 = self.scheduler.step_final(torch.cat(noise, 0), t, latents)
                 sdf = sdf_of(x1, xyz_samples, grid_size)
                 loss = fobj(sdf, cfg)                                   # (B,): one replay for all images
-                fl = gb.flags.cpu().tolist()                            # the iteration's one read-back (NaN is bit 0 of the flags)
+                fl = gb.flags.cpu().tolist()                            # the iteration's read-back (NaN is bit 0 of the flags) ...
+                if hip_dec is not None:                                 # ... with the rows the decoder's backward will find a gradient on
+                    _bound_active_rows(self.vae, max(fobj.active_rows()))
                 go = torch.zeros(B, device=device)
                 for b in range(B):
                     if b in left:
@@ -275,6 +304,7 @@ class GuidedShapePipeline:
                 opt.step()
                 stats["inner_iterations"] += 1
             gb.raise_on_flags(strict_k=False, ignore_images=list(left))
+            _check_rows_dropped(hip_dec)
             return torch.cat([n.detach() for n in noise], 0).clone()
 
         results = [None] * B
@@ -460,6 +490,8 @@ class GuidedShapePipeline:
                     sync_state(gb, g2)
                     loss = fobj(sdf, cfg)
                     nv, nf, fl = fobj.status()[0]          # one read-back per iteration (the reference's NaN test is one, too)
+                    if getattr(self.vae, "hip_geo", None) is not None:
+                        _bound_active_rows(self.vae, fobj.active_rows()[0])
                     if fl & 64:                            # empty iso-surface (PL:1394-1397, 1511-1513)
                         print("Invalid mesh detected, aborting step!")
                         stats["skipped_empty"] += 1
@@ -477,6 +509,7 @@ class GuidedShapePipeline:
                         print("Invalid mesh detected, aborting step!")
                         stats["skipped_empty"] += 1
                         continue
+                    _bound_active_rows(self.vae, xyz_samples.shape[0])     # the exact-size path: no count known before the backward -- all rows
                     loss = gb.objective(verts, faces, cfg)
                     stats["exact_size_iterations"] = stats.get("exact_size_iterations", 0) + 1
                 stats["inner_iterations"] += 1
@@ -500,6 +533,7 @@ class GuidedShapePipeline:
                 if cur is not gb:
                     sync_state(cur, gb)
             gb.raise_on_flags(strict_k=False)
+            _check_rows_dropped(getattr(self.vae, "hip_geo", None))
             param_log.append((phase, i, gb.params[0].detach().clone(), noise_pred.detach().clone()))
             if on_phase_end is not None:
                 on_phase_end(phase, i, gb)
