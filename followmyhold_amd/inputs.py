@@ -410,7 +410,7 @@ class MeshGuidanceRunner:
         self.config = config if config is not None else E.OptimizationConfig()
         self.device = device
         self.in_flight = max(1, int(in_flight))
-        # at most four streams (HIP has four hardware queues, NOTEBOOK.md section 6), at least two images per stream; measured for
+        # at most four streams (HIP has four hardware queues, docs/NOTEBOOK_r1-3.md section 6), at least two images per stream; measured for
         # whole jobs: 116 images/s at 8 in flight (4 x 2, the setting bench.py's `batched` record uses), 160 at 16 (4 x 4)
         self.n_streams = int(n_streams) if n_streams else max(1, min(4, (self.in_flight + 1) // 2))
         self.per_slot = (self.in_flight + self.n_streams - 1) // self.n_streams
