@@ -495,3 +495,37 @@ def test_full_grid_forward_and_backward_against_fp32_torch_and_sparse_against_de
     assert sc > 0 and (kv_rows - kv_dense).abs().max().item() <= 1e-3 * sc and cos >= 1 - 1e-6, ((kv_rows - kv_dense).abs().max().item(), sc, cos)
     cos = torch.nn.functional.cosine_similarity(g_rows.flatten(), gref_s.flatten(), dim=0).item()
     assert (g_rows - gref_s).abs().max().item() <= 1e-2 * gref_s.abs().max().item() and cos >= 1 - 1e-4
+
+
+@gpu
+def test_active_row_backward_is_graph_capturable():
+    """foho_geo_decode_bwd_rows has no host synchronisation -- the number of active rows never leaves the device --, so one captured
+    hipGraph serves gradients with ANY number of active rows: captured once, replayed with three different sparsity patterns (and an
+    all-zero gradient), each replay equal to the eager call on the same gradient, bit for bit."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(256, 4, 256)
+    g = torch.Generator().manual_seed(21)
+    lat = torch.randn(1, 256, 256, generator=g).half().cuda()
+    n_q = 9000
+    q = (torch.rand(1, n_q, 3, generator=g) * 2.2 - 1.1).half().float().cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)
+    hip.set_kv(hip.kv_of(lat).detach())
+    grads = []
+    for fill in (0.03, 0.4, 0.0, 1.0):
+        go = torch.randn(n_q, generator=g)
+        grads.append(torch.where(torch.rand(n_q, generator=g) < fill, go, torch.zeros(())).cuda())
+    eager = [hip.decode_bwd_rows(q, gg).clone() for gg in grads]
+    counts = [int((gg != 0).sum()) for gg in grads]
+    g_static = grads[0].clone()
+    hip.decode_bwd_rows(q, g_static)                    # warm-up outside the capture (workspaces allocated)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_static = hip.decode_bwd_rows(q, g_static)
+        stats_static = hip.last_row_stats
+    for gg, ref, n_act in zip(grads, eager, counts):
+        g_static.copy_(gg)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert stats_static.tolist() == [n_act, 0]
+        assert torch.equal(out_static, ref), n_act

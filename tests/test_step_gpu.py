@@ -510,3 +510,22 @@ def test_knn_role_ties_keep_lowest_index(layout):
         assert np.array_equal(idx, first[src[idx]])         # never the later copy
         out[name] = idx
     assert all(np.array_equal(out["decode kernel"], v) for v in out.values())
+
+
+@gpu
+def test_a_batch_refuses_images_with_different_joint_regressors():
+    """foho_step_desc.J_regressor is ONE regressor per batch: an image that brings another one is refused when the batch is built
+    (it would silently be regressed with the first image's) -- and again when a capacity-mode batch is re-loaded."""
+    from followmyhold_amd import _lib as L, engine as E
+    from helpers import make_scene
+    a = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in make_scene("ico2", 64, 64, seed=0).items()}
+    b = dict(a)
+    b["J_regressor"] = np.asarray(a["J_regressor"]).copy()
+    b["J_regressor"][3, 10] += 0.25
+    E.GuidanceBatch([a, dict(a)], grid_res=16)                          # equal regressors: fine
+    with pytest.raises(L.FohoError):
+        E.GuidanceBatch([a, b], grid_res=16)
+    gb = E.GuidanceBatch([a, dict(a)], grid_res=16, obj_capacity=(4096, 8192))
+    if gb.fits([a, b]):
+        with pytest.raises(L.FohoError):
+            gb.load_scenes([a, b])
