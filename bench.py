@@ -984,7 +984,8 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         def one4():
             noise4.grad = None
             torch.cuda.synchronize(dev); a = time.perf_counter()
-            pred = vae((1 / vae.scale_factor) * (lat4 + 0.1 * noise4))
+            with PLN.vae_attention_backend():
+                pred = vae((1 / vae.scale_factor) * (lat4 + 0.1 * noise4))
             sdf4 = torch.stack([-hip(hip.grid_queries(xyz), pred[b:b + 1]).view(-1).float() for b in range(B4)], 0)
             loss = obj4(sdf4, cfg)
             gb4.flags.cpu()

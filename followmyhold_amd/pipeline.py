@@ -35,11 +35,29 @@ from .facade import Meshes, TexturesVertex, generate_dense_grid_points, quaterni
 from .scheduler import retrieve_timesteps
 
 
+def vae_attention_backend():
+    """Context for the ShapeVAE transformer's forward (and the backward recorded under it): torch's scaled_dot_product_attention with
+    the memory-efficient kernel FIRST.  At the transformer's shape -- (1, 16 heads, 3072 tokens, 64) fp16, sixteen layers, run and
+    back-propagated in every inner iteration (PL:295, 1391-1393, 1507-1509) -- ROCm's default (flash, AOTriton) backend takes 509 us
+    per layer forward + backward on an MI355X, the efficient one 350 us (scripts/dev_sdpa.py): 2.5 ms of a 26 ms iteration.  The
+    other backends stay allowed behind it (a shape the efficient kernel does not take falls through); FOHO_VAE_SDPA=default leaves
+    torch's own choice alone."""
+    import contextlib
+    if os.environ.get("FOHO_VAE_SDPA", "efficient") != "efficient" or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    try:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        return sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True)
+    except (ImportError, TypeError):       # an older torch without the priority form: its own choice
+        return contextlib.nullcontext()
+
+
 def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     """PL:292-338 (return_mesh=False): rescale the latent, run the VAE transformer, query the geometry decoder in chunks of
     8000 grid points, negate the logits so that the field is negative inside.  -> (1, G, G, G) float32."""
     pred = 1 / vae.scale_factor * pred
-    pred = vae(pred)
+    with vae_attention_backend():
+        pred = vae(pred)
     hip = getattr(vae, "hip_geo", None)          # geo_decode.install(vae): the decoder on the matrix cores
     if hip is not None:
         # all grid points in one call, no 8000-query chunks; under autograd (PL:1391-1393, 1507-1509) the gradient reaches
@@ -247,7 +265,8 @@ class GuidedShapePipeline:
 
         def sdf_of(x1, xyz, gsz):
             """latent2sdf (PL:292-313) for B latents: the VAE transformer on all of them, the geometry decoder per image."""
-            pred = self.vae(1 / self.vae.scale_factor * x1)
+            with vae_attention_backend():
+                pred = self.vae(1 / self.vae.scale_factor * x1)
             out = []
             hip = getattr(self.vae, "hip_geo", None)
             for b in range(x1.shape[0]):
