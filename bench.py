@@ -486,6 +486,7 @@ def main():
                             ("closeup", lambda: closeup_record(E, torch, np, synthetic, render_fn, args, dev, cfg)),
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("geo_decode", lambda: geo_decode_record(torch, dev)),
+                            ("vae_attention", lambda: vae_attention_record(torch, dev)),
                             ("icp", lambda: icp_record(torch, np, dev)),
                             ("lbs", lambda: lbs_record(torch, np, synthetic, dev)),
                             ("pipeline_iteration", lambda: pipeline_iteration_record(E, torch, scenes[0], dev)),
@@ -560,10 +561,13 @@ def headline(out):
         ic = out.get("icp") or {}
         if "hip_ms" in ic:
             sec["icp"] = {"ms": _r(ic["hip_ms"]), "cpu_ms": _r(ic.get("cpu_ms_extrapolated"))}
+        va = out.get("vae_attention") or {}
+        if "torch_efficient" in va:
+            sec["vae_attn_fb_us"] = {k.replace("torch_", ""): _r(get(va, k, "forward_backward_us"), 3) for k in ("torch_default", "torch_efficient", "hip")}
         lb = out.get("lbs") or {}
         if "b8192" in lb:
             sec["lbs"] = {"b1_us": _r(get(lb, "b1", "fwd_bwd_us")), "b8192_frac": _r(get(lb, "b8192", "poseblend_frac_of_fp32_matrix_peak"), 3)}
-        for k in ("geo_decode", "pipeline_iteration", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs"):
+        for k in ("geo_decode", "pipeline_iteration", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs", "vae_attention"):
             if isinstance(out.get(k), dict) and "error" in out[k]:
                 sec[k] = {"error": out[k]["error"][:60]}
         if sec:
@@ -1013,6 +1017,54 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     out["what"] = ("latent -> 16-layer VAE transformer (torch) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
                    "step -> backward to the noise prediction; stand-in networks of the Hunyuan3D-2 shape, fp16")
     return out
+
+
+def vae_attention_record(torch, dev):
+    """The self-attention of the ShapeVAE transformer inside latent2sdf (PL:295: sixteen layers over 3072 tokens, 16 heads of 64, forward
+    and backward in every inner iteration) at its shape (1, 16, 3072, 64) fp16: torch's scaled_dot_product_attention on its default
+    (flash) backend, on the memory-efficient backend `pipeline.vae_attention_backend()` prefers, and this repository's kernels
+    (followmyhold_amd.sdpa: k_geo_attn / k_geo_attn_bwd / k_geo_attn_dq, opt-in with FOHO_VAE_SDPA=hip) -- microseconds per layer."""
+    import torch.nn.functional as F
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    from followmyhold_amd import sdpa
+    q, k, v = (torch.randn(1, 16, 3072, 64, device=dev, dtype=torch.float16, requires_grad=True) for _ in range(3))
+    go = torch.randn(1, 16, 3072, 64, device=dev, dtype=torch.float16)
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e6
+
+    def torch_fn(backend):
+        def call():
+            if backend is None:
+                return F.scaled_dot_product_attention(q, k, v)
+            with sdpa_kernel(backend):
+                return F.scaled_dot_product_attention(q, k, v)
+        return call
+
+    rec = {"shape": "(1, 16, 3072, 64) fp16", "unit": "us per layer", "gflop_forward": 4 * 16 * 3072 * 3072 * 64 / 1e9}
+    for name, fn in (("torch_default", torch_fn(None)), ("torch_efficient", torch_fn(SDPBackend.EFFICIENT_ATTENTION)), ("hip", lambda: sdpa.attention(q, k, v))):
+        def fwd():
+            with torch.no_grad():
+                return fn()
+        def fb():
+            for t in (q, k, v):
+                t.grad = None
+            fn().backward(go)
+        try:
+            rec[name] = {"forward_us": timed(fwd), "forward_backward_us": timed(fb)}
+        except Exception as e:  # noqa: BLE001
+            rec[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    with torch.no_grad():
+        ref = torch_fn(SDPBackend.MATH)().float()
+        rec["hip_max_abs_diff_vs_torch_math"] = float((sdpa.attention(q, k, v).float() - ref).abs().max())
+    return rec
 
 
 def icp_record(torch, np, dev):

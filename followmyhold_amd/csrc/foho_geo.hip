@@ -968,12 +968,24 @@ __global__ void k_geo_knorm(h16* __restrict__ KV, int ldkv, int L, int heads, co
 // V half of the KV projection (L rows, row stride ldkv, columns width + head*64 + d) -> Vt[head][d][pos(l)]: within every
 // block of 16 keys, key kq goes to position (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1) (keys 4-7 and 8-11 swap places):
 // the order in which a lane of the P^T fragment holds its 8 keys (C layout of the 32x32 MFMA: rows (r & 3) + 8 (r >> 2) + 4 hi).
-__global__ void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt) {
+__global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt, int col0 = -1) {
+    // one thread per (column, block of 16 keys): sixteen strided reads (coalesced across the threads of a wave: consecutive columns),
+    // one 32-byte row segment written in the permuted order.  (One thread per ELEMENT, 3072 x 1024 two-byte stores, took 19 us.)
     const int c = blockIdx.x * 256 + threadIdx.x;  // head * 64 + d
-    const int l = blockIdx.y;
+    const int l0 = blockIdx.y * 16;
     if (c >= width) return;
-    const int kq = l & 15, pos = (l & ~15) | (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1);
-    Vt[(size_t)c * L + pos] = KV[(size_t)l * ldkv + width + c];
+    const h16* src = KV + (size_t)l0 * ldkv + (col0 < 0 ? width : col0) + c;   // col0: first column of the half to transpose (default: the V half)
+    half8 lo, hi8;
+#pragma unroll
+    for (int pos = 0; pos < 16; pos++) {
+        const int kq = (pos & 3) | ((pos & 4) << 1) | ((pos & 8) >> 1);   // the permutation is an involution: position pos holds key kq
+        const h16 v = src[(size_t)kq * ldkv];
+        if (pos < 8) lo[pos] = v;
+        else hi8[pos - 8] = v;
+    }
+    h16* dst = Vt + (size_t)c * L + l0;
+    *reinterpret_cast<half8*>(dst) = lo;
+    *reinterpret_cast<half8*>(dst + 8) = hi8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1226,6 +1238,162 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
             *reinterpret_cast<f32x4*>(dst) = v;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ of an attention (round 5: the self-attention layers of the ShapeVAE transformer in front of the decoder -- latent2sdf runs and
+// back-propagates sixteen of them in every inner iteration, PL:295, 1391-1393, 1507-1509; in the decoder's own cross attention the
+// queries are grid points and have no gradient).   S = Qs K^T (log2 domain), P = exp2(S - lse), dP = dO V^T, dS = P (dP - delta),
+// dQ = dS K / 8.  The mirror image of k_geo_attn: a workgroup = 4 waves x 32 queries of ONE head, the queries stay in the lanes
+// (Qs and dO fragments in registers), 64-key tiles stream through LDS -- K rows and V rows (A operands of S^T = K Qs^T and
+// dP^T = V dO^T: a lane owns a query, so -lse and -delta are the accumulators' initial values) and K^T (transposed, key-permuted
+// like V^T in the forward: A operand of dQ^T += K^T dS^T, whose B operand is the dS^T accumulator itself, packed to fp16).
+// Tiles by LDS-DMA (buffer_load ... lds), two buffers.
+// ------------------------------------------------------------------------------------------------
+constexpr int DQQ = 128;   // queries per workgroup of k_geo_attn_dq
+__global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ Qs, const h16* __restrict__ dO, int ldq, const h16* __restrict__ KV,
+                                                        int ldkv, int width, const h16* __restrict__ Kt, int L, const float* __restrict__ nlse,
+                                                        const float* __restrict__ ndelta, h16* __restrict__ dQ, int M, int heads) {
+    __shared__ uint4 lds[2][3][AK * 8];  // [buffer][K | V | K^T][64 rows x 8 chunks] = 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int head, qblk;
+    if ((heads & 7) == 0) {
+        const int hpx = heads >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        head = xcd * hpx + j % hpx;
+        qblk = j / hpx;
+    } else {
+        head = blockIdx.x % heads;
+        qblk = blockIdx.x / heads;
+    }
+    if (qblk * DQQ >= M) return;
+    const int q0 = qblk * DQQ + w * 32;   // 32 queries per wave: two query blocks' fragments + accumulators do not fit 256 registers
+
+    half8 qf[1][4], dof[1][4];  // B operands: lane (q, hi) holds Qs / dO [q][16 kk + 8 hi .. + 7]
+    float nl[1], nd[1];
+#pragma unroll
+    for (int qb = 0; qb < 1; qb++) {
+        const int row = min(q0 + qb * 32 + l31, M - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            qf[qb][kk] = *reinterpret_cast<const half8*>(Qs + (size_t)row * ldq + head * 64 + 16 * kk + 8 * hi);
+            dof[qb][kk] = *reinterpret_cast<const half8*>(dO + (size_t)row * ldq + head * 64 + 16 * kk + 8 * hi);
+        }
+        nl[qb] = nlse[(size_t)row * heads + head];
+        nd[qb] = ndelta[(size_t)row * heads + head];
+    }
+    // DMA: per key tile every wave brings pieces 2 w and 2 w + 1 (8 rows x 128 bytes each) of each of the three tiles
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int c0 = (sslot ^ ((srow >> 1) & 7)) << 3, c1 = (sslot ^ ((4 + (srow >> 1)) & 7)) << 3;
+    const int vk0 = (srow * ldkv + c0) * 2, vk1 = (srow * ldkv + c1) * 2, vt0 = (srow * L + c0) * 2, vt1 = (srow * L + c1) * 2;
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)KV, (short)0, (int)min((size_t)L * ldkv * 2, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rkt = __builtin_amdgcn_make_buffer_rsrc((void*)Kt, (short)0, (int)min((size_t)width * L * 2, (size_t)0x7fffffff), 0x00020000);
+    const int r0 = 16 * w, r1 = 16 * w + 8;   // tile rows of this wave's two pieces
+    const int sk = head * 64 * 2, sv = (width + head * 64) * 2, skt = head * 64 * L * 2;
+#define DQ_ISSUE(t, buf)                                                                         \
+    do {                                                                                         \
+        const int kb_ = (t) * AK;                                                                \
+        dma16(rkv, &lds[buf][0][r0 * 8], vk0, sk + (kb_ + r0) * ldkv * 2);                       \
+        dma16(rkv, &lds[buf][0][r1 * 8], vk1, sk + (kb_ + r1) * ldkv * 2);                       \
+        dma16(rkv, &lds[buf][1][r0 * 8], vk0, sv + (kb_ + r0) * ldkv * 2);                       \
+        dma16(rkv, &lds[buf][1][r1 * 8], vk1, sv + (kb_ + r1) * ldkv * 2);                       \
+        dma16(rkt, &lds[buf][2][r0 * 8], vt0, skt + (r0 * L + kb_) * 2);                         \
+        dma16(rkt, &lds[buf][2][r1 * 8], vt1, skt + (r1 * L + kb_) * 2);                         \
+    } while (0)
+
+    f32x16 dq[1][2];  // [query block][d tile]: dQ^T, rows d, columns q
+#pragma unroll
+    for (int a = 0; a < 1; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dq[a][b][r] = 0.0f;
+    const unsigned lbase = lds_addr(&lds[0][0][0]);
+    unsigned ak[4], at_[2][2];   // fragment addresses in buffer 0: K / V rows (row = key), K^T rows (row = d)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) ak[kk] = lbase + l31 * 128 + (((2 * kk + hi) ^ swz(l31)) << 4);
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) at_[sub][k2] = lbase + l31 * 128 + (((4 * sub + 2 * k2 + hi) ^ swz(l31)) << 4);
+
+    const int nt = L / AK;
+    DQ_ISSUE(0, 0);
+    for (int t = 0; t < nt; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile t has landed for every wave, and everybody is done reading the other buffer
+        if (t + 1 < nt) {
+            if (t & 1) DQ_ISSUE(t + 1, 0);
+            else DQ_ISSUE(t + 1, 1);
+        }
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(t & 1) * (3u * AK * 8u * 16u);   // 24 KB per buffer
+#define DQ_SUB(SUB)                                                                                                                  \
+        do {                                                                                                                         \
+            half8 kf[4], vf[4], ktf[2][2];                                                                                           \
+            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                       \
+                GEO_DSR(kf[kk], ak[kk] + bo, (SUB) * 4096);          /* rows SUB * 32 + l31 (same swizzle: 32 rows = 4 x 8) */          \
+                GEO_DSR(vf[kk], ak[kk] + bo, 8192 + (SUB) * 4096);                                                                   \
+            }                                                                                                                        \
+            _Pragma("unroll") for (int k2 = 0; k2 < 2; k2++) {                                                                       \
+                GEO_DSR(ktf[0][k2], at_[SUB][k2] + bo, 16384);                                                                       \
+                GEO_DSR(ktf[1][k2], at_[SUB][k2] + bo, 16384 + 4096);                                                                \
+            }                                                                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                      \
+                         : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]),      \
+                           "+v"(ktf[0][0]), "+v"(ktf[0][1]), "+v"(ktf[1][0]), "+v"(ktf[1][1]));                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                       \
+            _Pragma("unroll") for (int qb = 0; qb < 1; qb++) {                                                                       \
+                f32x16 sc, dp;                                                                                                       \
+                _Pragma("unroll") for (int r = 0; r < 16; r++) sc[r] = nl[qb], dp[r] = nd[qb];                                       \
+                _Pragma("unroll") for (int kk = 0; kk < 4; kk++) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], sc, 0, 0, 0);   \
+                _Pragma("unroll") for (int kk = 0; kk < 4; kk++) dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kk], dof[qb][kk], dp, 0, 0, 0);  \
+                half8 dsf[2];                                                                                                        \
+                _Pragma("unroll") for (int k2 = 0; k2 < 2; k2++)                                                                     \
+                    _Pragma("unroll") for (int e = 0; e < 8; e += 2) {                                                               \
+                        const f32x2 dd = {ex2(sc[8 * k2 + e]) * dp[8 * k2 + e], ex2(sc[8 * k2 + e + 1]) * dp[8 * k2 + e + 1]};        \
+                        const half2v dh = __builtin_convertvector(dd, half2v);                                                       \
+                        dsf[k2][e] = dh[0], dsf[k2][e + 1] = dh[1];                                                                  \
+                    }                                                                                                                \
+                _Pragma("unroll") for (int dt = 0; dt < 2; dt++)                                                                     \
+                    _Pragma("unroll") for (int k2 = 0; k2 < 2; k2++)                                                                 \
+                        dq[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf[dt][k2], dsf[k2], dq[qb][dt], 0, 0, 0);              \
+                __builtin_amdgcn_sched_barrier(0);   /* one query block at a time: two sets of scores do not fit the register file */    \
+            }                                                                                                                        \
+        } while (0)
+        DQ_SUB(0);
+        DQ_SUB(1);
+#undef DQ_SUB
+    }
+#undef DQ_ISSUE
+    // ---- store: the lane holds, for ONE query, d = 32 dt + 8 g + 4 hi + (0..3); dQ = dS K / 8
+#pragma unroll
+    for (int qb = 0; qb < 1; qb++) {
+        const int row = q0 + qb * 32 + l31;
+        if (row < M) {
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    half4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (h16)(dq[qb][dt][4 * g + e] * 0.125f);
+                    *reinterpret_cast<half4*>(dQ + (size_t)row * ldq + head * 64 + dt * 32 + 8 * g + 4 * hi) = v;
+                }
+        }
+    }
+}
+
+// X (M rows, W columns) -> XT[c][pos(m)] (row length ldt), pos = m with bits 2 and 3 of (m & 15) swapped: the transposed copies
+// k_geo_attn_bwd reads (what the GEMM epilogue EP_TRANS writes inside the decoder); columns beyond M are left alone (cleared by the caller)
+__global__ __launch_bounds__(256) void k_geo_transpose_perm(const h16* __restrict__ X, int ldx, int M, int W, h16* __restrict__ XT, int ldt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int m = i % M, c8 = i / M;
+    if (c8 * 8 >= W) return;
+    const half8 v = *reinterpret_cast<const half8*>(X + (size_t)m * ldx + c8 * 8);
+    const int pm = (m & ~15) | (m & 3) | ((m & 4) << 1) | ((m & 8) >> 1);
+#pragma unroll
+    for (int e = 0; e < 8; e++) XT[(size_t)(c8 * 8 + e) * ldt + pm] = v[e];
 }
 
 // grad_kv = sum over the splits of k_geo_attn_bwd's partial sums (fixed order: bitwise repeatable)
@@ -1650,7 +1818,7 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
     if (!launch_ok("k_geo_ln(kv)")) return FOHO_ERR_LAUNCH;
     if (int rc = gemm(0, ln, W, (const h16*)w->w_kv, W, w->b_kv, nullptr, 0, kv, 2 * W, Lr, 2 * W, W, 1.0f, s)) return rc;
     if (w->k_norm) hipLaunchKernelGGL(k_geo_knorm, dim3((Lr * w->heads + 255) / 256), dim3(256), 0, s, kv, 2 * W, Lr, w->heads, w->k_norm);
-    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr / 16), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
     return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
@@ -1836,7 +2004,7 @@ extern "C" int foho_geo_set_kv(const foho_geo_weights* w, const void* kv_in, int
     h16 *kv = (h16*)(base + l.kv), *vt = (h16*)(base + l.vt);
     const int W = w->width, Lr = w->n_latents;
     if (hipMemcpyAsync(kv, kv_in, (size_t)Lr * 2 * W * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(FOHO_ERR_LAUNCH, "foho_geo_set_kv: copy failed");
-    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr / 16), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
     return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
@@ -2055,6 +2223,92 @@ extern "C" int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* 
     return launch_ok("k_geo_dkv_reduce") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
+// ---- Attention as an operator of its own, forward and backward (round 5): O = softmax(Q K^T / 8) V per head of 64, what
+// torch.nn.functional.scaled_dot_product_attention computes for the self-attention layers of the ShapeVAE transformer that latent2sdf
+// runs in front of the decoder (PL:295; sixteen layers of 3072 tokens x 16 heads, forward and backward in every inner iteration).
+// The forward is the decoder's k_geo_attn, dK / dV its k_geo_attn_bwd, dQ k_geo_attn_dq.
+struct SdpaLayout {
+    size_t vt, kt, qst, dot, delta, part, total;
+    int ldt, splits;
+};
+static SdpaLayout sdpa_layout(int M, int L, int heads) {
+    SdpaLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t W = (size_t)heads * 64;
+    l.ldt = (M + 63) & ~63;
+    l.vt = take(W * L * 2);
+    l.kt = take(W * L * 2);
+    l.qst = take(W * (size_t)l.ldt * 2);
+    l.dot = take(W * (size_t)l.ldt * 2);
+    l.delta = take((size_t)l.ldt * heads * 4);
+    const int ntiles = (M + 63) / 64, base = std::max(1, (L / 128) * heads);
+    l.splits = std::max(1, std::min((1024 + base - 1) / base, ntiles));
+    l.part = take((size_t)l.splits * L * 2 * W * 4);
+    l.total = off;
+    return l;
+}
+static int sdpa_args(const char* who, int M, int L, int heads, bool bwd) {
+    if (M < 1 || L < 64 || L % 64 || heads < 1 || heads > 16) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": M >= 1, L a multiple of 64, 1..16 heads of 64");
+    if (bwd && L % 128) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": L must be a multiple of 128");
+    if ((size_t)L * heads * 128 * 2 >= ((size_t)1 << 31)) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": K / V too large for 32-bit buffer offsets");
+    return FOHO_OK;
+}
+extern "C" size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads) {
+    if (sdpa_args("foho_sdpa_workspace_bytes", M, L, heads, false) != FOHO_OK) return 0;
+    return sdpa_layout(M, L, heads).total;
+}
+extern "C" int foho_sdpa_fwd(const void* q_scaled, const void* kv, void* out, float* nlse, int32_t M, int32_t L, int32_t heads, void* ws, size_t ws_bytes,
+                             void* stream_) {
+    if (int rc = sdpa_args("foho_sdpa_fwd", M, L, heads, false)) return rc;
+    if (!q_scaled || !kv || !out || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_fwd: null argument");
+    const SdpaLayout l = sdpa_layout(M, L, heads);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_sdpa_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = heads * 64;
+    h16* vt = (h16*)((char*)ws + l.vt);
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, (const h16*)kv, 2 * W, W, L, vt, -1);
+    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)q_scaled, W, (const h16*)kv, 2 * W, (const h16*)vt, L, (h16*)out, W,
+                       M, heads, nlse, (const int*)nullptr);
+    return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+extern "C" int foho_sdpa_bwd(const void* q_scaled, const void* kv, const void* out, const float* nlse, const void* grad_out, void* grad_q, float* grad_kv,
+                             int32_t M, int32_t L, int32_t heads, void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = sdpa_args("foho_sdpa_bwd", M, L, heads, true)) return rc;
+    if (!q_scaled || !kv || !out || !nlse || !grad_out || !grad_q || !grad_kv || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_bwd: null argument");
+    const SdpaLayout l = sdpa_layout(M, L, heads);
+    if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_sdpa_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const int W = heads * 64;
+    char* base = (char*)ws;
+    h16 *kt = (h16*)(base + l.kt), *qst = (h16*)(base + l.qst), *dot = (h16*)(base + l.dot);
+    float *delta = (float*)(base + l.delta), *part = (float*)(base + l.part);
+    const h16 *Qs = (const h16*)q_scaled, *dO = (const h16*)grad_out, *KV = (const h16*)kv;
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, KV, 2 * W, W, L, kt, 0);      // K^T, key-permuted
+    if (M & 63) {   // columns of the transposed copies beyond M meet P = 0 and must be finite
+        const size_t n16 = (size_t)W * l.ldt * 2 / 16;
+        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)qst, n16);
+        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dot, n16);
+    }
+    const unsigned tb = (unsigned)(((size_t)M * (W / 8) + 255) / 256);
+    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, Qs, W, M, W, qst, l.ldt);
+    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, dO, W, M, W, dot, l.ldt);
+    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), dim3(256), 0, s, dO, (const h16*)out, W, heads, M, delta, (const int*)nullptr);
+    if (!launch_ok("foho_sdpa_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
+    const int nkb = L / 128;
+    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((heads * l.splits + 7) / 8) * nkb), dim3(256), 0, s, Qs, (const h16*)qst, dO, (const h16*)dot, l.ldt, nlse, (const float*)delta,
+                       KV, 2 * W, W, heads, M, l.splits, L, 0, part, (const int*)nullptr);
+    const size_t n4 = (size_t)L * 2 * W / 4;
+    hipLaunchKernelGGL(k_geo_dkv_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, l.splits, n4, grad_kv);
+    hipLaunchKernelGGL(k_geo_attn_dq, dim3(((M + DQQ - 1) / DQQ) * heads), dim3(256), 0, s, Qs, dO, W, KV, 2 * W, W, (const h16*)kt, L, nlse, (const float*)delta,
+                       (h16*)grad_q, M, heads);
+    return launch_ok("k_geo_attn_dq") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
+
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
 extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
                              int32_t gelu, float scale, void* stream) {
@@ -2073,7 +2327,7 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
     if (!Q || !KV || !Vt_scratch || !O || heads <= 0 || n_latents <= 0 || n_latents % 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo_attention: bad argument");
     const int W = heads * 64;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents / 16), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,

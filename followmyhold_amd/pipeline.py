@@ -39,17 +39,25 @@ def vae_attention_backend():
     """Context for the ShapeVAE transformer's forward (and the backward recorded under it): torch's scaled_dot_product_attention with
     the memory-efficient kernel FIRST.  At the transformer's shape -- (1, 16 heads, 3072 tokens, 64) fp16, sixteen layers, run and
     back-propagated in every inner iteration (PL:295, 1391-1393, 1507-1509) -- ROCm's default (flash, AOTriton) backend takes 509 us
-    per layer forward + backward on an MI355X, the efficient one 350 us (scripts/dev_sdpa.py): 2.5 ms of a 26 ms iteration.  The
-    other backends stay allowed behind it (a shape the efficient kernel does not take falls through); FOHO_VAE_SDPA=default leaves
-    torch's own choice alone."""
+    per layer forward + backward on an MI355X, the efficient one 350 us (scripts/dev_sdpa.py): 3 ms of a 26 ms iteration.  The
+    other backends stay allowed behind it (a shape the efficient kernel does not take falls through).
+    FOHO_VAE_SDPA=default leaves torch's own choice alone; FOHO_VAE_SDPA=hip sends the eligible calls to this repository's attention
+    kernels instead (followmyhold_amd.sdpa: forward 63 us, backward 170 us of kernels per layer, but 380 us with the layout copies around
+    them -- measured no faster than the efficient backend at 3072 tokens, hence not the default)."""
     import contextlib
-    if os.environ.get("FOHO_VAE_SDPA", "efficient") != "efficient" or not torch.cuda.is_available():
+    mode = os.environ.get("FOHO_VAE_SDPA", "efficient")
+    if mode not in ("efficient", "hip") or not torch.cuda.is_available():
         return contextlib.nullcontext()
+    stack = contextlib.ExitStack()
     try:
         from torch.nn.attention import SDPBackend, sdpa_kernel
-        return sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True)
+        stack.enter_context(sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True))
     except (ImportError, TypeError):       # an older torch without the priority form: its own choice
-        return contextlib.nullcontext()
+        pass
+    if mode == "hip":
+        from . import sdpa
+        stack.enter_context(sdpa.hip_sdpa())
+    return stack
 
 
 def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):

@@ -487,6 +487,20 @@ size_t foho_geo_rows_workspace_bytes(int64_t n_queries, int64_t row_cap, int32_t
 int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
                              int64_t row_cap, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace,
                              size_t bwd_workspace_bytes, void* rows_workspace, size_t rows_workspace_bytes, int32_t* stats_out, void* stream);
+/* Attention as an operator, forward and backward (version 104): O = softmax(Q K^T / sqrt(64)) V per head of 64 -- what
+ * torch.nn.functional.scaled_dot_product_attention computes (no mask, no dropout) for the self-attention layers of the ShapeVAE
+ * transformer that latent2sdf runs and back-propagates in front of the geometry decoder in every inner iteration (PL:295, 1391-1393,
+ * 1507-1509).  The kernels are the decoder's own (k_geo_attn; k_geo_attn_bwd for dK / dV) plus k_geo_attn_dq.  One (batch item, all
+ * heads) per call.  q_scaled (M, 64 heads) fp16 = q x log2(e) / 8 with a row's heads side by side; kv (L, 128 heads) fp16 = [K of all
+ * heads | V of all heads] per key row; out (M, 64 heads) fp16; nlse ((M rounded up to 64), heads) fp32, written by the forward and
+ * handed back to the backward (minus the log2 of the softmax denominator); grad_out (M, 64 heads) fp16; grad_q (M, 64 heads) fp16 =
+ * d / d q (the UNSCALED q); grad_kv (L, 128 heads) fp32.  L a multiple of 64 (128 for the backward), 1..16 heads.  followmyhold_amd.sdpa
+ * wraps them as an autograd function and can stand in for F.scaled_dot_product_attention inside a context. */
+size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads);
+int foho_sdpa_fwd(const void* q_scaled, const void* kv, void* out, float* nlse, int32_t M, int32_t L, int32_t heads, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int foho_sdpa_bwd(const void* q_scaled, const void* kv, const void* out, const float* nlse, const void* grad_out, void* grad_q, float* grad_kv,
+                  int32_t M, int32_t L, int32_t heads, void* workspace, size_t workspace_bytes, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.

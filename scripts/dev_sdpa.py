@@ -27,3 +27,16 @@ for name, be in (("flash", SDPBackend.FLASH_ATTENTION), ("efficient", SDPBackend
         print(f"{name:10s}: forward {tf:7.1f} us = {fl / tf / 1e6:5.0f} TFLOP/s   forward + backward {tb:7.1f} us = {3.5 * fl / tb / 1e6:5.0f} TFLOP/s", flush=True)
     except Exception as e:
         print(name, "failed:", type(e).__name__, str(e)[:200], flush=True)
+# ... and the HIP kernels (followmyhold_amd.sdpa) at the same shape
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from followmyhold_amd import sdpa
+def hfwd():
+    with torch.no_grad():
+        return sdpa.attention(q, k, v)
+def hfb():
+    for t in (q, k, v): t.grad = None
+    sdpa.attention(q, k, v).backward(go)
+tf, tb = timed(hfwd), timed(hfb)
+fl = 4 * 16 * 3072 * 3072 * 64
+print(f"{'hip':10s}: forward {tf:7.1f} us = {fl / tf / 1e6:5.0f} TFLOP/s   forward + backward {tb:7.1f} us = {3.5 * fl / tb / 1e6:5.0f} TFLOP/s", flush=True)

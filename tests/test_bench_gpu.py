@@ -144,11 +144,13 @@ def test_headline_line_stays_under_the_log_tail_with_every_side_record_present()
                         "kernel_ms": 0.0115471, "algorithmic_bytes_per_launch": 2836864, "binding": "x" * 300},
            "roofline_valu": {"frac": 0.234567, "kernels": {"k": {"a": 1}}},
            "geo_decode": {"fwd_ms": 9.3123, "roofline": {"frac": 0.39812}, "fwd_bwd_rows_ms": 11.3123, "fwd_bwd_ms": 24.6123},
-           "pipeline_iteration": {"hip_decoder": {"iteration_ms": 31.5123, "backward_ms": 14.2123}, "torch_decoder": {"iteration_ms": 116.123}, "active_row_frac": 0.04641},
+           "pipeline_iteration": {"hip_decoder": {"iteration_ms": 31.5123, "backward_ms": 14.2123}, "torch_decoder": {"iteration_ms": 116.123}, "active_row_frac": 0.04641,
+                                  "batch_of_4": {"iteration_ms": 84.6789}},
            "closeup": {"one_image": {"value": 10712.34}, "in_flight_32": {"value": 43123.4}}, "batched": {"value": 74812.3}, "obj_40k": {"value": 14512.3},
            "topology_changing": {"ms_per_step": 0.14212}, "job": {f"in_flight_{k}": {"images_per_s": 200.123} for k in (1, 8, 16, 32)},
            "driver_on_files": {"images_per_s": 112.345}, "icp": {"hip_ms": 74.123, "cpu_ms_extrapolated": 51234.5},
            "lbs": {"b1": {"fwd_bwd_us": 61.234}, "b8192": {"poseblend_frac_of_fp32_matrix_peak": 0.3812}},
+           "vae_attention": {k: {"forward_us": 137.123, "forward_backward_us": 509.123} for k in ("torch_default", "torch_efficient", "hip")},
            "cpu_baseline": {"value": 2.2812345, "unit": "guidance-steps/s", "cores": 32, "kind": "port",
                             "sample": "30 joint steps (after 1 warm-up) of the same 512x512 / 20k-face scene, oracle/step_ref.py with OpenMP C rasteriser + torch CPU autograd, 32 thread(s)"},
            "cpu_baseline_1t": {"value": 0.2012345}, "parity": {"loss_rel_err_vs_oracle": 1.2345e-7, "pix_to_face_mismatch": 0}}

@@ -1,0 +1,89 @@
+"""followmyhold_amd.sdpa: scaled-dot-product attention forward and backward on the geometry decoder's attention kernels (the
+self-attention of the ShapeVAE transformer inside latent2sdf, PL:295) against torch's float32 math implementation."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+
+
+def test_sdpa_argument_checks_run_without_a_gpu():
+    from followmyhold_amd import _lib as L
+    lib = L.lib()
+    lib.foho_sdpa_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.foho_sdpa_workspace_bytes(3072, 3072, 16) > 2 * 1024 * 3072 * 2
+    assert lib.foho_sdpa_workspace_bytes(3072, 3000, 16) == 0            # keys not a multiple of 64
+    assert lib.foho_sdpa_workspace_bytes(3072, 3072, 17) == 0
+    lib.foho_sdpa_fwd.restype = lib.foho_sdpa_bwd.restype = ctypes.c_int
+    assert lib.foho_sdpa_fwd(None, None, None, None, 64, 128, 2, None, ctypes.c_size_t(0), None) != 0
+    one = ctypes.c_void_p(1)
+    assert lib.foho_sdpa_bwd(one, one, one, one, one, one, one, 64, 192, 2, one, ctypes.c_size_t(1 << 40), None) != 0      # 192 keys: forward only
+    from followmyhold_amd import sdpa
+    q = torch.zeros(1, 2, 8, 64)
+    assert not sdpa.eligible(q, q, q)                                    # CPU / fp32: torch's business
+
+
+@gpu
+@pytest.mark.parametrize("B,H,M,Lk", [(1, 2, 256, 256), (2, 4, 300, 384), (1, 16, 3072, 3072), (1, 16, 70, 128)])
+def test_attention_forward_and_backward_against_torch_math(B, H, M, Lk):
+    from followmyhold_amd import sdpa
+    g = torch.Generator().manual_seed(H + M)
+    q, k, v = (torch.randn(B, H, n, 64, generator=g).half().cuda() for n in (M, Lk, Lk))
+    k[:, 0, 5] *= 3.0                                                   # a key that dominates some rows
+    go = torch.randn(B, H, M, 64, generator=g).half().cuda()
+    qh, kh, vh = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = sdpa.attention(qh, kh, vh)
+    assert out.shape == (B, H, M, 64) and out.dtype == torch.float16
+    out.backward(go)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    att = torch.softmax(qr @ kr.transpose(-1, -2) / 8.0, dim=-1)
+    ref = att @ vr
+    ref.backward(go.float())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() <= 3e-3 * max(ref.abs().max().item(), 1.0)
+    for name, a, b in (("dq", qh.grad, qr.grad), ("dk", kh.grad, kr.grad), ("dv", vh.grad, vr.grad)):
+        a = a.float()
+        cos = F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 1.5e-2 * b.abs().max().item() and cos >= 1 - 2e-4, (name, (a - b).abs().max().item(), b.abs().max().item(), cos)
+    # repeatable: no atomics anywhere in the three kernels
+    q2, k2, v2 = (t.clone().requires_grad_(True) for t in (q, k, v))
+    sdpa.attention(q2, k2, v2).backward(go)
+    assert torch.equal(q2.grad, qh.grad) and torch.equal(k2.grad, kh.grad) and torch.equal(v2.grad, vh.grad)
+
+
+@gpu
+def test_hip_sdpa_context_serves_eligible_calls_and_leaves_the_rest_to_torch():
+    """Inside `with sdpa.hip_sdpa():` a module's F.scaled_dot_product_attention goes to the HIP kernels when the call is eligible (the
+    stand-in ShapeVAE transformer in fp16: forward and the gradient to its input agree with torch's) and to torch otherwise (fp32, a
+    mask); outside the context nothing is patched."""
+    from followmyhold_amd import sdpa, standins
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=256, embed_dim=8, width=128, heads=2, layers=2, num_freqs=8).cuda().half().eval()
+    vae.requires_grad_(False)
+    lat = torch.randn(1, 256, 8, device="cuda").half()
+    calls = {"n": 0}
+    orig_apply = sdpa._HipSdpaFn.apply
+    a = lat.clone().requires_grad_(True)
+    ref = vae(a)
+    ref.float().square().sum().backward()
+    b = lat.clone().requires_grad_(True)
+    with sdpa.hip_sdpa():
+        assert F.scaled_dot_product_attention is not None
+        import unittest.mock as um
+        with um.patch.object(sdpa._HipSdpaFn, "apply", side_effect=lambda *x: (calls.__setitem__("n", calls["n"] + 1), orig_apply(*x))[1]):
+            got = vae(b)
+            got.float().square().sum().backward()
+            # not eligible: float32 tensors, a mask -> torch's implementation, no error
+            x = torch.randn(1, 2, 128, 64, device="cuda")
+            F.scaled_dot_product_attention(x, x, x)
+            xh = x.half()
+            F.scaled_dot_product_attention(xh, xh, xh, attn_mask=torch.ones(128, 128, dtype=torch.bool, device="cuda"))
+    assert calls["n"] == 2                                              # the two self-attention layers, nothing else
+    assert F.scaled_dot_product_attention.__module__ != "followmyhold_amd.sdpa"
+    scale = ref.float().abs().max().item()
+    assert (got.float() - ref.float()).abs().max().item() <= 1e-2 * scale
+    ga, gb_ = a.grad.float(), b.grad.float()
+    assert F.cosine_similarity(ga.flatten(), gb_.flatten(), dim=0).item() >= 1 - 1e-3
