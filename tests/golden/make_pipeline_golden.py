@@ -143,6 +143,11 @@ def run_variant(variant, PL, SCH, OptimizationConfig, P, standins):
         stack.callback(os.chdir, cwd)
 
         net = standins.make_standin_pipeline(device="cpu", dtype=torch.float32, seed=1, **VAE_KW)
+        # the reference holds its networks with requires_grad at torch's default (GuidedShapePipeline switches it off: the guidance
+        # optimises no weight); autograd then also forms the weight gradients, through other kernels for LayerNorm / Linear whose
+        # input gradients differ in the last bit -- the committed trajectories are the reference's, so run it the reference's way
+        for m_ in (net.vae, net.model, net.conditioner):
+            m_.requires_grad_(True)
         pipe = object.__new__(PL.Hunyuan3DDiTFlowMatchingPipeline_main)
         pipe.vae, pipe.model, pipe.conditioner, pipe.image_processor = net.vae, net.model, net.conditioner, net.image_processor
         pipe.scheduler = SCH.FlowMatchEulerDiscreteScheduler()
