@@ -124,6 +124,16 @@ constexpr int EP_GELUBWD = 4, EP_SAVEZ = 8, EP_TRANS = 16;
 // part is LayerNorm-ed over them (gain / bias / eps: 129 floats passed in the R slot) BEFORE the scale, from the fp16-rounded
 // projection, the way the module normalises c_q's output per head.
 constexpr int EP_QNORM = 32;
+// LayerNorm folded into the GEMMs on either side of it (forward only; chain_latent_side explains the algebra):
+// EP_STATS (with EP_RESID): besides the output, the statistics of every output row's 64 columns of this part -- their mean and the sum
+//   of squared deviations from it, taken from the fp16-rounded values the output holds -- go to ((float*)C2)[(row * ldc2 + n0 / 64) * 2],
+//   ldc2 = N / 64 slots per row; k_geo_rowstat_finish merges a row's slots (exactly: Chan's update, no E[x^2] - mean^2).
+// EP_PREAFF (with EP_GELU): the GEMM ran on the UN-normalised rows with gamma folded into the weights; the pre-activation is
+//   rstd[m] * acc - (rstd[m] mean[m]) * s[n] + b'[n]: (rstd, rstd * mean) per row as float2 in the R slot, b' = bias[0..N), s = bias[N..2N)
+//   (ldr = N).
+// EP_LOGIT (with EP_RESID): the output itself is NOT stored; per row and part (mean, sum of squared deviations, sum of value x gw[n])
+//   go to ((float*)C2)[(row * ldc2 + n0 / 64) * 4], gw = bias[N..2N) (N = 64 ldc2): what ln_post + output_proj need of the row.
+constexpr int EP_STATS = 64, EP_PREAFF = 128, EP_LOGIT = 256;
 
 __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
     const float x = v * 0.70710678118654752f, ax = fabsf(x);
@@ -138,9 +148,64 @@ __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(
     return cdf + v * 0.3989422804014327f * g;
 }
 
+// sum over the 8 consecutive lanes that hold one row of the epilogue's read-back (all of them get it): three DPP adds -- quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror -- where __shfl_xor is three ds_bpermute round trips through the LDS pipe
+__device__ __forceinline__ float sum8(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));
+    return x;
+}
+
+// What an epilogue part reads from global memory, fetched AHEAD of its use: at one 256 x 256 tile per CU nothing hides an epilogue's
+// load round trips (1-1.5 us each under the load of the neighbouring tiles' DMA; four of them per tile -- bias and residual of two
+// parts -- were 15 % of a K = 1024 tile), so the kernels issue the column vectors and the first part's rows right after the main
+// loop and the second part's rows before they work on the first.
+struct EpiCols {   // per lane: bias (and, EP_PREAFF, the folded weights' row sums) of its 4 consecutive columns in each of the 8 groups;
+    f32x4 b[8], s[8], g0, g1;   // EP_LOGIT: gamma_post w_out of the 8 columns it reads back
+};
+struct EpiRows {   // the residual (or saved pre-activation) of the 8 rows x 8 columns it reads back; EP_PREAFF: (rstd, rstd mean) of its two rows
+    half8 r[8];
+    float rs[2], mr[2];
+};
+template <int EP>
+__device__ __forceinline__ void epi_cols(EpiCols& c, const float* __restrict__ bias, int ldr, int ldc2, int n0, int lane) {
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int nl = jn * 32 + 8 * g + 4 * hi;
+            c.b[jn * 4 + g] = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+            if (EP & EP_PREAFF) c.s[jn * 4 + g] = *reinterpret_cast<const f32x4*>(bias + ldr + n0 + nl);
+        }
+    if (EP & EP_LOGIT) {
+        const int gn = n0 + (lane & 7) * 8;
+        c.g0 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn), c.g1 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn + 4);
+    }
+}
+template <int EP>
+__device__ __forceinline__ void epi_rows(EpiRows& p, const h16* __restrict__ R, int ldr, int M, int m0, int n0, int lane) {
+    if (EP & EP_PREAFF) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int gm = min(m0 + i * 32 + (lane & 31), M - 1);
+            const float2 st = reinterpret_cast<const float2*>(R)[gm];
+            p.rs[i] = st.x, p.mr[i] = st.y;
+        }
+    }
+    if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM)) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int gm = min(m0 + q * 8 + (lane >> 3), M - 1), gn = n0 + (lane & 7) * 8;   // (rows beyond M are not stored)
+            p.r[q] = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
+        }
+    }
+}
+
 template <int EP>
 __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16& t01, const f32x16& t10, const f32x16& t11, h16* img,
-                                                const float* __restrict__ bias, const h16* __restrict__ R, int ldr, h16* __restrict__ C, int ldc,
+                                                const EpiCols& pc, const EpiRows& pr, const h16* __restrict__ R, h16* __restrict__ C, int ldc,
                                                 h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane) {
     const int hi = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -150,7 +215,7 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int nl = jn * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns (within the 64)
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+                const f32x4 b4 = pc.b[jn * 4 + g];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     const f32x16& t = jn == 0 ? (i == 0 ? t00 : t01) : (i == 0 ? t10 : t11);
@@ -162,7 +227,14 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
 #endif
 #pragma unroll
                         for (int q = 0; q < 4; q += 2) {
-                            f32x2 v = {t[4 * g + q] + b4[q], t[4 * g + q + 1] + b4[q + 1]};
+                            f32x2 v = {t[4 * g + q], t[4 * g + q + 1]};
+                            const f32x2 b2 = {b4[q], b4[q + 1]};
+                            if (EP & EP_PREAFF) {
+                                const f32x2 s2 = {pc.s[jn * 4 + g][q], pc.s[jn * 4 + g][q + 1]};
+                                v = v * pr.rs[i] + (s2 * -pr.mr[i] + b2);
+                            } else {
+                                v = v + b2;
+                            }
                             v = gelu_erf2(v) * scale;
                             const half2v h = __builtin_convertvector(v, half2v);
                             o[q] = h[0], o[q + 1] = h[1];
@@ -206,20 +278,14 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                     x[e] = (float)v[e];
                     sm += x[e];
                 }
-                sm += __shfl_xor(sm, 1);
-                sm += __shfl_xor(sm, 2);
-                sm += __shfl_xor(sm, 4);
-                const float mean = sm * (1.0f / 64.0f);
+                const float mean = sum8(sm) * (1.0f / 64.0f);
                 float sq = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     x[e] -= mean;
                     sq += x[e] * x[e];
                 }
-                sq += __shfl_xor(sq, 1);
-                sq += __shfl_xor(sq, 2);
-                sq += __shfl_xor(sq, 4);
-                const float rstd = rsqrtf(sq * (1.0f / 64.0f) + qn[128]);
+                const float rstd = rsqrtf(sum8(sq) * (1.0f / 64.0f) + qn[128]);
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (h16)((x[e] * rstd * qn[ch * 8 + e] + qn[64 + ch * 8 + e]) * scale);
                 if ((EP & EP_TRANS) && gm < M) {
@@ -228,13 +294,38 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                     for (int e = 0; e < 8; e++) C2[(size_t)(gn + e) * ldc2 + pm] = v[e];
                 }
             }
-            if (gm < M) {
-                if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM) && pass == 1) {
-                    const half8 r = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
+            if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM) && pass == 1) {
+                const half8 r = pr.r[q];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
+                for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
+            }
+            if (gm < M && !(EP & EP_LOGIT)) *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
+            if ((EP & (EP_STATS | EP_LOGIT)) && pass == 1) {   // the row's 64 (rounded) values sit in 8 consecutive lanes
+                float x[8], sm = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    x[e] = (float)v[e];
+                    sm += x[e];
                 }
-                *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
+                const float mean = sum8(sm) * (1.0f / 64.0f);
+                float sq = 0.0f, dot = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float d = x[e] - mean;
+                    sq = __builtin_fmaf(d, d, sq);
+                }
+                sq = sum8(sq);
+                if (EP & EP_LOGIT) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) dot = __builtin_fmaf(x[e], pc.g0[e], __builtin_fmaf(x[4 + e], pc.g1[e], dot));
+                    dot = sum8(dot);
+                }
+                if (ch == 0 && gm < M) {
+                    float* st = reinterpret_cast<float*>(C2);
+                    const size_t at = (size_t)gm * ldc2 + (n0 >> 6);
+                    if (EP & EP_LOGIT) *reinterpret_cast<f32x4*>(st + at * 4) = f32x4{mean, sq, dot, 0.0f};
+                    else *reinterpret_cast<float2*>(st + at * 2) = float2{mean, sq};
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is reused
@@ -352,7 +443,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
 
     // ---- epilogue (gemm_epilogue64): the staging buffers become the waves' transpose images
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
-    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, bias, R, ldr, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane);
+    EpiCols pc;
+    EpiRows pr;
+    epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
+    epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,12 +551,19 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
         }
     }
 #undef GEO_RD6
+    EpiCols pc;
+    EpiRows pr[2];
+    // (EP_PREAFF: two floats per row -- both parts' now: a wait for them behind the first part's stores would wait for the stores)
+    if (EP & EP_PREAFF) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
+    epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);
     __syncthreads();
 
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+    if (!(EP & EP_PREAFF)) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
 #pragma unroll
     for (int half = 0; half < 2; half++)
-        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, bias, R, ldr, C, ldc, C2, ldc2, M,
+        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
                             scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
 }
 
@@ -712,13 +814,21 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         g_p8[w][6] = nk;
     }
 #endif
+    // the epilogue's operands from global memory are on their way while the groups meet (the fragment registers are free now)
+    EpiCols pc;
+    EpiRows pr[2];
+    // (EP_PREAFF: two floats per row -- both parts' now: a wait for them behind the first part's stores would wait for the stores)
+    if (EP & EP_PREAFF) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
+    epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);
     if (wr == 0 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
     __syncthreads();
 
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+    if (!(EP & EP_PREAFF)) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
 #pragma unroll
     for (int half = 0; half < 2; half++)
-        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, bias, R, ldr, C, ldc, C2, ldc2, M,
+        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
                             scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
 }
 
@@ -1589,6 +1699,112 @@ __global__ __launch_bounds__(256) void k_geo_ln(const h16* __restrict__ X, int l
     }
 }
 
+// ---- LayerNorm folded into its neighbours (forward chain): the small kernels around the GEMM epilogues EP_STATS / EP_PREAFF / EP_LOGIT.
+// Merge of a row's per-part statistics (parts of 64 columns each: mean_i, M2_i = sum of squared deviations from mean_i):
+// mean = avg(mean_i), M2 = sum M2_i + 64 sum (mean_i - mean)^2 -- exact, no cancellation.
+// Sixteen lanes per row (one per part; lanes beyond nslots idle), four rows per wave: a row's parts are contiguous.
+__device__ __forceinline__ float sum16(float x) {   // over the 16 lanes of a DPP row; every lane gets it
+    x = sum8(x);
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
+}
+__device__ __forceinline__ void merge_parts(float mean_i, float m2_i, bool live, int nslots, float& mean, float& var) {
+    mean = sum16(live ? mean_i : 0.0f) / (float)nslots;
+    const float d = mean_i - mean;
+    var = sum16(live ? m2_i + 64.0f * d * d : 0.0f) / (64.0f * (float)nslots);
+}
+// out[row] = (rstd, rstd * mean) of the row whose parts c_proj's epilogue left in `stats`
+__global__ __launch_bounds__(256) void k_geo_rowstat_finish(const float* __restrict__ stats, int nslots, int M, float eps, float2* __restrict__ out,
+                                                            const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+    const bool live = row < M && part < nslots;
+    float2 st = float2{0.0f, 0.0f};
+    if (live) st = reinterpret_cast<const float2*>(stats)[(size_t)row * nslots + part];
+    float mean, var;
+    merge_parts(st.x, st.y, live, nslots, mean, var);
+    if (live && part == 0) {
+        const float rstd = rsqrtf(var + eps);
+        out[row] = float2{rstd, rstd * mean};
+    }
+}
+// logits[row] = prior(query) + gain * half(rstd (sum x gw - mean GW) + C0 + b_out): ln_post + output_proj of the row whose parts fc2's
+// epilogue left in `stats` (mean, M2, sum x gw per part); fold = (GW = sum gamma w_out, C0 = sum beta w_out)
+__global__ __launch_bounds__(256) void k_geo_logit_finish(const float* __restrict__ stats, int nslots, int M, float eps, const float* __restrict__ fold,
+                                                          float b_out, const float* __restrict__ queries, float radius, float sharpness, float gain,
+                                                          float* __restrict__ logits, const int* __restrict__ Mdev) {
+    if (Mdev) M = min(M, *Mdev);
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+    const bool live = row < M && part < nslots;
+    f32x4 st = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) st = reinterpret_cast<const f32x4*>(stats)[(size_t)row * nslots + part];
+    float mean, var;
+    merge_parts(st[0], st[1], live, nslots, mean, var);
+    const float dot = sum16(st[2]);
+    if (live && part == 0) {
+        const float rstd = rsqrtf(var + eps);
+        const float learned = (float)(h16)(rstd * (dot - mean * fold[0]) + fold[1] + b_out);
+        float prior = 0.0f;
+        if (sharpness != 0.0f) {
+            const float x = queries[3 * (size_t)row], y = queries[3 * (size_t)row + 1], z = queries[3 * (size_t)row + 2];
+            prior = (radius - sqrtf(x * x + y * y + z * z)) * sharpness;
+        }
+        logits[row] = prior + gain * learned;
+    }
+}
+// The folded operands, once per prepare (one wave per fc1 output column c): W1f[c][k] = half(W1[c][k] gamma2[k]),
+// fold1 = [b1'[c] = b1[c] + sum_k W1[c][k] beta2[k] | s[c] = sum_k W1f[c][k] (of the ROUNDED products: a constant row cancels exactly)].
+__global__ __launch_bounds__(256) void k_geo_fold_fc1(const h16* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int F, int width, h16* __restrict__ W1f, float* __restrict__ fold1) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= F) return;
+    float sb = 0.0f, ss = 0.0f;
+    for (int k0 = lane * 8; k0 < width; k0 += 512) {
+        const half8 wv = *reinterpret_cast<const half8*>(W1 + (size_t)c * width + k0);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float x = (float)wv[e];
+            o[e] = (h16)(x * gamma[k0 + e]);
+            ss += (float)o[e];
+            sb = __builtin_fmaf(x, beta[k0 + e], sb);
+        }
+        *reinterpret_cast<half8*>(W1f + (size_t)c * width + k0) = o;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sb += __shfl_xor(sb, off);
+        ss += __shfl_xor(ss, off);
+    }
+    if (lane == 0) {
+        fold1[c] = b1[c] + sb;
+        fold1[F + c] = ss;
+    }
+}
+// fold2 = [b2 (width) | gw = gamma_post w_out (width) | GW = sum gw | C0 = sum beta_post w_out]; one workgroup
+__global__ __launch_bounds__(256) void k_geo_fold_post(const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ w_out, int width, float* __restrict__ fold2) {
+    __shared__ float red[2][4];
+    float g = 0.0f, c0 = 0.0f;
+    for (int k = threadIdx.x; k < width; k += 256) {
+        const float gw = gamma[k] * w_out[k];
+        fold2[k] = b2[k];
+        fold2[width + k] = gw;
+        g += gw;
+        c0 = __builtin_fmaf(beta[k], w_out[k], c0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        g += __shfl_xor(g, off);
+        c0 += __shfl_xor(c0, off);
+    }
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = g, red[1][threadIdx.x >> 6] = c0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fold2[2 * width] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        fold2[2 * width + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
 // Fourier embedding of the query points, [x, sin(x f_j), cos(x f_j)] flattened as (coordinate, frequency) like the
 // reference's FourierEmbedder, rounded to fp16 and zero-padded to 64 columns (the K of the query projection GEMM).
 __global__ __launch_bounds__(256) void k_geo_embed(const float* __restrict__ queries, int M, int n_freqs, const float* __restrict__ freqs,
@@ -1729,8 +1945,9 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
                 int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr) {
     if (M <= 0) return FOHO_OK;
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & EP_QNORM) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
-    if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
-    if ((ep & (EP_SAVEZ | EP_TRANS)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
+    if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM | EP_PREAFF)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
+    if ((ep & (EP_SAVEZ | EP_TRANS | EP_STATS | EP_LOGIT)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
+    if (((ep & EP_PREAFF) && ldr != N) || ((ep & (EP_STATS | EP_LOGIT)) && ldc2 * 64 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: folded-LayerNorm epilogue operands");
     const bool big = N % HN == 0 && K >= 256 && M >= 2048 && !g_force128;  // the big GEMMs of the chain: 256 x 256 tiles
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
@@ -1745,6 +1962,9 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
         GEO_GEMM_CASE(EP_TRANS);
         GEO_GEMM_CASE(EP_QNORM);
         GEO_GEMM_CASE(EP_TRANS | EP_QNORM);
+        GEO_GEMM_CASE(EP_RESID | EP_STATS);
+        GEO_GEMM_CASE(EP_GELU | EP_PREAFF);
+        GEO_GEMM_CASE(EP_RESID | EP_LOGIT);
         default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
     }
 #undef GEO_GEMM_CASE
@@ -1766,7 +1986,7 @@ static int check_weights(const foho_geo_weights* w) {
 }
 
 struct Layout {
-    size_t kv, vt, e, a, b, c, h, total;
+    size_t kv, vt, e, a, b, c, h, w1f, fold1, fold2, stats, rowstat, total;
 };
 static Layout layout(const foho_geo_weights* w, int chunk) {
     Layout l{};
@@ -1779,13 +1999,46 @@ static Layout layout(const foho_geo_weights* w, int chunk) {
     const size_t W = w->width, Lr = w->n_latents, rows = std::max<size_t>(chunk, Lr);  // the prepare step normalises the latents in buffer A
     l.kv = take(Lr * 2 * W);
     l.vt = take(W * Lr);
+    // LayerNorm folded into the forward GEMMs (chain_latent_side): fc1's weights with ln_2's gain and the folded vectors -- like kv / vt
+    // written by the prepare step, at offsets that do not depend on the chunk
+    l.w1f = take((size_t)w->hidden * W);
+    l.fold1 = take((size_t)w->hidden * 4);        // 2 hidden floats
+    l.fold2 = take((size_t)W * 4 + 8);            // 2 W + 2 floats
     l.e = take((size_t)chunk * 64);
     l.a = take(rows * W);
     l.b = take((size_t)chunk * W);
     l.c = take((size_t)chunk * W);
     l.h = take((size_t)chunk * w->hidden);
+    // ... the per-row statistics of the folded LayerNorms (16 parts of 4 floats at width 1024) and (rstd, rstd mean) per row
+    l.stats = take((size_t)chunk * (W / 64) * 8); // chunk x parts x 4 floats
+    l.rowstat = take((size_t)chunk * 4);          // chunk x 2 floats
     l.total = off;
     return l;
+}
+// FOHO_GEO_LNFUSE=0: the forward chain with its LayerNorm kernels (A/B measurements, the parity test of the folded form); read at
+// every decode call, so that one process can compare the two forms
+static bool env_lnfuse() {
+    const char* e = getenv("FOHO_GEO_LNFUSE");
+    return !(e && e[0] == '0' && e[1] == 0);
+}
+struct Fold {   // device pointers of the folded operands in a prepared workspace (w1f == nullptr: chain with LayerNorm kernels)
+    const h16* w1f = nullptr;
+    const float *fold1 = nullptr, *fold2 = nullptr;
+    float *stats = nullptr, *rowstat = nullptr;
+};
+static Fold fold_of(const Layout& l, char* base) {
+    Fold f;
+    if (!env_lnfuse()) return f;
+    f.w1f = (const h16*)(base + l.w1f), f.fold1 = (const float*)(base + l.fold1), f.fold2 = (const float*)(base + l.fold2);
+    f.stats = (float*)(base + l.stats), f.rowstat = (float*)(base + l.rowstat);
+    return f;
+}
+static int fold_weights(const foho_geo_weights* w, const Layout& l, char* base, hipStream_t s) {
+    const int W = w->width, F = w->hidden;
+    hipLaunchKernelGGL(k_geo_fold_fc1, dim3((F + 3) / 4), dim3(256), 0, s, (const h16*)w->w_fc1, w->b_fc1, w->ln_2_g, w->ln_2_b, F, W, (h16*)(base + l.w1f),
+                       (float*)(base + l.fold1));
+    hipLaunchKernelGGL(k_geo_fold_post, dim3(1), dim3(256), 0, s, w->b_fc2, w->ln_post_g, w->ln_post_b, w->w_out, W, (float*)(base + l.fold2));
+    return launch_ok("k_geo_fold") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 
 }  // namespace geo
@@ -1819,7 +2072,8 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
     if (int rc = gemm(0, ln, W, (const h16*)w->w_kv, W, w->b_kv, nullptr, 0, kv, 2 * W, Lr, 2 * W, W, 1.0f, s)) return rc;
     if (w->k_norm) hipLaunchKernelGGL(k_geo_knorm, dim3((Lr * w->heads + 255) / 256), dim3(256), 0, s, kv, 2 * W, Lr, w->heads, w->k_norm);
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr / 16), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
-    return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
+    if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
+    return fold_weights(w, l, base, s);
 }
 
 // ---- the forward chain in two halves: what depends only on the query points (Fourier embedding -> query projection -> ln_q ->
@@ -1842,12 +2096,33 @@ static int chain_query_side(const foho_geo_weights* w, const float* q, int M, h1
 
 // attention over the latent tokens -> c_proj + residual -> ln_2 -> fc1 + GELU -> fc2 + residual.  Z != NULL keeps the MLP's
 // pre-activation, lse != NULL the attention's log-sum-exp (both for a backward).  X0 / Qs: the query side's outputs for these rows.
+//
+// With `fold` (the plain forward: nothing kept, logits wanted) the two LayerNorms of this half never run as kernels:
+//   ln_2 -> fc1:  LN(x) W^T = rstd (x (W gamma)^T) - rstd mean s + (b + W beta), s = row sums of W gamma -- c_proj's epilogue leaves the
+//     row statistics of x1 (EP_STATS), fc1 multiplies the un-normalised x1 with the folded weights and applies (rstd, mean) per row in
+//     its epilogue in front of the GELU (EP_PREAFF);
+//   fc2 -> ln_post -> output_proj:  logit = rstd (x2 . gw - mean GW) + C0 + b_out, gw = gamma_post w_out -- fc2's epilogue reduces its
+//     rows to (mean, M2, x2 . gw) per 64-column part (EP_LOGIT) and x2 is never written; k_geo_logit_finish merges the parts.
+// Same fp16-rounded x1 / x2 as the chain with LayerNorm kernels; what differs is one rounding (LN output to fp16 there, W gamma to
+// fp16 here) -- tests/test_geo_decode.py compares the two forms.  100 MB of reads + 100 MB of writes less per LayerNorm and row block.
 static int chain_latent_side(const foho_geo_weights* w, int M, const h16* X0, const h16* Qs, h16* At, h16* X1, h16* Xn, h16* Z, h16* H, h16* X2, float* lse,
-                             const h16* kv, const h16* vt, hipStream_t s, const int* Mdev = nullptr) {
+                             const h16* kv, const h16* vt, hipStream_t s, const int* Mdev = nullptr, const Fold* fold = nullptr, const float* q = nullptr,
+                             float* logits = nullptr) {
     const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
     const float* nof = nullptr;
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), dim3(256), 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse, Mdev);
     if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
+    if (fold && fold->w1f && !Z) {
+        const int parts = W / 64;
+        if (int rc = gemm(EP_RESID | EP_STATS, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s, (h16*)fold->stats, parts, Mdev)) return rc;
+        hipLaunchKernelGGL(k_geo_rowstat_finish, dim3((M + 15) / 16), dim3(256), 0, s, fold->stats, parts, M, eps_of(w, w->ln_2_eps), (float2*)fold->rowstat, Mdev);
+        if (!launch_ok("k_geo_rowstat_finish")) return FOHO_ERR_LAUNCH;
+        if (int rc = gemm(EP_GELU | EP_PREAFF, X1, W, fold->w1f, W, fold->fold1, (const h16*)fold->rowstat, F, H, F, M, F, W, 1.0f, s, nullptr, 0, Mdev)) return rc;
+        if (int rc = gemm(EP_RESID | EP_LOGIT, H, F, (const h16*)w->w_fc2, F, fold->fold2, X1, W, X2, W, M, W, F, 1.0f, s, (h16*)fold->stats, parts, Mdev)) return rc;
+        hipLaunchKernelGGL(k_geo_logit_finish, dim3((M + 15) / 16), dim3(256), 0, s, fold->stats, parts, M, w->ln_eps, fold->fold2 + 2 * W, w->b_out, q,
+                           w->prior_radius, w->prior_sharpness, w->out_gain, logits, Mdev);
+        return launch_ok("k_geo_logit_finish") ? FOHO_OK : FOHO_ERR_LAUNCH;
+    }
     if (int rc = gemm(EP_RESID, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s, nullptr, 0, Mdev)) return rc;
     hipLaunchKernelGGL(k_geo_ln<0>, dim3((M + 3) / 4), dim3(256), 0, s, X1, W, w->ln_2_g, w->ln_2_b, Xn, W, M, W, eps_of(w, w->ln_2_eps), nof, 0.0f, nof, 0.0f, 0.0f, 0.0f,
                        (float*)nullptr, Mdev);
@@ -1873,13 +2148,15 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
     char* base = (char*)ws;
     const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
     h16 *E = (h16*)(base + l.e), *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
+    const Fold fold = fold_of(l, base);
     for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
         const float* q = queries + 3 * r0;
         // x0 -> A, ln_q(x0) -> B, q -> C;  attention C -> B;  x1 = x0 + c_proj: B (+A) -> C;  ln_2: C -> B;  fc1: B -> H;  x2 = x1 + fc2: H (+C) -> A
         if (int rc = chain_query_side(w, q, M, E, bA, bB, bC, nullptr, 0, s)) return rc;
-        if (int rc = chain_latent_side(w, M, bA, bC, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s)) return rc;
-        if (int rc = chain_logits(w, q, M, bA, logits + r0, s)) return rc;
+        if (int rc = chain_latent_side(w, M, bA, bC, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s, nullptr, &fold, q, logits + r0)) return rc;
+        if (!fold.w1f)
+            if (int rc = chain_logits(w, q, M, bA, logits + r0, s)) return rc;
     }
     return FOHO_OK;
 }
@@ -1932,13 +2209,16 @@ extern "C" int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float
     char* base = (char*)ws;
     const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
     h16 *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
+    const Fold fold = fold_of(l, base);
     const h16 *X0 = (const h16*)((const char*)cache + c.x0), *Qs = (const h16*)((const char*)cache + c.qs);
     const size_t W = w->width;
     for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
         // attention Qs -> B;  x1 = x0 + c_proj: B (+X0) -> C;  ln_2: C -> B;  fc1: B -> H;  x2 = x1 + fc2: H (+C) -> A
-        if (int rc = chain_latent_side(w, M, X0 + r0 * W, Qs + r0 * W, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s)) return rc;
-        if (int rc = chain_logits(w, queries + 3 * r0, M, bA, logits + r0, s)) return rc;
+        if (int rc = chain_latent_side(w, M, X0 + r0 * W, Qs + r0 * W, bB, bC, bB, nullptr, bH, bA, nullptr, kv, vt, s, nullptr, &fold, queries + 3 * r0, logits + r0))
+            return rc;
+        if (!fold.w1f)
+            if (int rc = chain_logits(w, queries + 3 * r0, M, bA, logits + r0, s)) return rc;
     }
     return FOHO_OK;
 }
@@ -2005,7 +2285,8 @@ extern "C" int foho_geo_set_kv(const foho_geo_weights* w, const void* kv_in, int
     const int W = w->width, Lr = w->n_latents;
     if (hipMemcpyAsync(kv, kv_in, (size_t)Lr * 2 * W * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(FOHO_ERR_LAUNCH, "foho_geo_set_kv: copy failed");
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, Lr / 16), dim3(256), 0, s, kv, 2 * W, W, Lr, vt);
-    return launch_ok("k_geo_pack_vt") ? FOHO_OK : FOHO_ERR_LAUNCH;
+    if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
+    return fold_weights(w, l, base, s);
 }
 
 // What the backward of one row block needs from its forward: per block in the `save` buffer (kept mode) or in the backward

@@ -3,6 +3,7 @@ of the same shape (standins._GeoDecoder, float32 arithmetic on the same fp16-rep
 epilogue, the attention kernel, and the whole chain at a reduced and at the full Hunyuan3D-2 shape (3072 x 1024 latent
 tokens, 16 heads, hidden 4096, 65^3 queries).  fp16 storage / fp32 accumulation: tolerance 2e-3 of the output's scale."""
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -157,6 +158,19 @@ def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk)
     # a second call on the same tokens reuses K / V; new tokens are projected again
     out2 = hip(q.float(), lat)
     assert torch.equal(out, out2)
+    # the forward folds ln_2 into fc1 and ln_post + output_proj into fc2's epilogue; the chain with LayerNorm KERNELS (what the
+    # backward routes recompute) gives the same logits up to one fp16 rounding of an intermediate, and is as close to torch
+    os.environ["FOHO_GEO_LNFUSE"] = "0"
+    try:
+        out_ln = hip(q.float(), lat)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FOHO_GEO_LNFUSE"]
+    scale = max(learned.abs().max().item(), 1.0) * dec.gain
+    assert not torch.equal(out, out_ln) or width < 0          # (they are different computations)
+    # (the second term: the result is handed back in fp16, the analytic prior included)
+    assert (out.float() - out_ln.float()).abs().max().item() <= 1e-3 * scale + 1e-3 * ref.abs().max().item(), ((out.float() - out_ln.float()).abs().max().item(), scale)
+    assert (out_ln.float() - ref).abs().max().item() <= 2e-3 * scale + 1e-3 * ref.abs().max().item()
     # ... also when they live where the old ones did (the caching allocator reuses a freed latent's block: no reuse by address)
     lat_b = lat.clone()
     out_b = hip(q.float(), lat_b)
@@ -218,7 +232,14 @@ def test_decoder_backward_against_torch_autograd(width, heads, n_lat, n_q, chunk
     out_k, saved = hip.decode_keep(q.float())
     # (the keeping forward is another instantiation of the GEMM epilogue: where the compiler folds "times scale, to fp16" into
     # one v_fma_mixlo_f16 it rounds once, elsewhere twice -- a handful of logits differ in the last fp16 bit of an activation)
-    assert (out_k - hip.decode(q.float())).abs().max().item() <= 1e-3 * dec.gain
+    os.environ["FOHO_GEO_LNFUSE"] = "0"          # ... against the plain forward in the same form (LayerNorm kernels) ...
+    try:
+        out_plain = hip.decode(q.float())
+    finally:
+        del os.environ["FOHO_GEO_LNFUSE"]
+    assert (out_k - out_plain).abs().max().item() <= 1e-3 * dec.gain
+    # ... and against the forward the loop runs (LayerNorms folded into the GEMMs: another rounding of one intermediate)
+    assert (out_k - hip.decode(q.float())).abs().max().item() <= 2e-3 * dec.gain * 8
     assert torch.equal(hip.decode_bwd(q.float(), go, saved), gkv)
     hip.keep_activations = False
     lat_n = lat.clone().requires_grad_(True)
