@@ -595,6 +595,10 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
                                                        int ldc2, const int* __restrict__ Mdev) {
     __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
+    // the epilogue's column vectors (bias; EP_PREAFF: the folded weights' row sums and the rows' statistics; EP_LOGIT: gamma w_out) wait
+    // in LDS from the start of the tile: the epilogue of a K = 1024 tile has no global round trip of its own to sit out
+    __shared__ float ext_b[HN], ext_s[HN];
+    __shared__ float2 ext_r[HM];
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -604,6 +608,15 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     if (mp >= ntm) return;
     const int m0 = mp * HM, n0 = nt * HN;
     const int wr = w >> 2, wc = w & 3;  // this wave's 128 (M) x 64 (N) part of the tile; wr = its group
+    float ev0 = 0.0f, ev1 = 0.0f;
+    float2 ev2 = float2{1.0f, 0.0f};
+    if (tid < HN) {
+        ev0 = bias[n0 + tid];
+        if (EP & EP_PREAFF) ev1 = bias[ldr + n0 + tid];
+        if (EP & EP_LOGIT) ev1 = bias[64 * ldc2 + n0 + tid];
+    } else if (EP & EP_PREAFF) {
+        ev2 = reinterpret_cast<const float2*>(R)[min(m0 + tid - HN, M - 1)];
+    }
 
     // ---- LDS-DMA pieces of this wave: per K tile two pieces in each of four phases.  A piece = 8 rows x 128 bytes; a lane's 16 bytes
     // land at (row0 + lane / 8, slot lane % 8), so it FETCHES chunk slot ^ swz(row); swz(row0 + r) depends on row0 only through
@@ -688,6 +701,12 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     P8_DMA(1, 1, GK * 2);
     P8_DMA(2, 1, GK * 2);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (tid < HN) {
+        ext_b[tid] = ev0;
+        if (EP & (EP_PREAFF | EP_LOGIT)) ext_s[tid] = ev1;
+    } else if (EP & EP_PREAFF) {
+        ext_r[tid - HN] = ev2;
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk], 32768);
@@ -817,10 +836,26 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     // the epilogue's operands from global memory are on their way while the groups meet (the fragment registers are free now)
     EpiCols pc;
     EpiRows pr[2];
-    // (EP_PREAFF: two floats per row -- both parts' now: a wait for them behind the first part's stores would wait for the stores)
-    if (EP & EP_PREAFF) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
-    epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
-    epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);
+    if (!(EP & EP_PREAFF)) epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);   // (residual rows: from global memory)
+#pragma unroll
+    for (int g8 = 0; g8 < 8; g8++) {
+        const int nl = wc * 64 + (g8 >> 2) * 32 + 8 * (g8 & 3) + 4 * hi;
+        pc.b[g8] = *reinterpret_cast<const f32x4*>(&ext_b[nl]);
+        if (EP & EP_PREAFF) pc.s[g8] = *reinterpret_cast<const f32x4*>(&ext_s[nl]);
+    }
+    if (EP & EP_LOGIT) {
+        pc.g0 = *reinterpret_cast<const f32x4*>(&ext_s[wc * 64 + (lane & 7) * 8]);
+        pc.g1 = *reinterpret_cast<const f32x4*>(&ext_s[wc * 64 + (lane & 7) * 8 + 4]);
+    }
+    if (EP & EP_PREAFF) {
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const float2 st = ext_r[wr * 128 + half * 64 + i * 32 + l31];
+                pr[half].rs[i] = st.x, pr[half].mr[i] = st.y;
+            }
+    }
     if (wr == 0 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
     __syncthreads();
 
