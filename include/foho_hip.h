@@ -432,7 +432,12 @@ int64_t foho_geo_abi_size(void);
  * query at width 1024 / hidden 4096; 16384 rows keep a block inside the 256 MB Infinity Cache).  0 on bad arguments. */
 size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
 /* once per set of latent tokens: LayerNorm + K/V projection of `latents` (n_latents, width) fp16 into the workspace
- * (V transposed and key-permuted for the attention kernel).  The same chunk_rows as the decode calls that follow. */
+ * (V transposed and key-permuted for the attention kernel).  The same chunk_rows as the decode calls that follow.
+ * Also rebuilds, from the weights as they are at this call, the operands of the forward's folded LayerNorms (fc1's weights
+ * times ln_2's gain, their row sums, ln_post's gain times w_out: 8 MB, two small kernels) -- foho_geo_decode_fwd[_cached] run
+ * ln_2 inside fc1 and ln_post + output_proj inside fc2's epilogue; weights changed AFTER the prepare call take effect with
+ * the next one.  FOHO_GEO_LNFUSE=0 in the environment runs the chain with its LayerNorm kernels instead (same logits to one
+ * fp16 ulp; read at every decode call). */
 int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chunk_rows, void* workspace, size_t workspace_bytes,
                      void* stream);
 /* logits[n] = geo_decoder(queries[n], latents) for n < n_queries: queries (N,3) fp32 (already rounded the way the caller's
