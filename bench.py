@@ -1022,13 +1022,16 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
 def vae_attention_record(torch, dev):
     """The self-attention of the ShapeVAE transformer inside latent2sdf (PL:295: sixteen layers over 3072 tokens, 16 heads of 64, forward
     and backward in every inner iteration) at its shape (1, 16, 3072, 64) fp16: torch's scaled_dot_product_attention on its default
-    (flash) backend, on the memory-efficient backend `pipeline.vae_attention_backend()` prefers, and this repository's kernels
-    (followmyhold_amd.sdpa: k_geo_attn / k_geo_attn_bwd / k_geo_attn_dq, opt-in with FOHO_VAE_SDPA=hip) -- microseconds per layer."""
+    (flash) backend, on its memory-efficient backend, and this repository's kernels (followmyhold_amd.sdpa) in the two forms of
+    `pipeline.vae_attention_backend()`: `hip` = the HIP forward with torch's memory-efficient backward fed from it (the pipeline's
+    default), `hip_bwd` = the HIP backward kernels as well (k_geo_attn_bwd + k_geo_attn_dq) -- microseconds per layer.  The operands are
+    (B, N, H, 64) tensors viewed as (B, H, N, 64), the layout the transformer's projections leave them in."""
     import torch.nn.functional as F
     from torch.nn.attention import SDPBackend, sdpa_kernel
     from followmyhold_amd import sdpa
-    q, k, v = (torch.randn(1, 16, 3072, 64, device=dev, dtype=torch.float16, requires_grad=True) for _ in range(3))
-    go = torch.randn(1, 16, 3072, 64, device=dev, dtype=torch.float16)
+    base = [torch.randn(1, 3072, 16, 64, device=dev, dtype=torch.float16, requires_grad=True) for _ in range(3)]
+    q, k, v = (t.transpose(1, 2) for t in base)
+    go = torch.randn(1, 3072, 16, 64, device=dev, dtype=torch.float16).transpose(1, 2)
 
     def timed(fn, n=20):
         for _ in range(3):
@@ -1049,18 +1052,28 @@ def vae_attention_record(torch, dev):
         return call
 
     rec = {"shape": "(1, 16, 3072, 64) fp16", "unit": "us per layer", "gflop_forward": 4 * 16 * 3072 * 3072 * 64 / 1e9}
-    for name, fn in (("torch_default", torch_fn(None)), ("torch_efficient", torch_fn(SDPBackend.EFFICIENT_ATTENTION)), ("hip", lambda: sdpa.attention(q, k, v))):
+    def hip_fn(route):
+        def call():
+            sdpa.backward_route = route
+            return sdpa.attention(q, k, v)
+        return call
+
+    saved_route = sdpa.backward_route
+    for name, fn in (("torch_default", torch_fn(None)), ("torch_efficient", torch_fn(SDPBackend.EFFICIENT_ATTENTION)), ("hip", hip_fn("torch")),
+                     ("hip_bwd", hip_fn("hip"))):
         def fwd():
             with torch.no_grad():
                 return fn()
         def fb():
-            for t in (q, k, v):
+            for t in base:
                 t.grad = None
             fn().backward(go)
         try:
             rec[name] = {"forward_us": timed(fwd), "forward_backward_us": timed(fb)}
         except Exception as e:  # noqa: BLE001
             rec[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    sdpa.backward_route = saved_route
+    rec["hip_backward_by_torch_refused"] = bool(sdpa._torch_route_refused)
     with torch.no_grad():
         ref = torch_fn(SDPBackend.MATH)().float()
         rec["hip_max_abs_diff_vs_torch_math"] = float((sdpa.attention(q, k, v).float() - ref).abs().max())

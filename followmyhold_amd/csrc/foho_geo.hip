@@ -892,7 +892,12 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
-                                                     int heads, float* __restrict__ nlse, const int* __restrict__ Mdev) {
+                                                     int heads, float* __restrict__ nlse, const int* __restrict__ Mdev, int qhs = 64, int khs = 64,
+                                                     float qscale = 1.0f, float* __restrict__ lse_nat = nullptr) {
+    // lse_nat: optional (heads, M) fp32 -- the NATURAL-log log-sum-exp of the scaled scores per head and query, the form torch's
+    // attention backward kernels take (foho_sdpa_fwd)
+    // qhs / khs: distance of two heads inside a row of Q / K (64: heads side by side; 192: hy3dgen's interleaved q | k | v per head);
+    // qscale != 1: Q arrives UNSCALED and is multiplied (and rounded to fp16 again) as it is loaded (foho_sdpa_fwd)
     __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -913,11 +918,16 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     for (int qb = 0; qb < 2; qb++) {
         const int row = min(q0 + qb * 32 + l31, M - 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) qf[qb][kk] = *reinterpret_cast<const half8*>(Q + (size_t)row * ldq + head * 64 + 16 * kk + 8 * hi);
+        for (int kk = 0; kk < 4; kk++) {
+            qf[qb][kk] = *reinterpret_cast<const half8*>(Q + (size_t)row * ldq + head * qhs + 16 * kk + 8 * hi);
+            if (qscale != 1.0f)
+#pragma unroll
+                for (int e = 0; e < 8; e++) qf[qb][kk][e] = (h16)((float)qf[qb][kk][e] * qscale);
+        }
     }
 
     const int srow = tid >> 3, sch = tid & 7;
-    const h16* kg = Kp + (size_t)srow * ldk + head * 64 + sch * 8;
+    const h16* kg = Kp + (size_t)srow * ldk + head * khs + sch * 8;
     const h16* vg = Vt + ((size_t)head * 64 + srow) * L + sch * 8;
     const int sidx = srow * 8 + (sch ^ swz(srow));  // rows srow and srow + 32 share the swizzle
     uint4 st0, st1, st2, st3;
@@ -1063,6 +1073,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         // MINUS the log2 of the softmax denominator in the scores' own (log2) units: the backward pass starts its score accumulators
         // at this value and gets P = exp2(s - lse) without a subtraction; -inf for the rows that pad the last tile of 64 (P = 0)
         if (nlse && hi == 0 && row < ((M + 63) & ~63)) nlse[(size_t)row * heads + head] = (row < M) ? negm[qb][0] - __builtin_amdgcn_logf(lt) : -INFINITY;
+        if (lse_nat && hi == 0 && row < M) lse_nat[(size_t)head * M + row] = (__builtin_amdgcn_logf(lt) - negm[qb][0]) * 0.6931471805599453f;
         if (row < M) {
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
@@ -1113,13 +1124,14 @@ __global__ void k_geo_knorm(h16* __restrict__ KV, int ldkv, int L, int heads, co
 // V half of the KV projection (L rows, row stride ldkv, columns width + head*64 + d) -> Vt[head][d][pos(l)]: within every
 // block of 16 keys, key kq goes to position (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1) (keys 4-7 and 8-11 swap places):
 // the order in which a lane of the P^T fragment holds its 8 keys (C layout of the 32x32 MFMA: rows (r & 3) + 8 (r >> 2) + 4 hi).
-__global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt, int col0 = -1) {
+__global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt, int col0 = -1, int hs = 64) {
     // one thread per (column, block of 16 keys): sixteen strided reads (coalesced across the threads of a wave: consecutive columns),
     // one 32-byte row segment written in the permuted order.  (One thread per ELEMENT, 3072 x 1024 two-byte stores, took 19 us.)
     const int c = blockIdx.x * 256 + threadIdx.x;  // head * 64 + d
     const int l0 = blockIdx.y * 16;
     if (c >= width) return;
-    const h16* src = KV + (size_t)l0 * ldkv + (col0 < 0 ? width : col0) + c;   // col0: first column of the half to transpose (default: the V half)
+    // col0: first column of the half to transpose (default: the V half); hs: distance of two heads inside a row (64: side by side)
+    const h16* src = KV + (size_t)l0 * ldkv + (col0 < 0 ? width : col0) + (c >> 6) * hs + (c & 63);
     half8 lo, hi8;
 #pragma unroll
     for (int pos = 0; pos < 16; pos++) {
@@ -1167,7 +1179,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
                                                          const h16* __restrict__ dOT, int ldt, const float* __restrict__ nlse,
                                                          const float* __restrict__ ndelta, const h16* __restrict__ KV, int ldkv, int width,
                                                          int heads, int M, int splits, int L, int accumulate, float* __restrict__ part,
-                                                         const int* __restrict__ Mdev) {
+                                                         const int* __restrict__ Mdev, const h16* __restrict__ Vp = nullptr, int khs = 64) {
+    // K rows at KV + key ldkv + head khs; V rows at Vp + ... (default: the V half of the decoder's K | V projection, KV + width)
+    if (!Vp) Vp = KV + width;
     if (Mdev) M = max(min(M, *Mdev), 0);   // 0 rows: the first block of a call still writes its (zero) partial sums
     __shared__ uint4 lds[2][4][BQ * 8];   // [buffer][Qs | dO | Qs^T | dO^T][64 rows x 8 chunks] = 64 KB
     __shared__ float lsd[2][2][BQ];       // [buffer][-lse | -delta]
@@ -1183,8 +1197,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
     half8 kf[4], vf[4];   // B operands: lane (key, hi) holds K / V [key][16 kk + 8 hi .. + 7]
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        kf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + head * 64 + 16 * kk + 8 * hi);
-        vf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + width + head * 64 + 16 * kk + 8 * hi);
+        kf[kk] = *reinterpret_cast<const half8*>(KV + (size_t)key * ldkv + head * khs + 16 * kk + 8 * hi);
+        vf[kk] = *reinterpret_cast<const half8*>(Vp + (size_t)key * ldkv + head * khs + 16 * kk + 8 * hi);
     }
     f32x16 dk0, dk1, dv0, dv1;  // dK^T / dV^T [d tile]: rows d, columns key
 #pragma unroll
@@ -1398,7 +1412,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
 constexpr int DQQ = 128;   // queries per workgroup of k_geo_attn_dq
 __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ Qs, const h16* __restrict__ dO, int ldq, const h16* __restrict__ KV,
                                                         int ldkv, int width, const h16* __restrict__ Kt, int L, const float* __restrict__ nlse,
-                                                        const float* __restrict__ ndelta, h16* __restrict__ dQ, int M, int heads) {
+                                                        const float* __restrict__ ndelta, h16* __restrict__ dQ, int M, int heads,
+                                                        const h16* __restrict__ Vp = nullptr, int khs = 64) {
+    if (!Vp) Vp = KV + width;   // (K / V rows as in k_geo_attn_bwd)
     __shared__ uint4 lds[2][3][AK * 8];  // [buffer][K | V | K^T][64 rows x 8 chunks] = 48 KB
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1431,17 +1447,19 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ 
     const int srow = lane >> 3, sslot = lane & 7;
     const int c0 = (sslot ^ ((srow >> 1) & 7)) << 3, c1 = (sslot ^ ((4 + (srow >> 1)) & 7)) << 3;
     const int vk0 = (srow * ldkv + c0) * 2, vk1 = (srow * ldkv + c1) * 2, vt0 = (srow * L + c0) * 2, vt1 = (srow * L + c1) * 2;
-    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)KV, (short)0, (int)min((size_t)L * ldkv * 2, (size_t)0x7fffffff), 0x00020000);
+    const size_t kvspan = ((size_t)(L - 1) * ldkv + (size_t)(heads - 1) * khs + 64) * 2;   // bytes from the first to the last element of K (of V)
+    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void*)KV, (short)0, (int)min(kvspan, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rvv = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, (short)0, (int)min(kvspan, (size_t)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rkt = __builtin_amdgcn_make_buffer_rsrc((void*)Kt, (short)0, (int)min((size_t)width * L * 2, (size_t)0x7fffffff), 0x00020000);
     const int r0 = 16 * w, r1 = 16 * w + 8;   // tile rows of this wave's two pieces
-    const int sk = head * 64 * 2, sv = (width + head * 64) * 2, skt = head * 64 * L * 2;
+    const int sk = head * khs * 2, skt = head * 64 * L * 2;
 #define DQ_ISSUE(t, buf)                                                                         \
     do {                                                                                         \
         const int kb_ = (t) * AK;                                                                \
         dma16(rkv, &lds[buf][0][r0 * 8], vk0, sk + (kb_ + r0) * ldkv * 2);                       \
         dma16(rkv, &lds[buf][0][r1 * 8], vk1, sk + (kb_ + r1) * ldkv * 2);                       \
-        dma16(rkv, &lds[buf][1][r0 * 8], vk0, sv + (kb_ + r0) * ldkv * 2);                       \
-        dma16(rkv, &lds[buf][1][r1 * 8], vk1, sv + (kb_ + r1) * ldkv * 2);                       \
+        dma16(rvv, &lds[buf][1][r0 * 8], vk0, sk + (kb_ + r0) * ldkv * 2);                       \
+        dma16(rvv, &lds[buf][1][r1 * 8], vk1, sk + (kb_ + r1) * ldkv * 2);                       \
         dma16(rkt, &lds[buf][2][r0 * 8], vt0, skt + (r0 * L + kb_) * 2);                         \
         dma16(rkt, &lds[buf][2][r1 * 8], vt1, skt + (r1 * L + kb_) * 2);                         \
     } while (0)
@@ -1531,11 +1549,18 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ 
 
 // X (M rows, W columns) -> XT[c][pos(m)] (row length ldt), pos = m with bits 2 and 3 of (m & 15) swapped: the transposed copies
 // k_geo_attn_bwd reads (what the GEMM epilogue EP_TRANS writes inside the decoder); columns beyond M are left alone (cleared by the caller)
-__global__ __launch_bounds__(256) void k_geo_transpose_perm(const h16* __restrict__ X, int ldx, int M, int W, h16* __restrict__ XT, int ldt) {
+// hs: distance of two heads inside a row of X; scale != 1: the values are multiplied (and rounded to fp16 again) first, and Xs (M x W,
+// heads side by side) receives the scaled rows as well -- the scaled copy of Q the backward attention kernels stream
+__global__ __launch_bounds__(256) void k_geo_transpose_perm(const h16* __restrict__ X, int ldx, int M, int W, h16* __restrict__ XT, int ldt, int hs = 64,
+                                                            float scale = 1.0f, h16* __restrict__ Xs = nullptr) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int m = i % M, c8 = i / M;
     if (c8 * 8 >= W) return;
-    const half8 v = *reinterpret_cast<const half8*>(X + (size_t)m * ldx + c8 * 8);
+    half8 v = *reinterpret_cast<const half8*>(X + (size_t)m * ldx + (c8 >> 3) * hs + (c8 & 7) * 8);
+    if (scale != 1.0f)
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] * scale);
+    if (Xs) *reinterpret_cast<half8*>(Xs + (size_t)m * W + c8 * 8) = v;
     const int pm = (m & ~15) | (m & 3) | ((m & 4) << 1) | ((m & 8) >> 1);
 #pragma unroll
     for (int e = 0; e < 8; e++) XT[(size_t)(c8 * 8 + e) * ldt + pm] = v[e];
@@ -1552,6 +1577,23 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce(const float* __restrict_
         for (int e = 0; e < 4; e++) a[e] += b[e];
     }
     reinterpret_cast<f32x4*>(out)[i] = a;
+}
+
+// ... the same sum, handed out as two fp16 matrices (L x W each): dK and dV of foho_sdpa_bwd
+__global__ __launch_bounds__(256) void k_geo_dkv_reduce16(const float* __restrict__ part, int splits, int L, int W, h16* __restrict__ dk, h16* __restrict__ dv) {
+    const size_t n4 = (size_t)L * 2 * W / 4, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+    for (int sp = 1; sp < splits; sp++) {
+        const f32x4 b = reinterpret_cast<const f32x4*>(part)[(size_t)sp * n4 + i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[e] += b[e];
+    }
+    const size_t l = i / (W / 2), c = (i % (W / 2)) * 4;   // row, column within the 2 W wide row
+    half4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = (h16)a[e];
+    *reinterpret_cast<half4*>((c < (size_t)W ? dk + l * W + c : dv + l * W + (c - W))) = o;
 }
 
 // ndelta[q][head] = - sum_d dO[q][head, d] O[q][head, d] (negated: the backward attention starts its dP accumulators there); one
@@ -2544,7 +2586,7 @@ extern "C" int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* 
 // runs in front of the decoder (PL:295; sixteen layers of 3072 tokens x 16 heads, forward and backward in every inner iteration).
 // The forward is the decoder's k_geo_attn, dK / dV its k_geo_attn_bwd, dQ k_geo_attn_dq.
 struct SdpaLayout {
-    size_t vt, kt, qst, dot, delta, part, total;
+    size_t vt, kt, qs, qst, dot, delta, part, total;
     int ldt, splits;
 };
 static SdpaLayout sdpa_layout(int M, int L, int heads) {
@@ -2559,6 +2601,7 @@ static SdpaLayout sdpa_layout(int M, int L, int heads) {
     l.ldt = (M + 63) & ~63;
     l.vt = take(W * L * 2);
     l.kt = take(W * L * 2);
+    l.qs = take(W * (size_t)M * 2);
     l.qst = take(W * (size_t)l.ldt * 2);
     l.dot = take(W * (size_t)l.ldt * 2);
     l.delta = take((size_t)l.ldt * heads * 4);
@@ -2568,60 +2611,83 @@ static SdpaLayout sdpa_layout(int M, int L, int heads) {
     l.total = off;
     return l;
 }
-static int sdpa_args(const char* who, int M, int L, int heads, bool bwd) {
-    if (M < 1 || L < 64 || L % 64 || heads < 1 || heads > 16) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": M >= 1, L a multiple of 64, 1..16 heads of 64");
+static int sdpa_args(const char* who, const foho_sdpa_desc* d, bool bwd) {
+    if (!d) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": null descriptor");
+    const int M = d->M, L = d->L, heads = d->heads;
+    if (M < 1 || L < 64 || L % 64 || heads < 1 || heads > 16 || d->batch < 1)
+        return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": M >= 1, L a multiple of 64, 1..16 heads of 64, batch >= 1");
     if (bwd && L % 128) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": L must be a multiple of 128");
-    if ((size_t)L * heads * 128 * 2 >= ((size_t)1 << 31)) return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": K / V too large for 32-bit buffer offsets");
+    if (d->q_row < 64 || d->kv_row < 64 || d->q_head < 64 || d->kv_head < 64 || (d->q_row & 7) || (d->kv_row & 7) || (d->q_head & 7) || (d->kv_head & 7) ||
+        (d->q_batch & 7) || (d->kv_batch & 7))
+        return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": strides must be multiples of 8 halfs (16-byte rows), at least 64");
+    if (((size_t)(L - 1) * d->kv_row + (size_t)(heads - 1) * d->kv_head + 64) * 2 >= ((size_t)1 << 31) ||
+        ((size_t)(M - 1) * d->q_row + (size_t)(heads - 1) * d->q_head + 64) * 2 >= ((size_t)1 << 31))
+        return fail(FOHO_ERR_BAD_ARG, std::string(who) + ": operand too large for 32-bit buffer offsets");
     return FOHO_OK;
 }
+static const float SDPA_QSCALE = 1.4426950408889634f * 0.125f;   // log2(e) / sqrt(64): the kernels exponentiate with exp2
+
 extern "C" size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads) {
-    if (sdpa_args("foho_sdpa_workspace_bytes", M, L, heads, false) != FOHO_OK) return 0;
+    foho_sdpa_desc d{};
+    d.M = M, d.L = L, d.heads = heads, d.batch = 1, d.q_row = d.kv_row = heads * 64, d.q_head = d.kv_head = 64;
+    if (sdpa_args("foho_sdpa_workspace_bytes", &d, false) != FOHO_OK) return 0;
     return sdpa_layout(M, L, heads).total;
 }
-extern "C" int foho_sdpa_fwd(const void* q_scaled, const void* kv, void* out, float* nlse, int32_t M, int32_t L, int32_t heads, void* ws, size_t ws_bytes,
-                             void* stream_) {
-    if (int rc = sdpa_args("foho_sdpa_fwd", M, L, heads, false)) return rc;
-    if (!q_scaled || !kv || !out || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_fwd: null argument");
+extern "C" int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, void* out, float* nlse, float* lse_nat, void* ws,
+                             size_t ws_bytes, void* stream_) {
+    if (int rc = sdpa_args("foho_sdpa_fwd", d, false)) return rc;
+    if (!q || !k || !v || !out || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_fwd: null argument");
+    const int M = d->M, L = d->L, heads = d->heads, W = heads * 64;
     const SdpaLayout l = sdpa_layout(M, L, heads);
     if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_sdpa_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream_;
-    const int W = heads * 64;
     h16* vt = (h16*)((char*)ws + l.vt);
-    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, (const h16*)kv, 2 * W, W, L, vt, -1);
-    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)q_scaled, W, (const h16*)kv, 2 * W, (const h16*)vt, L, (h16*)out, W,
-                       M, heads, nlse, (const int*)nullptr);
+    const size_t nl = (size_t)((M + 63) & ~63) * heads;
+    for (int b = 0; b < d->batch; b++) {
+        const h16 *qb = (const h16*)q + (size_t)b * d->q_batch, *kb = (const h16*)k + (size_t)b * d->kv_batch, *vb = (const h16*)v + (size_t)b * d->kv_batch;
+        hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, vb, (int)d->kv_row, W, L, vt, 0, (int)d->kv_head);
+        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, qb, (int)d->q_row, kb, (int)d->kv_row, (const h16*)vt, L,
+                           (h16*)out + (size_t)b * M * W, W, M, heads, nlse ? nlse + b * nl : nullptr, (const int*)nullptr, (int)d->q_head, (int)d->kv_head, SDPA_QSCALE,
+                           lse_nat ? lse_nat + (size_t)b * heads * M : nullptr);
+    }
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
-extern "C" int foho_sdpa_bwd(const void* q_scaled, const void* kv, const void* out, const float* nlse, const void* grad_out, void* grad_q, float* grad_kv,
-                             int32_t M, int32_t L, int32_t heads, void* ws, size_t ws_bytes, void* stream_) {
-    if (int rc = sdpa_args("foho_sdpa_bwd", M, L, heads, true)) return rc;
-    if (!q_scaled || !kv || !out || !nlse || !grad_out || !grad_q || !grad_kv || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_bwd: null argument");
+extern "C" int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, const void* out, const float* nlse, const void* grad_out,
+                             void* grad_q, void* grad_k, void* grad_v, void* ws, size_t ws_bytes, void* stream_) {
+    if (int rc = sdpa_args("foho_sdpa_bwd", d, true)) return rc;
+    if (!q || !k || !v || !out || !nlse || !grad_out || !grad_q || !grad_k || !grad_v || !ws) return fail(FOHO_ERR_BAD_ARG, "foho_sdpa_bwd: null argument");
+    const int M = d->M, L = d->L, heads = d->heads, W = heads * 64;
     const SdpaLayout l = sdpa_layout(M, L, heads);
     if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_sdpa_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream_;
-    const int W = heads * 64;
     char* base = (char*)ws;
-    h16 *kt = (h16*)(base + l.kt), *qst = (h16*)(base + l.qst), *dot = (h16*)(base + l.dot);
+    h16 *kt = (h16*)(base + l.kt), *qs = (h16*)(base + l.qs), *qst = (h16*)(base + l.qst), *dot = (h16*)(base + l.dot);
     float *delta = (float*)(base + l.delta), *part = (float*)(base + l.part);
-    const h16 *Qs = (const h16*)q_scaled, *dO = (const h16*)grad_out, *KV = (const h16*)kv;
-    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, KV, 2 * W, W, L, kt, 0);      // K^T, key-permuted
-    if (M & 63) {   // columns of the transposed copies beyond M meet P = 0 and must be finite
-        const size_t n16 = (size_t)W * l.ldt * 2 / 16;
-        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)qst, n16);
-        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dot, n16);
+    const size_t nl = (size_t)((M + 63) & ~63) * heads;
+    const int nkb = L / 128, kvr = (int)d->kv_row, kvh = (int)d->kv_head;
+    for (int b = 0; b < d->batch; b++) {
+        const h16 *qb = (const h16*)q + (size_t)b * d->q_batch, *kb = (const h16*)k + (size_t)b * d->kv_batch, *vb = (const h16*)v + (size_t)b * d->kv_batch;
+        const h16 *dO = (const h16*)grad_out + (size_t)b * M * W, *O = (const h16*)out + (size_t)b * M * W;
+        const float* nls = nlse + b * nl;
+        hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, kb, kvr, W, L, kt, 0, kvh);      // K^T, key-permuted
+        if (M & 63) {   // columns of the transposed copies beyond M meet P = 0 and must be finite
+            const size_t n16 = (size_t)W * l.ldt * 2 / 16;
+            hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)qst, n16);
+            hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dot, n16);
+        }
+        const unsigned tb = (unsigned)(((size_t)M * (W / 8) + 255) / 256);
+        hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, qb, (int)d->q_row, M, W, qst, l.ldt, (int)d->q_head, SDPA_QSCALE, qs);
+        hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, dO, W, M, W, dot, l.ldt);
+        hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), dim3(256), 0, s, dO, O, W, heads, M, delta, (const int*)nullptr);
+        if (!launch_ok("foho_sdpa_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((heads * l.splits + 7) / 8) * nkb), dim3(256), 0, s, (const h16*)qs, (const h16*)qst, dO, (const h16*)dot, l.ldt, nls,
+                           (const float*)delta, kb, kvr, W, heads, M, l.splits, L, 0, part, (const int*)nullptr, vb, kvh);
+        const size_t n4 = (size_t)L * 2 * W / 4;
+        hipLaunchKernelGGL(k_geo_dkv_reduce16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, l.splits, L, W, (h16*)grad_k + (size_t)b * L * W,
+                           (h16*)grad_v + (size_t)b * L * W);
+        hipLaunchKernelGGL(k_geo_attn_dq, dim3(((M + DQQ - 1) / DQQ) * heads), dim3(256), 0, s, (const h16*)qs, dO, W, kb, kvr, W, (const h16*)kt, L, nls, (const float*)delta,
+                           (h16*)grad_q + (size_t)b * M * W, M, heads, vb, kvh);
     }
-    const unsigned tb = (unsigned)(((size_t)M * (W / 8) + 255) / 256);
-    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, Qs, W, M, W, qst, l.ldt);
-    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, dO, W, M, W, dot, l.ldt);
-    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), dim3(256), 0, s, dO, (const h16*)out, W, heads, M, delta, (const int*)nullptr);
-    if (!launch_ok("foho_sdpa_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
-    const int nkb = L / 128;
-    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((heads * l.splits + 7) / 8) * nkb), dim3(256), 0, s, Qs, (const h16*)qst, dO, (const h16*)dot, l.ldt, nlse, (const float*)delta,
-                       KV, 2 * W, W, heads, M, l.splits, L, 0, part, (const int*)nullptr);
-    const size_t n4 = (size_t)L * 2 * W / 4;
-    hipLaunchKernelGGL(k_geo_dkv_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, l.splits, n4, grad_kv);
-    hipLaunchKernelGGL(k_geo_attn_dq, dim3(((M + DQQ - 1) / DQQ) * heads), dim3(256), 0, s, Qs, dO, W, KV, 2 * W, W, (const h16*)kt, L, nlse, (const float*)delta,
-                       (h16*)grad_q, M, heads);
     return launch_ok("k_geo_attn_dq") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
 

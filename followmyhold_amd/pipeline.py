@@ -36,17 +36,21 @@ from .scheduler import retrieve_timesteps
 
 
 def vae_attention_backend():
-    """Context for the ShapeVAE transformer's forward (and the backward recorded under it): torch's scaled_dot_product_attention with
-    the memory-efficient kernel FIRST.  At the transformer's shape -- (1, 16 heads, 3072 tokens, 64) fp16, sixteen layers, run and
-    back-propagated in every inner iteration (PL:295, 1391-1393, 1507-1509) -- ROCm's default (flash, AOTriton) backend takes 509 us
-    per layer forward + backward on an MI355X, the efficient one 350 us (scripts/dev_sdpa.py): 3 ms of a 26 ms iteration.  The
-    other backends stay allowed behind it (a shape the efficient kernel does not take falls through).
-    FOHO_VAE_SDPA=default leaves torch's own choice alone; FOHO_VAE_SDPA=hip sends the eligible calls to this repository's attention
-    kernels instead (followmyhold_amd.sdpa: forward 63 us, backward 170 us of kernels per layer, but 380 us with the layout copies around
-    them -- measured no faster than the efficient backend at 3072 tokens, hence not the default)."""
+    """Context for the ShapeVAE transformer's forward (and the backward recorded under it).  At the transformer's shape -- (1, 16 heads,
+    3072 tokens, 64) fp16, sixteen layers, run and back-propagated in every inner iteration (PL:295, 1391-1393, 1507-1509) -- torch's
+    scaled_dot_product_attention is a quarter of an iteration: forward + backward per layer on an MI355X 509-548 us with ROCm's default
+    (flash, AOTriton) backend, 350 us with the memory-efficient one (139 forward, 212 backward: `vae_attention` bench record).
+    FOHO_VAE_SDPA selects:
+      hip (default)  the forward on this package's attention kernels (followmyhold_amd.sdpa: 68 us, operands read where the projections
+                     left them), the backward by torch's memory-efficient kernels from that forward's output and log-sum-exp -- the
+                     faster side of each pair, one image or a batch; calls the kernels do not take (a mask, another head size) and
+                     everything outside this context stay torch's, with the memory-efficient backend preferred;
+      hip_bwd        ... with the package's own backward kernels as well (level for one image, slower for a batch);
+      efficient      torch's memory-efficient backend first, the others allowed behind it;
+      default        torch's own choice, as the reference runs."""
     import contextlib
-    mode = os.environ.get("FOHO_VAE_SDPA", "efficient")
-    if mode not in ("efficient", "hip") or not torch.cuda.is_available():
+    mode = os.environ.get("FOHO_VAE_SDPA", "hip")
+    if mode not in ("efficient", "hip", "hip_bwd") or not torch.cuda.is_available():
         return contextlib.nullcontext()
     stack = contextlib.ExitStack()
     try:
@@ -54,9 +58,9 @@ def vae_attention_backend():
         stack.enter_context(sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True))
     except (ImportError, TypeError):       # an older torch without the priority form: its own choice
         pass
-    if mode == "hip":
+    if mode != "efficient":
         from . import sdpa
-        stack.enter_context(sdpa.hip_sdpa())
+        stack.enter_context(sdpa.hip_sdpa(backward="hip" if mode == "hip_bwd" else "torch"))
     return stack
 
 

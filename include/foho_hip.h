@@ -495,17 +495,25 @@ int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, in
 /* Attention as an operator, forward and backward (version 104): O = softmax(Q K^T / sqrt(64)) V per head of 64 -- what
  * torch.nn.functional.scaled_dot_product_attention computes (no mask, no dropout) for the self-attention layers of the ShapeVAE
  * transformer that latent2sdf runs and back-propagates in front of the geometry decoder in every inner iteration (PL:295, 1391-1393,
- * 1507-1509).  The kernels are the decoder's own (k_geo_attn; k_geo_attn_bwd for dK / dV) plus k_geo_attn_dq.  One (batch item, all
- * heads) per call.  q_scaled (M, 64 heads) fp16 = q x log2(e) / 8 with a row's heads side by side; kv (L, 128 heads) fp16 = [K of all
- * heads | V of all heads] per key row; out (M, 64 heads) fp16; nlse ((M rounded up to 64), heads) fp32, written by the forward and
- * handed back to the backward (minus the log2 of the softmax denominator); grad_out (M, 64 heads) fp16; grad_q (M, 64 heads) fp16 =
- * d / d q (the UNSCALED q); grad_kv (L, 128 heads) fp32.  L a multiple of 64 (128 for the backward), 1..16 heads.  followmyhold_amd.sdpa
- * wraps them as an autograd function and can stand in for F.scaled_dot_product_attention inside a context. */
+ * 1507-1509).  The kernels are the decoder's own (k_geo_attn; k_geo_attn_bwd for dK / dV) plus k_geo_attn_dq.
+ * q, k, v: fp16, read WHERE THEY LIE -- element (batch b, head h, row n, d) of q at q + b q_batch + n q_row + h q_head + d (k and v
+ * share kv_batch / kv_row / kv_head); that covers (B, N, H, 64) tensors viewed as (B, H, N, 64), the [K | V] output of one Linear
+ * (kv_row = 2 x 64 H, v = k + 64 H) and hy3dgen's interleaved q | k | v per head (row 3 x 64 H, head 192).  The 1 / sqrt(64) scale
+ * and the log2(e) of the exp2 softmax are applied inside.  out (batch, M, 64 H) fp16, heads side by side; nlse (batch, M rounded up
+ * to 64, H) fp32, written by the forward and handed back to the backward (either may be NULL); lse_natural (batch, H, M) fp32: the
+ * natural-log log-sum-exp of the scaled scores, the form torch's own attention backward takes; grad_out / grad_q like out, grad_k / grad_v (batch, L,
+ * 64 H) fp16.  L a multiple of 64 (128 for the backward), 1..16 heads; one workspace (foho_sdpa_workspace_bytes) serves any batch.
+ * followmyhold_amd.sdpa wraps them as an autograd function and can stand in for F.scaled_dot_product_attention inside a context. */
+typedef struct foho_sdpa_desc {
+    int32_t M, L, heads, batch;           /* queries, keys, heads of 64, batch items */
+    int64_t q_batch, q_row, q_head;       /* strides of q in halfs */
+    int64_t kv_batch, kv_row, kv_head;    /* strides of k and of v in halfs */
+} foho_sdpa_desc;
 size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads);
-int foho_sdpa_fwd(const void* q_scaled, const void* kv, void* out, float* nlse, int32_t M, int32_t L, int32_t heads, void* workspace,
-                  size_t workspace_bytes, void* stream);
-int foho_sdpa_bwd(const void* q_scaled, const void* kv, const void* out, const float* nlse, const void* grad_out, void* grad_q, float* grad_kv,
-                  int32_t M, int32_t L, int32_t heads, void* workspace, size_t workspace_bytes, void* stream);
+int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, void* out, float* nlse, float* lse_natural,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, const void* out, const float* nlse,
+                  const void* grad_out, void* grad_q, void* grad_k, void* grad_v, void* workspace, size_t workspace_bytes, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.

@@ -17,18 +17,28 @@ def test_sdpa_argument_checks_run_without_a_gpu():
     assert lib.foho_sdpa_workspace_bytes(3072, 3000, 16) == 0            # keys not a multiple of 64
     assert lib.foho_sdpa_workspace_bytes(3072, 3072, 17) == 0
     lib.foho_sdpa_fwd.restype = lib.foho_sdpa_bwd.restype = ctypes.c_int
-    assert lib.foho_sdpa_fwd(None, None, None, None, 64, 128, 2, None, ctypes.c_size_t(0), None) != 0
-    one = ctypes.c_void_p(1)
-    assert lib.foho_sdpa_bwd(one, one, one, one, one, one, one, 64, 192, 2, one, ctypes.c_size_t(1 << 40), None) != 0      # 192 keys: forward only
     from followmyhold_amd import sdpa
+    one = ctypes.c_void_p(1)
+    d = sdpa.FohoSdpaDesc(64, 128, 2, 1, 64 * 128, 128, 64, 128 * 256, 256, 64)
+    assert lib.foho_sdpa_fwd(None, one, one, one, one, None, None, one, ctypes.c_size_t(1 << 40), None) != 0                 # no descriptor
+    assert lib.foho_sdpa_fwd(ctypes.byref(d), None, None, None, None, None, None, None, ctypes.c_size_t(0), None) != 0      # null operands
+    assert lib.foho_sdpa_fwd(ctypes.byref(d), one, one, one, one, None, None, one, ctypes.c_size_t(16), None) != 0           # workspace too small
+    d.L = 192                                                                                                               # 192 keys: forward only
+    assert lib.foho_sdpa_bwd(ctypes.byref(d), one, one, one, one, one, one, one, one, one, one, ctypes.c_size_t(1 << 40), None) != 0
+    d.L, d.q_head = 128, 60                                                                                                 # strides: multiples of 8 halfs
+    assert lib.foho_sdpa_bwd(ctypes.byref(d), one, one, one, one, one, one, one, one, one, one, ctypes.c_size_t(1 << 40), None) != 0
     q = torch.zeros(1, 2, 8, 64)
     assert not sdpa.eligible(q, q, q)                                    # CPU / fp32: torch's business
 
 
 @gpu
+@pytest.mark.parametrize("route", ["hip", "torch"])
 @pytest.mark.parametrize("B,H,M,Lk", [(1, 2, 256, 256), (2, 4, 300, 384), (1, 16, 3072, 3072), (1, 16, 70, 128)])
-def test_attention_forward_and_backward_against_torch_math(B, H, M, Lk):
+def test_attention_forward_and_backward_against_torch_math(B, H, M, Lk, route, monkeypatch):
+    """route: the backward behind the HIP forward -- the package's own kernels, or torch's memory-efficient attention backward fed with
+    the HIP forward's output and log-sum-exp (the default)."""
     from followmyhold_amd import sdpa
+    monkeypatch.setattr(sdpa, "backward_route", route)
     g = torch.Generator().manual_seed(H + M)
     q, k, v = (torch.randn(B, H, n, 64, generator=g).half().cuda() for n in (M, Lk, Lk))
     k[:, 0, 5] *= 3.0                                                   # a key that dominates some rows
@@ -48,10 +58,36 @@ def test_attention_forward_and_backward_against_torch_math(B, H, M, Lk):
         a = a.float()
         cos = F.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
         assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 1.5e-2 * b.abs().max().item() and cos >= 1 - 2e-4, (name, (a - b).abs().max().item(), b.abs().max().item(), cos)
+    # the operands are read where they lie: k and v as the two halves of one projection's output (row 2 x 64 H), q / k / v interleaved
+    # per head as hy3dgen's c_qkv leaves them (row 3 x 64 H, head 192) -- same numbers, same results
+    if B == 1:
+        kv = torch.cat([k.transpose(1, 2).reshape(B, Lk, H * 64), v.transpose(1, 2).reshape(B, Lk, H * 64)], dim=-1).contiguous()
+        ks, vs = (kv[..., i * H * 64:(i + 1) * H * 64].view(B, Lk, H, 64).transpose(1, 2) for i in (0, 1))
+        assert ks.stride() == vs.stride() and ks.stride(2) == 2 * H * 64
+        q3 = q.detach().clone().requires_grad_(True)
+        kv3 = kv.detach().clone().requires_grad_(True)
+        k3, v3 = (kv3[..., i * H * 64:(i + 1) * H * 64].view(B, Lk, H, 64).transpose(1, 2) for i in (0, 1))
+        out3 = sdpa.attention(q3, k3, v3)
+        out3.backward(go)
+        assert torch.equal(out3, out)
+        if route == "hip":
+            assert torch.equal(q3.grad, qh.grad)
+            assert torch.equal(kv3.grad[..., :H * 64].view(B, Lk, H, 64).transpose(1, 2), kh.grad)
+            assert torch.equal(kv3.grad[..., H * 64:].view(B, Lk, H, 64).transpose(1, 2), vh.grad)
+        else:
+            for a, b in ((q3.grad, qh.grad), (kv3.grad[..., :H * 64].view(B, Lk, H, 64).transpose(1, 2), kh.grad), (kv3.grad[..., H * 64:].view(B, Lk, H, 64).transpose(1, 2), vh.grad)):
+                assert (a.float() - b.float()).abs().max().item() <= 2e-3 * b.float().abs().max().item()
+        if M == Lk:
+            qkv = torch.stack([t.transpose(1, 2) for t in (q, k, v)], dim=3).reshape(B, M, H, 192).contiguous()   # (B, N, H, [q | k | v])
+            q4, k4, v4 = (qkv[..., i * 64:(i + 1) * 64].transpose(1, 2) for i in (0, 1, 2))
+            assert q4.stride(1) == 192 and torch.equal(q4, q)
+            assert torch.equal(sdpa.attention(q4, k4, v4), out)
+    assert not sdpa._torch_route_refused                                # (the torch route did not fall back)
     # repeatable: no atomics anywhere in the three kernels
-    q2, k2, v2 = (t.clone().requires_grad_(True) for t in (q, k, v))
-    sdpa.attention(q2, k2, v2).backward(go)
-    assert torch.equal(q2.grad, qh.grad) and torch.equal(k2.grad, kh.grad) and torch.equal(v2.grad, vh.grad)
+    if route == "hip":
+        q2, k2, v2 = (t.clone().requires_grad_(True) for t in (q, k, v))
+        sdpa.attention(q2, k2, v2).backward(go)
+        assert torch.equal(q2.grad, qh.grad) and torch.equal(k2.grad, kh.grad) and torch.equal(v2.grad, vh.grad)
 
 
 @gpu
