@@ -585,6 +585,12 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 #ifdef P8_STAMPS
 __device__ unsigned long long g_p8[8][8];
 #endif
+#ifdef P8_TIMELINE   // development build: per workgroup, shader-clock stamps of {entry, first tile landed, loop end, groups re-joined, exit} + HW_ID / XCC_ID
+__device__ unsigned long long g_p8tl[4096][8];
+#define P8_TL(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i]))
+#else
+#define P8_TL(i) do { } while (0)
+#endif
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -594,7 +600,10 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
                                                        int ldc2, const int* __restrict__ Mdev) {
-    __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
+    // [buffer][A | W][256 rows x 8 chunks] = 128 KB, + 9.5 KB: the epilogue's image (8 waves x 64 rows x 72 halfs = 72 KB) lies over buffer 1
+    // and this tail, so that buffer 0 can take the NEXT tile's first K tile while the epilogue runs
+    __shared__ uint4 ldsx[2 * 2 * (HM * GK * 2 / 16) + 608];
+    uint4 (&lds)[2][2][HM * GK * 2 / 16] = *reinterpret_cast<uint4 (*)[2][2][HM * GK * 2 / 16]>(ldsx);
     // the epilogue's column vectors (bias; EP_PREAFF: the folded weights' row sums and the rows' statistics; EP_LOGIT: gamma w_out) wait
     // in LDS from the start of the tile: the epilogue of a K = 1024 tile has no global round trip of its own to sit out
     __shared__ float ext_b[HN], ext_s[HN];
@@ -603,20 +612,48 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntn = N / HN, ntm = (M + HM - 1) / HM;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int mp = (j / ntn) * 8 + xcd, nt = j % ntn;
-    if (mp >= ntm) return;
-    const int m0 = mp * HM, n0 = nt * HN;
+    // PERSISTENT: a workgroup walks the tiles L = blockIdx.x, + gridDim.x, ... (the host launches one workgroup per CU when there are
+    // more tiles than CUs).  Measured per tile of the fc1 shape before (shader cycles, scripts/dev_p8_timeline.py): K loop 36 900, but
+    // 8 300 from entry to the first matrix instruction (the first K tile's DMA: 2 700 until this wave's pieces land + 3 900 until the
+    // slowest wave's), 4 300 epilogue and 3 300 between one workgroup's exit and the next one's entry on the CU.  Here the next
+    // tile's first K tile is fetched into buffer 0 WHILE the epilogue runs, and there is no exit / entry in between.
+    const int total = 8 * ((ntm + 7) / 8) * ntn;
+    auto tile_of = [&](int L_, int& m0_, int& n0_) {
+        const int xcd = L_ & 7, j = L_ >> 3, mp = (j / ntn) * 8 + xcd;
+        m0_ = mp * HM, n0_ = (j % ntn) * HN;
+        return mp < ntm;
+    };
+    int L = blockIdx.x, m0 = 0, n0 = 0;
+    while (L < total && !tile_of(L, m0, n0)) L += gridDim.x;
+    if (L >= total) return;
     const int wr = w >> 2, wc = w & 3;  // this wave's 128 (M) x 64 (N) part of the tile; wr = its group
+#ifdef P8_TIMELINE
+    unsigned long long tl_[8];
+#endif
+    P8_TL(0);
     float ev0 = 0.0f, ev1 = 0.0f;
     float2 ev2 = float2{1.0f, 0.0f};
-    if (tid < HN) {
-        ev0 = bias[n0 + tid];
-        if (EP & EP_PREAFF) ev1 = bias[ldr + n0 + tid];
-        if (EP & EP_LOGIT) ev1 = bias[64 * ldc2 + n0 + tid];
-    } else if (EP & EP_PREAFF) {
-        ev2 = reinterpret_cast<const float2*>(R)[min(m0 + tid - HN, M - 1)];
-    }
+#define P8_EV_LOAD(E0, E1, E2, M0, N0)                                                     \
+    do {                                                                                   \
+        if (tid < HN) {                                                                    \
+            E0 = bias[(N0) + tid];                                                         \
+            if (EP & EP_PREAFF) E1 = bias[ldr + (N0) + tid];                               \
+            if (EP & EP_LOGIT) E1 = bias[64 * ldc2 + (N0) + tid];                          \
+        } else if (EP & EP_PREAFF) {                                                       \
+            E2 = reinterpret_cast<const float2*>(R)[min((M0) + tid - HN, M - 1)];          \
+        }                                                                                  \
+    } while (0)
+    P8_EV_LOAD(ev0, ev1, ev2, m0, n0);
+#define P8_EV_WRITE()                                                                      \
+    do {                                                                                   \
+        if (tid < HN) {                                                                    \
+            ext_b[tid] = ev0;                                                              \
+            if (EP & (EP_PREAFF | EP_LOGIT)) ext_s[tid] = ev1;                             \
+        } else if (EP & EP_PREAFF) {                                                       \
+            ext_r[tid - HN] = ev2;                                                         \
+        }                                                                                  \
+    } while (0)
+    P8_EV_WRITE();   // (the first tile's vectors: one exposed round trip per workgroup; the later tiles' travel during the K loop)
 
     // ---- LDS-DMA pieces of this wave: per K tile two pieces in each of four phases.  A piece = 8 rows x 128 bytes; a lane's 16 bytes
     // land at (row0 + lane / 8, slot lane % 8), so it FETCHES chunk slot ^ swz(row); swz(row0 + r) depends on row0 only through
@@ -637,13 +674,14 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, (short)0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
     int sq[4][2];   // scalar byte offsets of the pieces at K tile 0
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        sq[0][e] = (n0 + rowq[0][e]) * ldw * 2;
-        sq[1][e] = (m0 + rowq[1][e]) * lda * 2;
-        sq[2][e] = (m0 + rowq[2][e]) * lda * 2;
-        sq[3][e] = (n0 + rowq[3][e]) * ldw * 2;
+#define P8_SET_SQ(M0, N0)                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 2; e++) {                                        \
+        sq[0][e] = ((N0) + rowq[0][e]) * ldw * 2;                                          \
+        sq[1][e] = ((M0) + rowq[1][e]) * lda * 2;                                          \
+        sq[2][e] = ((M0) + rowq[2][e]) * lda * 2;                                          \
+        sq[3][e] = ((N0) + rowq[3][e]) * ldw * 2;                                          \
     }
+    P8_SET_SQ(m0, n0);
 #ifndef P8_ABL
 #define P8_ABL 0
 #endif
@@ -675,12 +713,6 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     } while (0)
 
     f32x16 acc[2][4];  // [n tile][m tile]
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
     const int ra = wr * 128 + l31, rw = wc * 64 + l31;
     const unsigned base = lds_addr(&lds[0][0][0]);
@@ -693,26 +725,36 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     const int nk = K / GK;
     half8 fa0[4][2], fa1[4][2], fw0[4], fw1[4];   // A rows sub 0 / sub 1 (two 32-row tiles each), W columns sub 0 / sub 1, by K step
 
-    // ---- prologue: K tile 0 whole and the three quarters of K tile 1 the steady state would have issued by now; then W columns sub 0
-    // of tile 0 into registers; the second group starts one barrier late
+    // ---- prologue: K tile 0 whole (for every tile but the workgroup's first it is already on its way: issued before the previous
+    // tile's epilogue) and the three quarters of K tile 1 the steady state would have issued by now; then W columns sub 0 of tile 0
+    // into registers; the second group starts one barrier late
 #pragma unroll
     for (int q = 0; q < 4; q++) P8_DMA(q, 0, 0);
+  for (;;) {   // ---- one output tile per pass
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+    // the next tile of this workgroup: its vectors travel (into registers) during this tile's K loop
+    int Ln = L + gridDim.x, m0n = 0, n0n = 0;
+    while (Ln < total && !tile_of(Ln, m0n, n0n)) Ln += gridDim.x;
+    const bool more = Ln < total;
+    if (more) P8_EV_LOAD(ev0, ev1, ev2, m0n, n0n);
     P8_DMA(0, 1, GK * 2);
     P8_DMA(1, 1, GK * 2);
     P8_DMA(2, 1, GK * 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (tid < HN) {
-        ext_b[tid] = ev0;
-        if (EP & (EP_PREAFF | EP_LOGIT)) ext_s[tid] = ev1;
-    } else if (EP & EP_PREAFF) {
-        ext_r[tid - HN] = ev2;
-    }
+    P8_TL(5);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (everything older than the six pieces: the first K tile -- and the previous tile's stores)
+    P8_TL(6);
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk], 32768);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]));
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();
+    P8_TL(1);
 
 #define P8_DSR(dst, addr, off)                 \
     do {                                        \
@@ -820,23 +862,16 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     P8_TILE(1, 0, 0, 0, 8, 6, 4, 2);   // t = nk - 2: only W columns sub 1 of the last tile is still to come
     t++;
     P8_TILE(0, 0, 0, 0, 0, 0, 0, 0);   // t = nk - 1
-#undef P8_TILE
-#undef P8_COMPUTE
-#undef P8_SYNC8
-#undef P8_SYNC4
-#undef P8_DMA
-#undef P8_WAIT
-#undef P8_DSR
 #ifdef P8_STAMPS
     if (blockIdx.x == 0 && lane == 0) {
         for (int q_ = 0; q_ < 6; q_++) g_p8[w][q_] = (unsigned long long)(long long)seg[q_];
         g_p8[w][6] = nk;
     }
 #endif
-    // the epilogue's operands from global memory are on their way while the groups meet (the fragment registers are free now)
+    P8_TL(2);
+    // ---- the epilogue's column vectors and row statistics from LDS into registers ...
     EpiCols pc;
     EpiRows pr[2];
-    if (!(EP & EP_PREAFF)) epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);   // (residual rows: from global memory)
 #pragma unroll
     for (int g8 = 0; g8 < 8; g8++) {
         const int nl = wc * 64 + (g8 >> 2) * 32 + 8 * (g8 & 3) + 4 * hi;
@@ -856,15 +891,57 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
                 pr[half].rs[i] = st.x, pr[half].mr[i] = st.y;
             }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (wr == 0 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
-    __syncthreads();
+    __syncthreads();                                              // every wave is done with both buffers and has the vectors in registers
+    P8_TL(3);
+    // ... the next tile's into their place (nothing of this wave's is in flight here: the wait the compiler puts in front is free) ...
+    if (more) P8_EV_WRITE();
+    // ... the residual rows of BOTH parts from global memory (a later load would queue behind the next tile's DMA: vmcnt is in order) ...
+    if (!(EP & EP_PREAFF)) {
+        epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);
+        epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    }
+    const int m0c = m0, n0c = n0;
+    if (more) {   // ... and the next tile's first K tile into buffer 0, on its way during the epilogue
+        m0 = m0n, n0 = n0n;
+        P8_SET_SQ(m0, n0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) P8_DMA(q, 0, 0);
+    }
 
-    h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
-    if (!(EP & EP_PREAFF)) epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+    h16* img = reinterpret_cast<h16*>(&lds[1][0][0]) + w * (64 * CPAD);
 #pragma unroll
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
+                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane);
+#ifdef P8_TIMELINE
+    P8_TL(4);
+    if (tid == 0 && L < 4096) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        for (int i_ = 0; i_ < 5; i_++) g_p8tl[L][i_] = tl_[i_];
+        g_p8tl[L][5] = hwid;
+        g_p8tl[L][6] = xcc;
+        g_p8tl[L][7] = ((tl_[5] - tl_[0]) << 32) | ((tl_[6] - tl_[5]) & 0xffffffffull);   // entry -> DMA issued | -> first tile landed
+    }
+#endif
+    if (!more) break;
+    __syncthreads();   // the image (buffer 1) and the vectors' LDS slots are free for the next tile
+    L = Ln;
+    P8_TL(0);
+  }
+#undef P8_TILE
+#undef P8_COMPUTE
+#undef P8_SYNC8
+#undef P8_SYNC4
+#undef P8_DMA
+#undef P8_WAIT
+#undef P8_DSR
+#undef P8_EV_LOAD
+#undef P8_EV_WRITE
+#undef P8_SET_SQ
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2010,7 +2087,17 @@ static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int ld
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
     // the phased kernel addresses its operands through 32-bit buffer offsets
     const bool phased = big && K / GK >= 2 && !g_force_lockstep && !env_lockstep() && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31);
-    if (phased) hipLaunchKernelGGL(k_geo_gemm8p<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    if (phased) {
+        // persistent: one workgroup per CU walks the tiles (a multiple of 8 workgroups: the tile order deals consecutive tiles to the 8 XCDs)
+        static const unsigned ncu = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+            return (unsigned)(n & ~7);
+        }();
+        const char* e = getenv("FOHO_GEO_GEMM");
+        const bool one_tile = e && std::string(e) == "onetile";   // A/B: one workgroup per tile, as before
+        hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(one_tile ? grid.x : std::min(grid.x, ncu)), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    }
     else if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
 }
@@ -2125,6 +2212,9 @@ using namespace geo;
 extern "C" const char* foho_geo_last_error(void) { return g_err; }
 #ifdef P8_STAMPS
 extern "C" void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geo::g_p8), sizeof(geo::g_p8)); }
+#endif
+#ifdef P8_TIMELINE
+extern "C" void foho_geo_p8_timeline(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geo::g_p8tl), sizeof(geo::g_p8tl)); }
 #endif
 
 extern "C" int64_t foho_geo_abi_size(void) { return (int64_t)sizeof(foho_geo_weights); }
