@@ -61,10 +61,6 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ void glds4(const void* src, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]),  fp16 in / fp32 accumulate / fp16 out.
@@ -130,14 +126,13 @@ constexpr int EP_GELUBWD = 4, EP_SAVEZ = 8, EP_TRANS = 16;
 constexpr int EP_QNORM = 32;
 // LayerNorm folded into the GEMMs on either side of it (forward only; chain_latent_side explains the algebra):
 // EP_STATS (with EP_RESID): besides the output, the statistics of every output row's 64 columns of this part -- their mean and the sum
-//   of squared deviations from it, taken from the fp16-rounded values the output holds, per part of 32 columns -- go to
-//   ((float*)C2)[(row * ldc2 + column / 32) * 2], ldc2 = N / 32 slots per row; k_geo_rowstat_finish merges a row's slots (exactly:
-//   Chan's update, no E[x^2] - mean^2).
+//   of squared deviations from it, taken from the fp16-rounded values the output holds -- go to ((float*)C2)[(row * ldc2 + n0 / 64) * 2],
+//   ldc2 = N / 64 slots per row; k_geo_rowstat_finish merges a row's slots (exactly: Chan's update, no E[x^2] - mean^2).
 // EP_PREAFF (with EP_GELU): the GEMM ran on the UN-normalised rows with gamma folded into the weights; the pre-activation is
 //   rstd[m] * acc - (rstd[m] mean[m]) * s[n] + b'[n]: (rstd, rstd * mean) per row as float2 in the R slot, b' = bias[0..N), s = bias[N..2N)
 //   (ldr = N).
 // EP_LOGIT (with EP_RESID): the output itself is NOT stored; per row and part (mean, sum of squared deviations, sum of value x gw[n])
-//   go to ((float*)C2)[(row * ldc2 + column / 32) * 4], gw = bias[N..2N) (N = 32 ldc2): what ln_post + output_proj need of the row.
+//   go to ((float*)C2)[(row * ldc2 + n0 / 64) * 4], gw = bias[N..2N) (N = 64 ldc2): what ln_post + output_proj need of the row.
 constexpr int EP_STATS = 64, EP_PREAFF = 128, EP_LOGIT = 256;
 
 __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
@@ -155,11 +150,6 @@ __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(
 
 // sum over the 8 consecutive lanes that hold one row of the epilogue's read-back (all of them get it): three DPP adds -- quad_perm
 // [1,0,3,2], [2,3,0,1], row_half_mirror -- where __shfl_xor is three ds_bpermute round trips through the LDS pipe
-__device__ __forceinline__ float sum4(float x) {   // over a quad of lanes (all four get it): two DPP adds
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));
-    return x;
-}
 __device__ __forceinline__ float sum8(float x) {
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));
@@ -191,7 +181,7 @@ __device__ __forceinline__ void epi_cols(EpiCols& c, const float* __restrict__ b
         }
     if (EP & EP_LOGIT) {
         const int gn = n0 + (lane & 7) * 8;
-        c.g0 = *reinterpret_cast<const f32x4*>(bias + 32 * ldc2 + gn), c.g1 = *reinterpret_cast<const f32x4*>(bias + 32 * ldc2 + gn + 4);
+        c.g0 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn), c.g1 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn + 4);
     }
 }
 template <int EP>
@@ -310,29 +300,29 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                 for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
             }
             if (gm < M && !(EP & EP_LOGIT)) *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
-            if ((EP & (EP_STATS | EP_LOGIT)) && pass == 1) {   // the row's 64 (rounded) values sit in 8 consecutive lanes: two parts of 32 columns, a quad each
+            if ((EP & (EP_STATS | EP_LOGIT)) && pass == 1) {   // the row's 64 (rounded) values sit in 8 consecutive lanes
                 float x[8], sm = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     x[e] = (float)v[e];
                     sm += x[e];
                 }
-                const float mean = sum4(sm) * (1.0f / 32.0f);
+                const float mean = sum8(sm) * (1.0f / 64.0f);
                 float sq = 0.0f, dot = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const float d = x[e] - mean;
                     sq = __builtin_fmaf(d, d, sq);
                 }
-                sq = sum4(sq);
+                sq = sum8(sq);
                 if (EP & EP_LOGIT) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) dot = __builtin_fmaf(x[e], pc.g0[e], __builtin_fmaf(x[4 + e], pc.g1[e], dot));
-                    dot = sum4(dot);
+                    dot = sum8(dot);
                 }
-                if ((ch & 3) == 0 && gm < M) {
+                if (ch == 0 && gm < M) {
                     float* st = reinterpret_cast<float*>(C2);
-                    const size_t at = (size_t)gm * ldc2 + (n0 >> 5) + (ch >> 2);
+                    const size_t at = (size_t)gm * ldc2 + (n0 >> 6);
                     if (EP & EP_LOGIT) *reinterpret_cast<f32x4*>(st + at * 4) = f32x4{mean, sq, dot, 0.0f};
                     else *reinterpret_cast<float2*>(st + at * 2) = float2{mean, sq};
                 }
@@ -648,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         if (tid < HN) {                                                                    \
             E0 = bias[(N0) + tid];                                                         \
             if (EP & EP_PREAFF) E1 = bias[ldr + (N0) + tid];                               \
-            if (EP & EP_LOGIT) E1 = bias[32 * ldc2 + (N0) + tid];                          \
+            if (EP & EP_LOGIT) E1 = bias[64 * ldc2 + (N0) + tid];                          \
         } else if (EP & EP_PREAFF) {                                                       \
             E2 = reinterpret_cast<const float2*>(R)[min((M0) + tid - HN, M - 1)];          \
         }                                                                                  \
@@ -955,360 +945,6 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 }
 
 // ------------------------------------------------------------------------------------------------
-// The phased GEMM as ONE STREAM over the tiles of a workgroup (k_geo_gemm8s): the K loop of k_geo_gemm8p, never drained.  One workgroup per
-// CU walks its output tiles; the first K tile of the NEXT output tile is simply K tile nk of the stream -- its quarters are issued in the
-// load segments of this tile's last two K tiles, with the next tile's offsets, into the buffers the schedule would use anyway (K / 64 even:
-// K tile 0 of every output tile lies in buffer 0) -- so that a tile begins in the steady state: no prologue, no wait for a first K tile
-// (measured on k_geo_gemm8p at the fc1 shape, shader cycles per tile: K loop 36 900; entry -> first matrix instruction 8 300; epilogue
-// 4 300; exit -> next entry 3 300).  What makes room for it: both LDS buffers belong to the stream at all times, so the epilogue
-// works on a wave-private image of ONE 32 x 32 accumulator tile (2.5 KB per wave, outside the buffers; eight passes per wave), and its
-// column vectors / row statistics arrive by 4-byte LDS-DMA in a double-buffered 4 KB slot during the previous tile's K loop -- no
-// register of the K loop carries anything for the epilogue.  Epilogues: plain, GELU, residual, and the folded-LayerNorm forms.
-// ------------------------------------------------------------------------------------------------
-constexpr int CP32 = 40;   // halfs per row of the 32 x 32 image (32 + 8: 16-byte aligned rows, banks spread)
-// One 32 (n) x 32 (m) accumulator tile t (transposed C layout: a lane holds, for m = lane & 31, n = 8 g + 4 (lane >> 5) + 0..3) ->
-// C[m0 .. +31][n0 .. +31].  b / sv: bias (and, EP_PREAFF, folded row sums) of the lane's columns per group g; rs / mr: EP_PREAFF's
-// (rstd, rstd mean) of the lane's row; res: the residual chunks of the two rows x 8 columns the lane reads back; gw: EP_LOGIT's
-// gamma w_out of those 8 columns.  Statistics (EP_STATS / EP_LOGIT) per row and 32-column part.
-template <int EP>
-__device__ __forceinline__ void gemm_epilogue32(const f32x16& t, h16* img, const f32x4* b, const f32x4* sv, float rs, float mr, const half8* res,
-                                                const f32x4* gw, h16* __restrict__ C, int ldc, float* __restrict__ stats, int nslots, int M, float scale,
-                                                int m0, int n0, int lane) {
-    const int hi = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        half4 o;
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {
-            f32x2 v = {t[4 * g + q], t[4 * g + q + 1]};
-            const f32x2 b2 = {b[g][q], b[g][q + 1]};
-            if (EP & EP_PREAFF) {
-                const f32x2 s2 = {sv[g][q], sv[g][q + 1]};
-                v = v * rs + (s2 * -mr + b2);
-            } else {
-                v = v + b2;
-            }
-            if (EP & EP_GELU) v = gelu_erf2(v);
-            v = v * scale;
-            const half2v h = __builtin_convertvector(v, half2v);
-            o[q] = h[0], o[q + 1] = h[1];
-        }
-        *reinterpret_cast<half4*>(img + l31 * CP32 + 8 * g + 4 * hi) = o;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image: only this wave's own writes
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int r = q * 16 + (lane >> 2), c = lane & 3;
-        const int gm = m0 + r, gn = n0 + c * 8;
-        half8 v = *reinterpret_cast<const half8*>(img + r * CP32 + c * 8);
-        if (EP & EP_RESID)
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (h16)((float)v[e] + (float)res[q][e]);
-        if (gm < M && !(EP & EP_LOGIT)) *reinterpret_cast<half8*>(C + (size_t)gm * ldc + gn) = v;
-        if (EP & (EP_STATS | EP_LOGIT)) {   // the row's 32 (rounded) values sit in a quad of lanes
-            float x[8], sm = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                x[e] = (float)v[e];
-                sm += x[e];
-            }
-            const float mean = sum4(sm) * (1.0f / 32.0f);
-            float sq = 0.0f, dot = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float d = x[e] - mean;
-                sq = __builtin_fmaf(d, d, sq);
-            }
-            sq = sum4(sq);
-            if (EP & EP_LOGIT) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) dot = __builtin_fmaf(x[e], gw[0][e], __builtin_fmaf(x[4 + e], gw[1][e], dot));
-                dot = sum4(dot);
-            }
-            if (c == 0 && gm < M) {
-                const size_t at = (size_t)gm * nslots + (n0 >> 5);
-                if (EP & EP_LOGIT) *reinterpret_cast<f32x4*>(stats + at * 4) = f32x4{mean, sq, dot, 0.0f};
-                else *reinterpret_cast<float2*>(stats + at * 2) = float2{mean, sq};
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is reused by the next pass
-}
-
-template <int EP>
-__global__ __launch_bounds__(512, 1) void k_geo_gemm8s(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
-                                                       const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
-                                                       h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                       int ldc2, const int* __restrict__ Mdev) {
-    static_assert((EP & ~(EP_GELU | EP_RESID | EP_STATS | EP_PREAFF | EP_LOGIT)) == 0, "k_geo_gemm8s: epilogue not available on the stream");
-    __shared__ uint4 lds[2][2][HM * GK * 2 / 16];   // [buffer][A | W][256 rows x 8 chunks] = 128 KB: the stream's
-    __shared__ h16 image[8][32 * CP32];              // 20 KB: the epilogue's, one 32 x 32 tile per wave
-    __shared__ float ext[2][4 * HN];                 // 8 KB: [tile parity][bias 256 | row sums or gamma w_out 256 | (rstd, rstd mean) x 256]
-    if (Mdev) M = min(M, *Mdev);
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = N / HN, ntm = (M + HM - 1) / HM;
-    const int total = 8 * ((ntm + 7) / 8) * ntn;
-    auto tile_of = [&](int L_, int& m0_, int& n0_) {   // XCD-aware order: consecutive tiles to the 8 XCDs
-        const int xcd = L_ & 7, j = L_ >> 3, mp = (j / ntn) * 8 + xcd;
-        m0_ = mp * HM, n0_ = (j % ntn) * HN;
-        return mp < ntm;
-    };
-    int L = blockIdx.x, m0 = 0, n0 = 0;
-    while (L < total && !tile_of(L, m0, n0)) L += gridDim.x;
-    if (L >= total) return;
-    const int wr = w >> 2, wc = w & 3;   // this wave's 128 (M) x 64 (N) part of the tile; wr = its group
-
-    // ---- LDS-DMA pieces of this wave (as in k_geo_gemm8p): per K tile two pieces in each of four phases
-    const int srow = lane >> 3, sslot = lane & 7;
-    const int va0 = (srow * lda + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, va1 = (srow * lda + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
-    const int vw0 = (srow * ldw + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, vw1 = (srow * ldw + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
-    int rowq[4][2];
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const int Lp = 2 * w + e;
-        rowq[0][e] = 64 * (Lp >> 2) + 8 * (Lp & 3);
-        rowq[1][e] = 128 * (Lp >> 3) + 8 * (Lp & 7);
-        rowq[2][e] = 128 * (Lp >> 3) + 64 + 8 * (Lp & 7);
-        rowq[3][e] = 64 * (Lp >> 2) + 32 + 8 * (Lp & 3);
-    }
-    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, (short)0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
-    int sq[4][2], sqn[4][2];   // scalar byte offsets of the pieces at K tile 0: this output tile's, the next one's
-#define S8_SET(SQ, M0, N0)                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 2; e++) {                                        \
-        SQ[0][e] = ((N0) + rowq[0][e]) * ldw * 2;                                          \
-        SQ[1][e] = ((M0) + rowq[1][e]) * lda * 2;                                          \
-        SQ[2][e] = ((M0) + rowq[2][e]) * lda * 2;                                          \
-        SQ[3][e] = ((N0) + rowq[3][e]) * ldw * 2;                                          \
-    }
-#define S8_DMA(q, nb, SQ, koff)                                                            \
-    do {                                                                                   \
-        if ((q) == 0 || (q) == 3) {                                                        \
-            dma16(rw_, &lds[nb][1][rowq[q][0] * 8], vw0, SQ[q][0] + (koff));               \
-            dma16(rw_, &lds[nb][1][rowq[q][1] * 8], vw1, SQ[q][1] + (koff));               \
-        } else {                                                                           \
-            dma16(ra_, &lds[nb][0][rowq[q][0] * 8], va0, SQ[q][0] + (koff));               \
-            dma16(ra_, &lds[nb][0][rowq[q][1] * 8], va1, SQ[q][1] + (koff));               \
-        }                                                                                  \
-    } while (0)
-    // the epilogue's vectors of the tile at (M0, N0) into slot E, 4 bytes per lane: waves 0-3 the bias, 4-7 the second column vector,
-    // all eight the 512 floats of the rows' (rstd, rstd mean)
-#define S8_VEC(E, M0, N0)                                                                                                          \
-    do {                                                                                                                           \
-        if (w < 4) glds4(bias + (N0) + w * 64 + lane, &ext[E][w * 64]);                                                            \
-        else if (EP & EP_PREAFF) glds4(bias + ldr + (N0) + (w - 4) * 64 + lane, &ext[E][HN + (w - 4) * 64]);                       \
-        else if (EP & EP_LOGIT) glds4(bias + 32 * ldc2 + (N0) + (w - 4) * 64 + lane, &ext[E][HN + (w - 4) * 64]);                  \
-        if (EP & EP_PREAFF) {                                                                                                      \
-            const int f_ = w * 64 + lane;                                                                                          \
-            glds4(reinterpret_cast<const float*>(R) + 2 * (size_t)min((M0) + (f_ >> 1), M - 1) + (f_ & 1), &ext[E][2 * HN + w * 64]); \
-        }                                                                                                                          \
-    } while (0)
-
-    f32x16 acc[2][4];  // [n tile][m tile]
-    const int ra = wr * 128 + l31, rw = wc * 64 + l31;
-    const unsigned base = lds_addr(&lds[0][0][0]);
-    unsigned aa[4], aw[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-        aa[kk] = base + ra * 128 + (((2 * kk + hi) ^ swz(ra)) << 4);
-        aw[kk] = base + rw * 128 + (((2 * kk + hi) ^ swz(rw)) << 4);
-    }
-    const int nk = K / GK;   // even, >= 2 (the host's choice of this kernel)
-    half8 fa0[4][2], fa1[4][2], fw0[4], fw1[4];   // A rows sub 0 / sub 1 (two 32-row tiles each), W columns sub 0 / sub 1, by K step
-
-#define S8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define S8_COMPUTE(ACC0, ACC1, FW, FA, WAITN)                                                                                       \
-    do {                                                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
-            ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][0], ACC0, 0, 0, 0);                                        \
-            ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][1], ACC1, 0, 0, 0);                                        \
-        }                                                                                                                           \
-        __builtin_amdgcn_s_setprio(0);                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                          \
-        S8_WAIT(WAITN);                                                                                                             \
-        __builtin_amdgcn_s_barrier();                                                                                               \
-    } while (0)
-#define S8_SYNC8(F)                                                                                                                 \
-    do {                                                                                                                            \
-        __builtin_amdgcn_s_barrier();                                                                                               \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1])); \
-    } while (0)
-#define S8_SYNC4(F)                                                                                \
-    do {                                                                                           \
-        __builtin_amdgcn_s_barrier();                                                              \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]));     \
-    } while (0)
-    // One K tile = four phases (k_geo_gemm8p's).  D0: does phase 0 issue W columns sub 1 of stream tile t + 1 (offsets SQ0, K offset
-    // KO0); D1: do phases 1-3 issue W sub 0 / A sub 0 / A sub 1 of stream tile t + 2 (SQ1, KO1); RD: does phase 3 read W sub 0 of the
-    // next K tile (not across output tiles: the next tile reads its own at its start); W0..W3: the counted waits.
-#define S8_TILE(D0, SQ0, KO0, D1, SQ1, KO1, RD, W0, W1, W2, W3)                                                                     \
-    do {                                                                                                                            \
-        const unsigned bo = (unsigned)(t & 1) << 16, bn = bo ^ 0x10000u;                                                            \
-        const int cb = t & 1, nb = cb ^ 1;                                                                                          \
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
-            GEO_DSR(fa0[kk][0], aa[kk] + bo, 0);                                                                                    \
-            GEO_DSR(fa0[kk][1], aa[kk] + bo, 4096);                                                                                 \
-        }                                                                                                                           \
-        if (D0) S8_DMA(3, nb, SQ0, KO0);                                                                                            \
-        S8_SYNC8(fa0);                                                                                                              \
-        S8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0);                                                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
-            GEO_DSR(fa1[kk][0], aa[kk] + bo, 8192);                                                                                 \
-            GEO_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                                \
-        }                                                                                                                           \
-        if (D1) S8_DMA(0, cb, SQ1, KO1);                                                                                            \
-        S8_SYNC8(fa1);                                                                                                              \
-        S8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                                             \
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) GEO_DSR(fw1[kk], aw[kk] + bo, 32768 + 4096);                               \
-        if (D1) S8_DMA(1, cb, SQ1, KO1);                                                                                            \
-        S8_SYNC4(fw1);                                                                                                              \
-        S8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                                             \
-        if (RD) {                                                                                                                   \
-            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk] + bn, 32768);                                  \
-        }                                                                                                                           \
-        if (D1) S8_DMA(2, cb, SQ1, KO1);                                                                                            \
-        S8_SYNC4(fw0);                                                                                                              \
-        S8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3);                                                                             \
-    } while (0)
-
-    // ---- the workgroup's first tile: its vectors, its K tile 0 whole and three quarters of K tile 1 -- the state every later tile finds
-    S8_VEC(0, m0, n0);
-    S8_SET(sq, m0, n0);
-#pragma unroll
-    for (int q = 0; q < 4; q++) S8_DMA(q, 0, sq, 0);
-    S8_DMA(0, 1, sq, GK * 2);
-    S8_DMA(1, 1, sq, GK * 2);
-    S8_DMA(2, 1, sq, GK * 2);
-    S8_WAIT(6);
-    __builtin_amdgcn_s_barrier();
-    int eb = 0;   // which slot holds this tile's vectors
-#ifdef P8_TIMELINE
-    unsigned long long tl_[8];
-#endif
-    for (;;) {
-        P8_TL(0);
-        int Ln = L + gridDim.x, m0n = 0, n0n = 0;
-        while (Ln < total && !tile_of(Ln, m0n, n0n)) Ln += gridDim.x;
-        const bool more = Ln < total;
-        if (more) {   // the next tile's vectors travel during this tile's K loop (older than all of its pieces: landed by the first counted wait)
-            S8_VEC(eb ^ 1, m0n, n0n);
-        } else {      // the workgroup's last tile: the stream runs on all the same (one code path, no drain) -- into a re-fetch of this tile's
-            m0n = m0, n0n = n0;   // first two K tiles that nobody reads; the last wait below collects it before the workgroup's LDS is given up
-        }
-        S8_SET(sqn, m0n, n0n);
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-        // W columns sub 0 of K tile 0 (landed and published: the first tile by the barrier above, every other by the previous tile's waits
-        // and barriers); the second group starts one barrier late
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk], 32768);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]));
-        __builtin_amdgcn_sched_barrier(0);
-        if (wr == 1) __builtin_amdgcn_s_barrier();
-        P8_TL(1);
-
-        int t = 0;
-        for (; t < nk - 2; t++) {
-            const int k1 = (t + 1) * GK * 2, k2 = (t + 2) * GK * 2;
-            S8_TILE(1, sq, k1, 1, sq, k2, 1, 8, 8, 8, 8);
-        }
-        {   // the stream runs on into the next output tile
-            const int k1 = (t + 1) * GK * 2;
-            S8_TILE(1, sq, k1, 1, sqn, 0, 1, 8, 8, 8, 8);             // t = nk - 2: ... + the next tile's K tile 0, three quarters
-            t++;
-            S8_TILE(1, sqn, 0, 1, sqn, GK * 2, 0, 8, 8, 8, 8);        // t = nk - 1: its fourth quarter, three quarters of its K tile 1
-        }
-
-        P8_TL(2);
-        // ---- epilogue: the vectors out of LDS, the groups re-join, the residual rows, eight 32 x 32 passes.  Every index below derives
-        // from `le`, an opaque copy of the lane id: addresses the compiler could compute once per workgroup would stay live across the K
-        // loop (it hoists them out of the tile loop), and that loop has no register to spare
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        const int hie = le >> 5, l31e = le & 31;
-        const float* ev = ext[eb];
-        f32x4 pb[8], ps[8], gwv[2][2];
-        float rs[4] = {1.0f, 1.0f, 1.0f, 1.0f}, mr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int g8 = 0; g8 < 8; g8++) {
-            const int nl = wc * 64 + (g8 >> 2) * 32 + 8 * (g8 & 3) + 4 * hie;
-            pb[g8] = *reinterpret_cast<const f32x4*>(&ev[nl]);
-            if (EP & EP_PREAFF) ps[g8] = *reinterpret_cast<const f32x4*>(&ev[HN + nl]);
-        }
-        if (EP & EP_LOGIT)
-#pragma unroll
-            for (int jn = 0; jn < 2; jn++) {
-                gwv[jn][0] = *reinterpret_cast<const f32x4*>(&ev[HN + wc * 64 + jn * 32 + (le & 3) * 8]);
-                gwv[jn][1] = *reinterpret_cast<const f32x4*>(&ev[HN + wc * 64 + jn * 32 + (le & 3) * 8 + 4]);
-            }
-        if (EP & EP_PREAFF)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float2 st = *reinterpret_cast<const float2*>(&ev[2 * HN + 2 * (wr * 128 + i * 32 + l31e)]);
-                rs[i] = st.x, mr[i] = st.y;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wr == 0) __builtin_amdgcn_s_barrier();   // the first group's barrier count catches up with the second's
-        __syncthreads();                             // (every wave has this tile's vectors: the slot may be refilled from the next tile on)
-        P8_TL(3);
-        half8 res[4][2][2];
-        if (EP & EP_RESID)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int jn = 0; jn < 2; jn++)
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int gm = min(m0 + wr * 128 + i * 32 + q * 16 + (le >> 2), M - 1), gn = n0 + wc * 64 + jn * 32 + (le & 3) * 8;
-                        res[i][jn][q] = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
-                    }
-        h16* img = image[w];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int jn = 0; jn < 2; jn++)
-                gemm_epilogue32<EP>(acc[jn][i], img, &pb[jn * 4], &ps[jn * 4], rs[i], mr[i], res[i][jn], gwv[jn], C, ldc, reinterpret_cast<float*>(C2), ldc2, M, scale,
-                                    m0 + wr * 128 + i * 32, n0 + wc * 64 + jn * 32, le);
-#ifdef P8_TIMELINE
-        P8_TL(4);
-        if (tid == 0 && L < 4096) {
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            for (int i_ = 0; i_ < 5; i_++) g_p8tl[L][i_] = tl_[i_];
-            g_p8tl[L][5] = hwid;
-            g_p8tl[L][6] = xcc;
-            g_p8tl[L][7] = 0;
-        }
-#endif
-        if (!more) {
-            S8_WAIT(0);   // (the re-fetch above: no DMA may land in LDS that is no longer this workgroup's)
-            break;
-        }
-        L = Ln, m0 = m0n, n0 = n0n, eb ^= 1;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) sq[q][e] = sqn[q][e];
-    }
-#undef S8_TILE
-#undef S8_COMPUTE
-#undef S8_SYNC8
-#undef S8_SYNC4
-#undef S8_DMA
-#undef S8_WAIT
-#undef S8_SET
-#undef S8_VEC
-}
-
-// ------------------------------------------------------------------------------------------------
 // Cross attention, head dimension 64: O[M, heads*64] = softmax(Q K^T) V per head, Q pre-scaled by log2(e)/sqrt(64).
 // K rows: Kp + l * ldk + head * 64 (the K half of the KV projection, as the GEMM left it); V: Vt[head][d][pos(l)],
 // transposed, with the keys of every 16-block stored in the order the P fragment holds them (pack_vt below).
@@ -1599,6 +1235,10 @@ __global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV,
 // ------------------------------------------------------------------------------------------------
 constexpr int BQ = 64;  // queries per tile
 
+__device__ __forceinline__ void glds4(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 __device__ __forceinline__ f32x16 cat16(f32x4 a, f32x4 b, f32x4 c, f32x4 d) {
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     const f32x8 lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -2216,40 +1856,27 @@ __global__ __launch_bounds__(256) void k_geo_ln(const h16* __restrict__ X, int l
 // ---- LayerNorm folded into its neighbours (forward chain): the small kernels around the GEMM epilogues EP_STATS / EP_PREAFF / EP_LOGIT.
 // Merge of a row's per-part statistics (parts of 64 columns each: mean_i, M2_i = sum of squared deviations from mean_i):
 // mean = avg(mean_i), M2 = sum M2_i + 64 sum (mean_i - mean)^2 -- exact, no cancellation.
-// Sixteen lanes per row (each takes parts lane and lane + 16 of the row's up to 32 parts of 32 columns), four rows per wave: a row's
-// parts are contiguous.  mean = avg(mean_i), M2 = sum M2_i + 32 sum (mean_i - mean)^2 -- exact, no cancellation.
+// Sixteen lanes per row (one per part; lanes beyond nslots idle), four rows per wave: a row's parts are contiguous.
 __device__ __forceinline__ float sum16(float x) {   // over the 16 lanes of a DPP row; every lane gets it
     x = sum8(x);
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true));   // row_mirror
 }
-__device__ __forceinline__ void merge_parts(const float* mean_i, const float* m2_i, const bool* live, int nslots, float& mean, float& var) {
-    mean = sum16((live[0] ? mean_i[0] : 0.0f) + (live[1] ? mean_i[1] : 0.0f)) / (float)nslots;
-    float m2 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const float d = mean_i[k] - mean;
-        if (live[k]) m2 += m2_i[k] + 32.0f * d * d;
-    }
-    var = sum16(m2) / (32.0f * (float)nslots);
+__device__ __forceinline__ void merge_parts(float mean_i, float m2_i, bool live, int nslots, float& mean, float& var) {
+    mean = sum16(live ? mean_i : 0.0f) / (float)nslots;
+    const float d = mean_i - mean;
+    var = sum16(live ? m2_i + 64.0f * d * d : 0.0f) / (64.0f * (float)nslots);
 }
 // out[row] = (rstd, rstd * mean) of the row whose parts c_proj's epilogue left in `stats`
 __global__ __launch_bounds__(256) void k_geo_rowstat_finish(const float* __restrict__ stats, int nslots, int M, float eps, float2* __restrict__ out,
                                                             const int* __restrict__ Mdev) {
     if (Mdev) M = min(M, *Mdev);
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
-    float mi[2] = {0.0f, 0.0f}, m2[2] = {0.0f, 0.0f};
-    bool live[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        live[k] = row < M && part + 16 * k < nslots;
-        if (live[k]) {
-            const float2 st = reinterpret_cast<const float2*>(stats)[(size_t)row * nslots + part + 16 * k];
-            mi[k] = st.x, m2[k] = st.y;
-        }
-    }
+    const bool live = row < M && part < nslots;
+    float2 st = float2{0.0f, 0.0f};
+    if (live) st = reinterpret_cast<const float2*>(stats)[(size_t)row * nslots + part];
     float mean, var;
-    merge_parts(mi, m2, live, nslots, mean, var);
-    if (live[0] && part == 0) {
+    merge_parts(st.x, st.y, live, nslots, mean, var);
+    if (live && part == 0) {
         const float rstd = rsqrtf(var + eps);
         out[row] = float2{rstd, rstd * mean};
     }
@@ -2261,20 +1888,13 @@ __global__ __launch_bounds__(256) void k_geo_logit_finish(const float* __restric
                                                           float* __restrict__ logits, const int* __restrict__ Mdev) {
     if (Mdev) M = min(M, *Mdev);
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
-    float mi[2] = {0.0f, 0.0f}, m2[2] = {0.0f, 0.0f}, dt = 0.0f;
-    bool live[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        live[k] = row < M && part + 16 * k < nslots;
-        if (live[k]) {
-            const f32x4 st = reinterpret_cast<const f32x4*>(stats)[(size_t)row * nslots + part + 16 * k];
-            mi[k] = st[0], m2[k] = st[1], dt += st[2];
-        }
-    }
+    const bool live = row < M && part < nslots;
+    f32x4 st = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) st = reinterpret_cast<const f32x4*>(stats)[(size_t)row * nslots + part];
     float mean, var;
-    merge_parts(mi, m2, live, nslots, mean, var);
-    const float dot = sum16(dt);
-    if (live[0] && part == 0) {
+    merge_parts(st[0], st[1], live, nslots, mean, var);
+    const float dot = sum16(st[2]);
+    if (live && part == 0) {
         const float rstd = rsqrtf(var + eps);
         const float learned = (float)(h16)(rstd * (dot - mean * fold[0]) + fold[1] + b_out);
         float prior = 0.0f;
@@ -2467,7 +2087,6 @@ static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int ld
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
     // the phased kernel addresses its operands through 32-bit buffer offsets
     const bool phased = big && K / GK >= 2 && !g_force_lockstep && !env_lockstep() && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31);
-    constexpr bool streamable = (EP & ~(EP_GELU | EP_RESID | EP_STATS | EP_PREAFF | EP_LOGIT)) == 0;
     if (phased) {
         // persistent: one workgroup per CU walks the tiles (a multiple of 8 workgroups: the tile order deals consecutive tiles to the 8 XCDs)
         static const unsigned ncu = [] {
@@ -2477,13 +2096,6 @@ static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int ld
         }();
         const char* e = getenv("FOHO_GEO_GEMM");
         const bool one_tile = e && std::string(e) == "onetile";   // A/B: one workgroup per tile, as before
-        const bool no_stream = e && std::string(e) == "nostream";  // A/B: the persistent kernel that restarts its K loop per tile
-        if constexpr (streamable) {
-            if ((K / GK) % 2 == 0 && !one_tile && !no_stream) {     // the stream: K tile 0 of every output tile in buffer 0
-                hipLaunchKernelGGL(k_geo_gemm8s<EP>, dim3(std::min(grid.x, ncu)), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-                return;
-            }
-        }
         hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(one_tile ? grid.x : std::min(grid.x, ncu)), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     }
     else if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
@@ -2499,7 +2111,7 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & EP_QNORM) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
     if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM | EP_PREAFF)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
     if ((ep & (EP_SAVEZ | EP_TRANS | EP_STATS | EP_LOGIT)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
-    if (((ep & EP_PREAFF) && ldr != N) || ((ep & (EP_STATS | EP_LOGIT)) && ldc2 * 32 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: folded-LayerNorm epilogue operands");
+    if (((ep & EP_PREAFF) && ldr != N) || ((ep & (EP_STATS | EP_LOGIT)) && ldc2 * 64 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: folded-LayerNorm epilogue operands");
     const bool big = N % HN == 0 && K >= 256 && M >= 2048 && !g_force128;  // the big GEMMs of the chain: 256 x 256 tiles
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
@@ -2562,7 +2174,7 @@ static Layout layout(const foho_geo_weights* w, int chunk) {
     l.c = take((size_t)chunk * W);
     l.h = take((size_t)chunk * w->hidden);
     // ... the per-row statistics of the folded LayerNorms (16 parts of 4 floats at width 1024) and (rstd, rstd mean) per row
-    l.stats = take((size_t)chunk * (W / 32) * 8); // chunk x parts of 32 columns x 4 floats
+    l.stats = take((size_t)chunk * (W / 64) * 8); // chunk x parts x 4 floats
     l.rowstat = take((size_t)chunk * 4);          // chunk x 2 floats
     l.total = off;
     return l;
@@ -2668,7 +2280,7 @@ static int chain_latent_side(const foho_geo_weights* w, int M, const h16* X0, co
     hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), dim3(256), 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse, Mdev);
     if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
     if (fold && fold->w1f && !Z) {
-        const int parts = W / 32;
+        const int parts = W / 64;
         if (int rc = gemm(EP_RESID | EP_STATS, At, W, (const h16*)w->w_proj, W, w->b_proj, X0, W, X1, W, M, W, W, 1.0f, s, (h16*)fold->stats, parts, Mdev)) return rc;
         hipLaunchKernelGGL(k_geo_rowstat_finish, dim3((M + 15) / 16), dim3(256), 0, s, fold->stats, parts, M, eps_of(w, w->ln_2_eps), (float2*)fold->rowstat, Mdev);
         if (!launch_ok("k_geo_rowstat_finish")) return FOHO_ERR_LAUNCH;

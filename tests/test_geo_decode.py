@@ -35,9 +35,9 @@ def test_geo_workspace_query_and_argument_checks_run_without_a_gpu():
         if typ is L.vp:
             setattr(w, name, 1)       # non-null: the size query only looks at the shape
     n = lib.foho_geo_workspace_bytes(ctypes.byref(w), 16384)
-    # per row: the block's activations + the folded LayerNorms' statistics (32 parts of 32 columns x 4 floats + 2 floats); per weight
-    # set: K / V / V^T of the tokens, fc1's weights with ln_2's gain folded in and the folded vectors
-    per_row = 2 * (64 + 3 * 1024 + 4096) + 32 * 16 + 8
+    # per row: the block's activations + the folded LayerNorms' statistics (16 parts x 4 floats + 2 floats); per weight set: K / V / V^T
+    # of the tokens, fc1's weights with ln_2's gain folded in and the folded vectors
+    per_row = 2 * (64 + 3 * 1024 + 4096) + 16 * 16 + 8
     fixed = 3072 * 1024 * 2 * 3 + 4096 * 1024 * 2 + 4096 * 8 + 1024 * 8 + 8
     assert 16384 * per_row + fixed <= n <= 16384 * per_row + fixed + 16384
     w.heads = 8                        # head dimension 128: refused
