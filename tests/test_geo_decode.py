@@ -198,6 +198,39 @@ def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk)
 
 
 @gpu
+def test_folded_layernorms_do_not_cancel_on_rows_with_a_large_common_offset():
+    """ln_2 inside fc1 is rstd (x (W gamma)^T) - rstd mean s + b': two terms of the size of the row's MEAN.  s is the row sum of the
+    ROUNDED folded weights, so a common offset of a row cancels exactly whatever the rounding of W gamma was; with the residual stream
+    30 standard deviations off zero (query_proj's bias) the folded chain still agrees with the chain that runs the LayerNorm kernels --
+    both see the same fp16 x1 -- and with the float32 module as closely as that chain does."""
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    dec = _decoder(256, 4, 256)
+    with torch.no_grad():
+        dec.query_proj.bias.add_(30.0 * dec.query_proj.weight.std() * (dec.query_proj.in_features ** 0.5))
+        dec.query_proj.bias.copy_(dec.query_proj.bias.half().float())
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 256, 256, generator=g).half().cuda()
+    q = (torch.rand(1, 4000, 3, generator=g) * 2.2 - 1.1).half().cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)
+    out = hip(q.float(), lat).float()
+    os.environ["FOHO_GEO_LNFUSE"] = "0"
+    try:
+        out_ln = hip(q.float(), lat).float()
+    finally:
+        del os.environ["FOHO_GEO_LNFUSE"]
+    with torch.no_grad():
+        q32 = q.float()
+        emb = (q32[..., None] * dec.freqs).flatten(-2)
+        x0 = dec.query_proj(torch.cat([q32, emb.sin(), emb.cos()], -1))
+        ref = dec(q, lat.float())
+    assert (x0.mean(-1).abs() / x0.std(-1)).median().item() > 5              # the rows really sit far off zero
+    scale = max((ref - (dec.radius - q.float().norm(dim=-1, keepdim=True)) * dec.sharpness).abs().max().item() / dec.gain, 1.0) * dec.gain
+    d_fold, d_ln, d_between = (out - ref).abs().max().item(), (out_ln - ref).abs().max().item(), (out - out_ln).abs().max().item()
+    assert torch.isfinite(out).all() and d_between <= 2e-3 * scale + 1e-3 * ref.abs().max().item(), (d_between, scale)
+    assert d_fold <= 1.5 * d_ln + 2e-3 * scale, (d_fold, d_ln, scale)
+
+
+@gpu
 @pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384), (1024, 16, 3072, 3000, 16384),
                                                          (256, 4, 128, 70, 2048), (256, 4, 256, 4097, 4096)])
 def test_decoder_backward_against_torch_autograd(width, heads, n_lat, n_q, chunk):

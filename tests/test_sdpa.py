@@ -91,6 +91,39 @@ def test_attention_forward_and_backward_against_torch_math(B, H, M, Lk, route, m
 
 
 @gpu
+def test_backward_falls_back_to_the_hip_kernels_when_torch_refuses(monkeypatch):
+    """The default backward behind the HIP forward is a private torch operator; a build that lacks it, or one that refuses the call,
+    must not cost a run: the HIP backward takes over (from that call on) with the same gradients."""
+    from followmyhold_amd import sdpa
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(1, 256, 4, 64, generator=g).half().cuda().transpose(1, 2) for _ in range(3))
+    go = torch.randn(1, 256, 4, 64, generator=g).half().cuda().transpose(1, 2)
+
+    def grads():
+        leaves = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+        sdpa.attention(*leaves).backward(go)
+        return [t.grad for t in leaves]
+
+    monkeypatch.setattr(sdpa, "backward_route", "hip")
+    want = grads()
+    monkeypatch.setattr(sdpa, "backward_route", "torch")
+    monkeypatch.setattr(sdpa, "_torch_route_refused", False)
+
+    def refuse(*a, **kw):
+        raise RuntimeError("no such kernel on this build")
+
+    monkeypatch.setattr(sdpa, "_torch_backward_op", lambda: refuse)
+    got = grads()
+    assert sdpa._torch_route_refused
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    got2 = grads()                                   # ... and the following calls do not even try
+    assert all(torch.equal(a, b) for a, b in zip(got2, want))
+    monkeypatch.setattr(sdpa, "_torch_backward_op", lambda: None)      # an absent operator: the HIP route from the forward on
+    monkeypatch.setattr(sdpa, "_torch_route_refused", False)
+    assert all(torch.equal(a, b) for a, b in zip(grads(), want)) and not sdpa._torch_route_refused
+
+
+@gpu
 def test_hip_sdpa_context_serves_eligible_calls_and_leaves_the_rest_to_torch():
     """Inside `with sdpa.hip_sdpa():` a module's F.scaled_dot_product_attention goes to the HIP kernels when the call is eligible (the
     stand-in ShapeVAE transformer in fp16: forward and the gradient to its input agree with torch's) and to torch otherwise (fp32, a
