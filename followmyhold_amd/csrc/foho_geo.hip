@@ -34,6 +34,7 @@
 #include <stdlib.h>
 
 #include "../../include/foho_hip.h"
+#include "foho_geo_stamps.h"
 
 namespace geo {
 
@@ -220,11 +221,7 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                 for (int i = 0; i < 2; i++) {
                     const f32x16& t = jn == 0 ? (i == 0 ? t00 : t01) : (i == 0 ? t10 : t11);
                     half4 o;
-#ifdef GELU_SCALAR
-                    if (false) {
-#else
                     if ((EP & EP_GELU) && pass == 1) {   // (scale is 1 on the GELU path: fc1)
-#endif
 #pragma unroll
                         for (int q = 0; q < 4; q += 2) {
                             f32x2 v = {t[4 * g + q], t[4 * g + q + 1]};
@@ -243,9 +240,6 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             float v = t[4 * g + q] + b4[q];
-#ifdef GELU_SCALAR
-                            if ((EP & EP_GELU) && pass == 1) v = gelu_erf(v);
-#endif
                             if (!(EP & EP_QNORM)) v *= scale;
                             o[q] = (h16)v;
                         }
@@ -582,15 +576,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 // scalars), rows beyond M read zeros (the resource's bound) instead of a clamped row.  The schedule is the "8-phase" form of
 // cdna_hip_programming.md section 5 (T3 + T4 + T5) laid over this kernel's 32 x 32 x 16 fragments.
 // ------------------------------------------------------------------------------------------------
-#ifdef P8_STAMPS
-__device__ unsigned long long g_p8[8][8];
-#endif
-#ifdef P8_TIMELINE   // development build: per workgroup, shader-clock stamps of {entry, first tile landed, loop end, groups re-joined, exit} + HW_ID / XCC_ID
-__device__ unsigned long long g_p8tl[4096][8];
-#define P8_TL(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i]))
-#else
-#define P8_TL(i) do { } while (0)
-#endif
+// (development builds -DP8_STAMPS / -DP8_TIMELINE: the P8_STAMP / P8_TL hooks below are defined in foho_geo_stamps.h; empty otherwise)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -627,9 +613,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     while (L < total && !tile_of(L, m0, n0)) L += gridDim.x;
     if (L >= total) return;
     const int wr = w >> 2, wc = w & 3;  // this wave's 128 (M) x 64 (N) part of the tile; wr = its group
-#ifdef P8_TIMELINE
-    unsigned long long tl_[8];
-#endif
+    P8_TL_DECL;
     P8_TL(0);
     float ev0 = 0.0f, ev1 = 0.0f;
     float2 ev2 = float2{1.0f, 0.0f};
@@ -682,27 +666,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         sq[3][e] = ((N0) + rowq[3][e]) * ldw * 2;                                          \
     }
     P8_SET_SQ(m0, n0);
-#ifndef P8_ABL
-#define P8_ABL 0
-#endif
-#ifndef P8_VAR
-#define P8_VAR 0
-#endif
-#ifdef P8_STAMPS   // development build: per-wave sums of the loop's segment durations (shader clocks), workgroup 0 -> foho_geo_p8_stamps()
-#define P8_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[i]))   /* (the wait: ~40 cycles per stamp, and it retires the LDS reads early) */
-#define P8_ACC()                                                                         \
-    do {                                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 6; q_++) seg[q_] += (int)(long long)(ts[q_ + 1] - ts[q_]); \
-        ts[0] = ts[6];                                                                   \
-    } while (0)
-#else
-#define P8_STAMP(i) do { } while (0)
-#define P8_ACC() do { } while (0)
-#endif
 #define P8_DMA(q, nb, koff)                                                                                                        \
     do {                                                                                                                           \
-        if ((P8_ABL & 1) && (koff) != 0) break;                                                                                    \
         if ((q) == 0 || (q) == 3) {                                                                                                \
             dma16(rw_, &lds[nb][1][rowq[q][0] * 8], vw0, sq[q][0] + (koff));                                                       \
             dma16(rw_, &lds[nb][1][rowq[q][1] * 8], vw1, sq[q][1] + (koff));                                                       \
@@ -753,25 +718,14 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     for (int kk = 0; kk < 4; kk++) GEO_DSR(fw0[kk], aw[kk], 32768);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3]));
     __builtin_amdgcn_sched_barrier(0);
-    if (wr == 1 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
     P8_TL(1);
 
-#define P8_DSR(dst, addr, off)                 \
-    do {                                        \
-        if (!(P8_ABL & 2)) GEO_DSR(dst, addr, off); \
-    } while (0)
-#if P8_ABL & 8
-#define P8_LGKM ""
-#else
+#define P8_DSR(dst, addr, off) GEO_DSR(dst, addr, off)
 #define P8_LGKM "s_waitcnt lgkmcnt(0)"
-#endif
-#if P8_ABL & 16
-#define P8_WAIT(n) do { } while (0)
-#else
 #define P8_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#endif
     // compute segment: prio 1, eight matrix instructions, prio 0, the counted wait for this wave's older DMA pieces, barrier
-#define P8_COMPUTE(ACC0, ACC1, FW, FA, WAITN, MID)                                                                                  \
+#define P8_COMPUTE(ACC0, ACC1, FW, FA, WAITN)                                                                                       \
     do {                                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
         P8_STAMP(3);                                                                                                                \
@@ -779,11 +733,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][0], ACC0, 0, 0, 0);                                        \
             ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][1], ACC1, 0, 0, 0);                                        \
-            if (kk == 0) {                                                                                                          \
-                __builtin_amdgcn_sched_barrier(0);                                                                                  \
-                MID;                                                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                                                  \
-            }                                                                                                                       \
+            if (kk == 0) __builtin_amdgcn_sched_barrier(0);   /* (pins the segment: without it the scheduler moves matrix instructions across the phase's barriers) */ \
         }                                                                                                                           \
         __builtin_amdgcn_s_setprio(0);                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                                          \
@@ -819,55 +769,42 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         const unsigned bo = (unsigned)(t & 1) << 16, bn = bo ^ 0x10000u;   /* 64 KB per buffer */                                   \
         const int cb = t & 1, nb = cb ^ 1, k1 = (t + 1) * GK * 2, k2 = (t + 2) * GK * 2;                                            \
         /* phase 0: A rows sub 0 (x) W columns sub 0 (read in the previous phase 3) */                                              \
-        if (P8_VAR == 1 && I0) P8_DMA(3, nb, k1);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             P8_DSR(fa0[kk][0], aa[kk] + bo, 0);                                                                                     \
             P8_DSR(fa0[kk][1], aa[kk] + bo, 4096);                                                                                  \
         }                                                                                                                           \
-        if (P8_VAR == 0 && I0) P8_DMA(3, nb, k1);                                                                                   \
+        if (I0) P8_DMA(3, nb, k1);                                                                                                  \
         P8_SYNC8(fa0);                                                                                                              \
-        P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0, if (P8_VAR == 2 && I0) P8_DMA(3, nb, k1));                                                                             \
+        P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0);                                                            \
         /* phase 1: A rows sub 1 (x) W columns sub 0 */                                                                             \
-        if (P8_VAR == 1 && I1) P8_DMA(0, cb, k2);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             P8_DSR(fa1[kk][0], aa[kk] + bo, 8192);                                                                                  \
             P8_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                                 \
         }                                                                                                                           \
-        if (P8_VAR == 0 && I1) P8_DMA(0, cb, k2);                                                                                   \
+        if (I1) P8_DMA(0, cb, k2);                                                                                                  \
         P8_SYNC8(fa1);                                                                                                              \
-        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1, if (P8_VAR == 2 && I1) P8_DMA(0, cb, k2));                                                                             \
+        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                            \
         /* phase 2: A rows sub 1 (x) W columns sub 1 */                                                                             \
-        if (P8_VAR == 1 && I2) P8_DMA(1, cb, k2);                                                                                   \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw1[kk], aw[kk] + bo, 32768 + 4096);                                \
-        if (P8_VAR == 0 && I2) P8_DMA(1, cb, k2);                                                                                   \
+        if (I2) P8_DMA(1, cb, k2);                                                                                                  \
         P8_SYNC4(fw1);                                                                                                              \
-        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2, if (P8_VAR == 2 && I2) P8_DMA(1, cb, k2));                                                                             \
+        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                            \
         /* phase 3: A rows sub 0 (x) W columns sub 1; W columns sub 0 of the NEXT tile come in for its phase 0 */                   \
         if (I0) {                                                                                                                   \
             _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw0[kk], aw[kk] + bn, 32768);                                   \
         }                                                                                                                           \
-        if (P8_VAR != 2 && I3) P8_DMA(2, cb, k2);                                                                                   \
+        if (I3) P8_DMA(2, cb, k2);                                                                                                  \
         P8_SYNC4(fw0);                                                                                                              \
-        P8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3, if (P8_VAR == 2 && I3) P8_DMA(2, cb, k2));                                                                             \
+        P8_COMPUTE(acc[1][0], acc[1][1], fw1, fa0, W3);                                                            \
     } while (0)
 
-#ifdef P8_STAMPS
-    unsigned long long ts[7];
-    int seg[6] = {0, 0, 0, 0, 0, 0};
-    P8_STAMP(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+    P8_STAMP_DECL;
     int t = 0;
     for (; t < nk - 2; t++) P8_TILE(1, 1, 1, 1, 8, 8, 8, 8);
     P8_TILE(1, 0, 0, 0, 8, 6, 4, 2);   // t = nk - 2: only W columns sub 1 of the last tile is still to come
     t++;
     P8_TILE(0, 0, 0, 0, 0, 0, 0, 0);   // t = nk - 1
-#ifdef P8_STAMPS
-    if (blockIdx.x == 0 && lane == 0) {
-        for (int q_ = 0; q_ < 6; q_++) g_p8[w][q_] = (unsigned long long)(long long)seg[q_];
-        g_p8[w][6] = nk;
-    }
-#endif
+    P8_STAMP_DUMP(w, nk);
     P8_TL(2);
     // ---- the epilogue's column vectors and row statistics from LDS into registers ...
     EpiCols pc;
@@ -892,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (wr == 0 && !(P8_ABL & 4)) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // the first group's count catches up with the second's
     __syncthreads();                                              // every wave is done with both buffers and has the vectors in registers
     P8_TL(3);
     // ... the next tile's into their place (nothing of this wave's is in flight here: the wait the compiler puts in front is free) ...
@@ -915,18 +852,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
                             scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane);
-#ifdef P8_TIMELINE
     P8_TL(4);
-    if (tid == 0 && L < 4096) {
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        for (int i_ = 0; i_ < 5; i_++) g_p8tl[L][i_] = tl_[i_];
-        g_p8tl[L][5] = hwid;
-        g_p8tl[L][6] = xcc;
-        g_p8tl[L][7] = ((tl_[5] - tl_[0]) << 32) | ((tl_[6] - tl_[5]) & 0xffffffffull);   // entry -> DMA issued | -> first tile landed
-    }
-#endif
+    P8_TL_DUMP(L);
     if (!more) break;
     __syncthreads();   // the image (buffer 1) and the vectors' LDS slots are free for the next tile
     L = Ln;
@@ -2210,12 +2137,6 @@ static int fold_weights(const foho_geo_weights* w, const Layout& l, char* base, 
 using namespace geo;
 
 extern "C" const char* foho_geo_last_error(void) { return g_err; }
-#ifdef P8_STAMPS
-extern "C" void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geo::g_p8), sizeof(geo::g_p8)); }
-#endif
-#ifdef P8_TIMELINE
-extern "C" void foho_geo_p8_timeline(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geo::g_p8tl), sizeof(geo::g_p8tl)); }
-#endif
 
 extern "C" int64_t foho_geo_abi_size(void) { return (int64_t)sizeof(foho_geo_weights); }
 
