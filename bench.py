@@ -490,6 +490,7 @@ def main():
                             ("icp", lambda: icp_record(torch, np, dev)),
                             ("lbs", lambda: lbs_record(torch, np, synthetic, dev)),
                             ("pipeline_iteration", lambda: pipeline_iteration_record(E, torch, scenes[0], dev)),
+                            ("final_decode", lambda: final_decode_record(torch, np, dev)),
                             ("job", lambda: job_record(E, torch, synthetic, render_fn, args, dev)),
                             ("driver_on_files", lambda: driver_record(E, torch, np, synthetic, render_fn, args))):
                 try:
@@ -558,6 +559,9 @@ def headline(out):
             sec["job_img_s"] = {k.replace("in_flight_", "f"): _r(v["images_per_s"], 3) for k, v in jb.items() if k.startswith("in_flight_")}
         if "images_per_s" in (out.get("driver_on_files") or {}):
             sec["driver_img_s"] = _r(out["driver_on_files"]["images_per_s"], 3)
+        fd = out.get("final_decode") or {}
+        if "latent2sdf_ms" in fd:
+            sec["final_decode_ms"] = _r(fd["latent2sdf_ms"] + fd["flexicubes_ms"])
         ic = out.get("icp") or {}
         if "hip_ms" in ic:
             sec["icp"] = {"ms": _r(ic["hip_ms"]), "cpu_ms": _r(ic.get("cpu_ms_extrapolated"))}
@@ -567,7 +571,7 @@ def headline(out):
         lb = out.get("lbs") or {}
         if "b8192" in lb:
             sec["lbs"] = {"b1_us": _r(get(lb, "b1", "fwd_bwd_us")), "b8192_frac": _r(get(lb, "b8192", "poseblend_frac_of_fp32_matrix_peak"), 3)}
-        for k in ("geo_decode", "pipeline_iteration", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs", "vae_attention"):
+        for k in ("geo_decode", "pipeline_iteration", "final_decode", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs", "vae_attention"):
             if isinstance(out.get(k), dict) and "error" in out[k]:
                 sec[k] = {"error": out[k]["error"][:60]}
         if sec:
@@ -1017,6 +1021,42 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     out["what"] = ("latent -> 16-layer VAE transformer (torch) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
                    "step -> backward to the noise prediction; stand-in networks of the Hunyuan3D-2 shape, fp16")
     return out
+
+
+def final_decode_record(torch, np, dev):
+    """The pipeline's LAST decode (PL:1623-1642): the final latent through the VAE transformer and the geometry decoder on the dense
+    385^3 grid (octree resolution 384: 57 M query points, 208 times the guidance grid, 1.9 PFLOP), then the iso-surface at resolution
+    384 -- once per image, stand-in networks of the Hunyuan3D-2 shape.  The query side of a grid this size is not cached (228 GB):
+    `foho_geo_decode_fwd` recomputes it per row block."""
+    from followmyhold_amd import geo_decode, ops, pipeline as PLN, standins
+    from followmyhold_amd.facade import generate_dense_grid_points
+    torch.manual_seed(0)
+    vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=16, num_freqs=8).to(dev).half().eval()
+    vae.requires_grad_(False)
+    geo_decode.install(vae)
+    lat = torch.randn(1, 3072, 64, device=dev).half()
+    res = 384
+    b = np.array([1.1] * 3, dtype=np.float32)
+    xyz_np, gsz, _ = generate_dense_grid_points(-b, b, octree_depth=5, octree_resolution=res, indexing="ij")
+    xyz = torch.as_tensor(xyz_np, dtype=torch.float32, device=dev)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            sdf = PLN.latent2sdf(lat, xyz, gsz, vae, dev)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        v, f, _ = ops.flexicubes(xyz, sdf[0].flatten(), res)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0] + best[1]:
+            best = (t1 - t0, t2 - t1)
+    n = int(xyz.shape[0])
+    flop = n * (4 * 3072 * 1024 + 2 * 1024 * 1024 + 4 * 1024 * 4096 + 2 * 64 * 1024 + 2 * 1024 * 1024)
+    return {"grid": f"{res + 1}^3", "query_points": n, "latent2sdf_ms": best[0] * 1e3, "flexicubes_ms": best[1] * 1e3, "decoder_tflops": flop / best[0] / 1e12,
+            "vertices": int(v.shape[0]), "faces": int(f.shape[0]), "sdf_finite": bool(torch.isfinite(sdf).all()),
+            "what": "VAE transformer + geometry decoder on the dense 385^3 grid + FlexiCubes at resolution 384, once per image"}
 
 
 def vae_attention_record(torch, dev):
