@@ -875,8 +875,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 // Cross attention, head dimension 64: O[M, heads*64] = softmax(Q K^T) V per head, Q pre-scaled by log2(e)/sqrt(64).
 // K rows: Kp + l * ldk + head * 64 (the K half of the KV projection, as the GEMM left it); V: Vt[head][d][pos(l)],
 // transposed, with the keys of every 16-block stored in the order the P fragment holds them (pack_vt below).
-// Workgroup = 4 waves x 64 queries of ONE head; 64-key tiles double-buffered in LDS (register staging: the loads for
-// tile t+1 are issued before tile t is computed and written to LDS after it).
+// Workgroup = 4 waves x 64 queries of ONE head; 64-key tiles of K and V^T double-buffered in LDS, brought by LDS-DMA (buffer_load ... lds:
+// tile t + 1 is in flight while tile t is computed; no staging registers, which is what pays for four score buffers -- see inside).
 // ------------------------------------------------------------------------------------------------
 constexpr int AQ = 256, AK = 64;
 constexpr float RESCALE_THR = 6.0f;  // log2 domain: P <= 2^6 while the running max lags behind
@@ -904,7 +904,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     // qscale != 1: Q arrives UNSCALED and is multiplied (and rounded to fp16 again) as it is loaded (foho_sdpa_fwd)
     __shared__ uint4 lds[2][2][AK * 8];  // [buffer][K | Vt][64 rows x 8 chunks] = 32 KB
     if (Mdev) M = min(M, *Mdev);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int head, qblk;
     if ((heads & 7) == 0) {  // an XCD (block id mod 8) keeps heads/8 heads: their K and V stay in its L2
         const int hpx = heads >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -930,29 +931,35 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         }
     }
 
-    const int srow = tid >> 3, sch = tid & 7;
-    const h16* kg = Kp + (size_t)srow * ldk + head * khs + sch * 8;
-    const h16* vg = Vt + ((size_t)head * 64 + srow) * L + sch * 8;
-    const int sidx = srow * 8 + (sch ^ swz(srow));  // rows srow and srow + 32 share the swizzle
-    uint4 st0, st1, st2, st3;
-#define ATT_GLOAD(t)                                                                    \
-    do {                                                                                \
-        st0 = *reinterpret_cast<const uint4*>(kg + (size_t)((t) * AK) * ldk);           \
-        st1 = *reinterpret_cast<const uint4*>(kg + (size_t)((t) * AK + 32) * ldk);      \
-        st2 = *reinterpret_cast<const uint4*>(vg + (t) * AK);                           \
-        st3 = *reinterpret_cast<const uint4*>(vg + (size_t)32 * L + (t) * AK);          \
+    // ---- K / V^T tiles by LDS-DMA: per key tile every wave brings pieces 2 w and 2 w + 1 (8 rows x 128 bytes each) of both; a lane's
+    // 16 bytes land at (row, slot = lane & 7), so it FETCHES chunk slot ^ swz(row)
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int c0 = (sslot ^ ((srow >> 1) & 7)) << 3, c1 = (sslot ^ ((4 + (srow >> 1)) & 7)) << 3;
+    const int vk0 = (srow * ldk + c0) * 2, vk1 = (srow * ldk + c1) * 2, vt0 = (srow * L + c0) * 2, vt1 = (srow * L + c1) * 2;
+    const size_t kspan = ((size_t)(L - 1) * ldk + (size_t)(heads - 1) * khs + 64) * 2;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, (short)0, (int)min(kspan, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, (short)0, (int)min((size_t)heads * 64 * L * 2, (size_t)0x7fffffff), 0x00020000);
+    const int r0 = 16 * w, r1 = 16 * w + 8;
+    const int sk = head * khs * 2, skt = head * 64 * L * 2;
+#define A2_ISSUE(t, buf)                                                              \
+    do {                                                                              \
+        const int kb_ = (t) * AK;                                                     \
+        dma16(rk, &lds[buf][0][r0 * 8], vk0, sk + (kb_ + r0) * ldk * 2);              \
+        dma16(rk, &lds[buf][0][r1 * 8], vk1, sk + (kb_ + r1) * ldk * 2);              \
+        dma16(rv, &lds[buf][1][r0 * 8], vt0, skt + (r0 * L + kb_) * 2);               \
+        dma16(rv, &lds[buf][1][r1 * 8], vt1, skt + (r1 * L + kb_) * 2);               \
     } while (0)
-#define ATT_LWRITE(buf)                  \
-    do {                                 \
-        lds[buf][0][sidx] = st0;         \
-        lds[buf][0][sidx + 256] = st1;   \
-        lds[buf][1][sidx] = st2;         \
-        lds[buf][1][sidx + 256] = st3;   \
-    } while (0)
+    const unsigned lbase = lds_addr(&lds[0][0][0]);
+    unsigned ak[4], av[2][2];   // fragment addresses in buffer 0: K rows (row = key; + 4096 per sub-tile), V^T rows (row = d; + 4096 per d tile)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) ak[kk] = lbase + l31 * 128 + (((2 * kk + hi) ^ swz(l31)) << 4);
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) av[sub][k2] = lbase + 8192 + l31 * 128 + (((4 * sub + 2 * k2 + hi) ^ swz(l31)) << 4);
 
     f32x16 o[2][2];  // [query block][d tile]: O^T, rows d, columns q
-    f32x16 negm[2];  // -(running max) of the lane's query in all 16 registers: the accumulator S^T starts from, so the MFMA
-                     // chain delivers s - m and the softmax needs no subtraction
+    f32x16 negm[2];  // -(running max) of the lane's query in all 16 registers: the accumulator S^T starts from
 #pragma unroll
     for (int a = 0; a < 2; a++) {
 #pragma unroll
@@ -964,110 +971,134 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
     }
     float lsum[2] = {0.0f, 0.0f};
 
-    const int nt = L / AK;
-    ATT_GLOAD(0);
-    ATT_LWRITE(0);
-    __syncthreads();
-    for (int t = 0; t < nt; t++) {
-        if (t + 1 < nt) ATT_GLOAD(t + 1);
-        const uint4* lk = lds[t & 1][0];
-        const uint4* lv = lds[t & 1][1];
-        // A tile is four UNITS (32 keys x 32 queries): (sub-tile, query block) = (0,0) (0,1) (1,0) (1,1).  Per unit: QK (4 MFMAs)
-        // -> softmax (VALU) -> PV (4 MFMAs).  They are issued SKEWED -- the QK of unit u+1 goes out before the softmax of unit u,
-        // whose PV follows it -- so that every softmax has independent matrix work in flight beside it (an in-order wave
-        // cannot overlap its own VALU with MFMAs that come later in program order).
-        auto kfrag = [&](int sub, half8* kf) {
-            const int krow = sub * 32 + l31;
+    // One key tile = four UNITS (32 keys x 32 queries): u0 = (sub-tile 0, query block 0), u1 = (0, 1), u2 = (1, 0), u3 = (1, 1).  A unit is QK
+    // (4 matrix instructions) -> softmax -> PV (4).  FOUR score buffers and two P buffers: while unit u is exponentiated the matrix pipe
+    // has the PV of unit u - 1 and the QK of unit u + 2 -- both independent of u -- instead of only work that waits for u's own P.
+    //   R0: QK u0, QK u1        R1: check u0; exp u0 || QK u2        R2: check u1; exp u1 || PV u0, QK u3
+    //   R3: check u2; exp u2 || PV u1    R4: check u3; exp u3 || PV u2    R5: PV u3
+    // (the QK of a query block starts from -(its running max): it is issued after the check of that block's previous unit, as before)
+    auto qk = [&](const half8* kf, int qb) {
+        f32x16 r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const uint4 u = lk[krow * 8 + ((2 * kk + hi) ^ swz(krow))];
-                kf[kk] = *reinterpret_cast<const half8*>(&u);
+        for (int kk = 1; kk < 4; kk++) r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], r, 0, 0, 0);
+        return r;
+    };
+    auto check = [&](f32x16& sc, int qb, bool first) {   // raise the running max when a score exceeds it by 2^6 (the first unit SETS it)
+        float tm = max3(sc[0], sc[1], sc[2]);
+        tm = max3(tm, sc[3], sc[4]);
+        tm = max3(tm, sc[5], sc[6]);
+        tm = max3(tm, sc[7], sc[8]);
+        tm = max3(tm, sc[9], sc[10]);
+        tm = max3(tm, sc[11], sc[12]);
+        tm = max3(tm, sc[13], sc[14]);
+        tm = fmaxf(tm, sc[15]);
+        if (first || __any(tm > RESCALE_THR)) {
+            tm = fmaxf(tm, other_half(tm));
+            const float up = first ? tm : fmaxf(tm, 0.0f);
+            const float alpha = ex2(-up);
+            lsum[qb] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[r] -= up;
+                negm[qb][r] -= up;
             }
-        };
-        auto vfrag = [&](int sub, half8 (*vf)[2]) {
-#pragma unroll
-            for (int dt = 0; dt < 2; dt++) {
-                const int vrow = dt * 32 + l31;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) {
-                    const uint4 u = lv[vrow * 8 + ((4 * sub + 2 * k2 + hi) ^ swz(vrow))];
-                    vf[dt][k2] = *reinterpret_cast<const half8*>(&u);
-                }
-            }
-        };
-        auto qk = [&](const half8* kf, int qb) {
-            f32x16 r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
-#pragma unroll
-            for (int kk = 1; kk < 4; kk++) r = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[qb][kk], r, 0, 0, 0);
-            return r;
-        };
-        // online softmax of one unit in the log2 domain (a query's 32 scores sit in two lanes, 16 registers each), then O^T += V^T P^T
-        auto sm_pv = [&](f32x16& sc, int qb, const half8 (*vf)[2], bool first) {
-            float tm = max3(sc[0], sc[1], sc[2]);
-            tm = max3(tm, sc[3], sc[4]);
-            tm = max3(tm, sc[5], sc[6]);
-            tm = max3(tm, sc[7], sc[8]);
-            tm = max3(tm, sc[9], sc[10]);
-            tm = max3(tm, sc[11], sc[12]);
-            tm = max3(tm, sc[13], sc[14]);
-            tm = fmaxf(tm, sc[15]);
-            // the other half-wave holds the query's other 16 scores: it is only consulted when somebody's maximum has to move
-            if (first || __any(tm > RESCALE_THR)) {
-                // raise the running max (the first unit SETS it: there it may also fall below the initial 0) and rescale what is
-                // accumulated -- rare after the first tiles: the max only moves when a score exceeds it by 2^6
-                tm = fmaxf(tm, other_half(tm));
-                const float up = first ? tm : fmaxf(tm, 0.0f);
-                const float alpha = ex2(-up);
-                lsum[qb] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    sc[r] -= up;
-                    negm[qb][r] -= up;
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) o[qb][dt][r] *= alpha;
-            }
-            half8 pf[2];
-            float ls = 0.0f;
-#pragma unroll
-            for (int k2 = 0; k2 < 2; k2++)
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const float p0 = ex2(sc[8 * k2 + e]), p1 = ex2(sc[8 * k2 + e + 1]);
-                    ls += p0 + p1;
-                    const f32x2 pp = {p0, p1};
-                    const half2v ph = __builtin_convertvector(pp, half2v);
-                    pf[k2][e] = ph[0];
-                    pf[k2][e + 1] = ph[1];
-                }
-            lsum[qb] += ls;
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
-        };
-        {
-            half8 kf0[4], kf1[4], vf0[2][2], vf1[2][2];
-            kfrag(0, kf0);
-            f32x16 sA = qk(kf0, 0);      // unit 0
-            f32x16 sB = qk(kf0, 1);      // unit 1's scores are under way while unit 0 is exponentiated
-            vfrag(0, vf0);
-            kfrag(1, kf1);
-            sm_pv(sA, 0, vf0, t == 0);
-            sA = qk(kf1, 0);             // unit 2
-            sm_pv(sB, 1, vf0, t == 0);
-            sB = qk(kf1, 1);             // unit 3
-            vfrag(1, vf1);
-            sm_pv(sA, 0, vf1, false);
-            sm_pv(sB, 1, vf1, false);
+                for (int r = 0; r < 16; r++) o[qb][dt][r] *= alpha;
         }
-        if (t + 1 < nt) ATT_LWRITE((t + 1) & 1);  // that buffer was last read in iteration t - 1, before the barrier every wave passed
-        __syncthreads();
+    };
+    auto expo = [&](const f32x16& sc, int qb, half8* pf) {
+        float ls = 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float p0 = ex2(sc[8 * k2 + e]), p1 = ex2(sc[8 * k2 + e + 1]);
+                ls += p0 + p1;
+                const f32x2 pp = {p0, p1};
+                const half2v ph = __builtin_convertvector(pp, half2v);
+                pf[k2][e] = ph[0];
+                pf[k2][e + 1] = ph[1];
+            }
+        lsum[qb] += ls;
+        asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(lsum[qb]));   // (P is wanted HERE: left alone, the compiler sinks the exponentials to P's first use, one region later)
+    };
+    auto pv = [&](const half8 (*vf)[2], const half8* pf, int qb) {
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt][k2], pf[k2], o[qb][dt], 0, 0, 0);
+    };
+#define A2_RDK(sub)  _Pragma("unroll") for (int kk = 0; kk < 4; kk++) GEO_DSR(kf[kk], ak[kk] + bo, (sub) * 4096)
+#define A2_RDV(sub)                                                          \
+    _Pragma("unroll") for (int dt = 0; dt < 2; dt++)                         \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; k2++) GEO_DSR(vf[dt][k2], av[sub][k2] + bo, dt * 4096)
+#define A2_WAITK() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]))
+#define A2_WAITKV()                                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0][0]), "+v"(vf[0][1]), \
+                 "+v"(vf[1][0]), "+v"(vf[1][1]))
+#define A2_WAITV() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]))
+
+    const int nt = L / AK;
+    A2_ISSUE(0, 0);
+    for (int t = 0; t < nt; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile t has landed for every wave, and everybody is done reading the other buffer
+        if (t + 1 < nt) {
+            if (t & 1) A2_ISSUE(t + 1, 0);
+            else A2_ISSUE(t + 1, 1);
+        }
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(t & 1) * (2u * AK * 8u * 16u);   // 16 KB per buffer
+        half8 kf[4], vf[2][2], pfA[2], pfB[2];
+        f32x16 s0, s1, s2, s3;
+        // R0
+        A2_RDK(0);
+        A2_WAITK();
+        s0 = qk(kf, 0);
+        s1 = qk(kf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        A2_RDK(1);
+        A2_RDV(0);
+        // R1
+        check(s0, 0, t == 0);
+        A2_WAITKV();
+        __builtin_amdgcn_sched_barrier(0);
+        s2 = qk(kf, 0);
+        expo(s0, 0, pfA);
+        __builtin_amdgcn_sched_barrier(0);
+        // R2
+        check(s1, 1, t == 0);
+        __builtin_amdgcn_sched_barrier(0);
+        s3 = qk(kf, 1);
+        pv(vf, pfA, 0);
+        expo(s1, 1, pfB);
+        __builtin_amdgcn_sched_barrier(0);
+        // R3
+        check(s2, 0, false);
+        __builtin_amdgcn_sched_barrier(0);
+        pv(vf, pfB, 1);
+        expo(s2, 0, pfA);
+        __builtin_amdgcn_sched_barrier(0);
+        A2_RDV(1);
+        // R4
+        check(s3, 1, false);
+        A2_WAITV();
+        __builtin_amdgcn_sched_barrier(0);
+        pv(vf, pfA, 0);
+        expo(s3, 1, pfB);
+        __builtin_amdgcn_sched_barrier(0);
+        // R5
+        pv(vf, pfB, 1);
     }
-#undef ATT_GLOAD
-#undef ATT_LWRITE
+
+#undef A2_ISSUE
+#undef A2_RDK
+#undef A2_RDV
+#undef A2_WAITK
+#undef A2_WAITKV
+#undef A2_WAITV
     // ---- normalise and store: the lane holds, for ONE query, d = 32 dt + 8 g + 4 hi + (0..3)
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {
@@ -1091,6 +1122,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, 
         }
     }
 }
+
 
 // hy3dgen's qk_norm on the key side: LayerNorm over the 64 dimensions of every head of K, in place (one thread per token
 // and head; 3072 x 16 of them, once per set of latent tokens).  kn: gain (64), bias (64), eps.
@@ -2069,6 +2101,7 @@ static int check_weights(const foho_geo_weights* w) {
     if (w->n_latents <= 0 || w->n_latents % 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo: n_latents must be a multiple of 64");
     if (w->hidden <= 0 || w->hidden % 128) return fail(FOHO_ERR_BAD_ARG, "foho_geo: hidden must be a multiple of 128");
     if (w->n_freqs < 0 || w->n_freqs > 10) return fail(FOHO_ERR_BAD_ARG, "foho_geo: 3 (2 n_freqs + 1) must fit 64 columns");
+    if ((size_t)w->n_latents * w->width * 4 >= ((size_t)1 << 31)) return fail(FOHO_ERR_BAD_ARG, "foho_geo: K / V of the latent tokens exceed 32-bit buffer offsets");
     if (!w->w_qproj || !w->b_qproj || !w->w_q || !w->b_q || !w->w_kv || !w->b_kv || !w->w_proj || !w->b_proj || !w->w_fc1 || !w->b_fc1 ||
         !w->w_fc2 || !w->b_fc2 || !w->w_out || !w->ln_q_g || !w->ln_q_b || !w->ln_kv_g || !w->ln_kv_b || !w->ln_2_g || !w->ln_2_b ||
         !w->ln_post_g || !w->ln_post_b || !w->freqs)
@@ -2164,6 +2197,11 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
     return fold_weights(w, l, base, s);
 }
 
+static void launch_attn(dim3 grid, hipStream_t s, const h16* Q, int ldq, const h16* Kp, int ldk, const h16* Vt, int L, h16* O, int ldo, int M, int heads, float* nlse,
+                        const int* Mdev, int qhs = 64, int khs = 64, float qscale = 1.0f, float* lse_nat = nullptr) {
+    hipLaunchKernelGGL(k_geo_attn, grid, dim3(256), 0, s, Q, ldq, Kp, ldk, Vt, L, O, ldo, M, heads, nlse, Mdev, qhs, khs, qscale, lse_nat);
+}
+
 // ---- the forward chain in two halves: what depends only on the query points (Fourier embedding -> query projection -> ln_q ->
 // c_q [+ q_norm], scaled for the exp2 softmax), and what depends on the latent tokens.  The first half is the same for every
 // decode of one grid (foho_geo_prepare_queries caches it: X0 and Qs of all rows, 4 KB per query at width 1024).
@@ -2198,7 +2236,7 @@ static int chain_latent_side(const foho_geo_weights* w, int M, const h16* X0, co
                              float* logits = nullptr) {
     const int W = w->width, Lr = w->n_latents, F = w->hidden, NH = w->heads;
     const float* nof = nullptr;
-    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * NH), dim3(256), 0, s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse, Mdev);
+    launch_attn(dim3(((M + AQ - 1) / AQ) * NH), s, Qs, W, kv, 2 * W, vt, Lr, At, W, M, NH, lse, Mdev);
     if (!launch_ok("k_geo_attn")) return FOHO_ERR_LAUNCH;
     if (fold && fold->w1f && !Z) {
         const int parts = W / 64;
@@ -2657,9 +2695,8 @@ extern "C" int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void*
     for (int b = 0; b < d->batch; b++) {
         const h16 *qb = (const h16*)q + (size_t)b * d->q_batch, *kb = (const h16*)k + (size_t)b * d->kv_batch, *vb = (const h16*)v + (size_t)b * d->kv_batch;
         hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, vb, (int)d->kv_row, W, L, vt, 0, (int)d->kv_head);
-        hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, qb, (int)d->q_row, kb, (int)d->kv_row, (const h16*)vt, L,
-                           (h16*)out + (size_t)b * M * W, W, M, heads, nlse ? nlse + b * nl : nullptr, (const int*)nullptr, (int)d->q_head, (int)d->kv_head, SDPA_QSCALE,
-                           lse_nat ? lse_nat + (size_t)b * heads * M : nullptr);
+        launch_attn(dim3(((M + AQ - 1) / AQ) * heads), s, qb, (int)d->q_row, kb, (int)d->kv_row, (const h16*)vt, L, (h16*)out + (size_t)b * M * W, W, M, heads,
+                    nlse ? nlse + b * nl : nullptr, (const int*)nullptr, (int)d->q_head, (int)d->kv_head, SDPA_QSCALE, lse_nat ? lse_nat + (size_t)b * heads * M : nullptr);
     }
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
@@ -2717,13 +2754,14 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
 
 extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
                                   void* stream) {
-    if (!Q || !KV || !Vt_scratch || !O || heads <= 0 || n_latents <= 0 || n_latents % 64) return fail(FOHO_ERR_BAD_ARG, "foho_geo_attention: bad argument");
+    if (!Q || !KV || !Vt_scratch || !O || heads <= 0 || n_latents <= 0 || n_latents % 64 || (size_t)n_latents * heads * 256 >= ((size_t)1 << 31))
+        return fail(FOHO_ERR_BAD_ARG, "foho_geo_attention: bad argument");
     const int W = heads * 64;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, n_latents / 16), dim3(256), 0, s, (const h16*)KV, 2 * W, W, n_latents, (h16*)Vt_scratch);
     if (!launch_ok("k_geo_pack_vt")) return FOHO_ERR_LAUNCH;
     if (M <= 0) return FOHO_OK;
-    hipLaunchKernelGGL(k_geo_attn, dim3(((M + AQ - 1) / AQ) * heads), dim3(256), 0, s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch,
-                       n_latents, (h16*)O, W, M, heads, (float*)nullptr, (const int*)nullptr);
+    launch_attn(dim3(((M + AQ - 1) / AQ) * heads), s, (const h16*)Q, W, (const h16*)KV, 2 * W, (const h16*)Vt_scratch, n_latents, (h16*)O, W, M, heads, (float*)nullptr,
+                (const int*)nullptr);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
