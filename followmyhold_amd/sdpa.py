@@ -161,7 +161,9 @@ def attention(q, k, v):
 def hip_sdpa(backward=None):
     """Inside the context `torch.nn.functional.scaled_dot_product_attention` sends eligible calls to the HIP kernels and everything
     else to torch's own implementation.  (A module that bound the function at import time -- `from torch.nn.functional import
-    scaled_dot_product_attention` -- keeps torch's.)  backward: "torch" / "hip" sets `backward_route` for the forwards recorded inside."""
+    scaled_dot_product_attention` -- keeps torch's.)  backward: "torch" / "hip" sets `backward_route` for the forwards recorded inside.
+    The patch is process-wide while the context is open (other threads calling the function meanwhile get the same dispatch: eligible
+    calls to the HIP kernels, the rest to torch -- harmless, but the context is not meant to be nested or entered concurrently)."""
     global backward_route
     orig = F.scaled_dot_product_attention
     saved_route = backward_route
