@@ -135,6 +135,11 @@ constexpr int EP_QNORM = 32;
 // EP_LOGIT (with EP_RESID): the output itself is NOT stored; per row and part (mean, sum of squared deviations, sum of value x gw[n])
 //   go to ((float*)C2)[(row * ldc2 + n0 / 64) * 4], gw = bias[N..2N) (N = 64 ldc2): what ln_post + output_proj need of the row.
 constexpr int EP_STATS = 64, EP_PREAFF = 128, EP_LOGIT = 256;
+// EP_QKN (with EP_PREAFF; the fused q | k | v projection of a ShapeVAE transformer layer, foho_vae.inc): the output's columns are
+// [Q of all heads | K of all heads | V of all heads] (N = 3 width, ldr = N under EP_PREAFF); the 64 columns of a part in the first
+// third are LayerNorm-ed with q_norm's gain / bias / eps, of a part in the second third with k_norm's, the last third is left alone:
+// 129 floats each at bias[2 N ..] and bias[2 N + 132 ..] (hy3dgen's qk_norm).  With EP_SAVEZ the un-normalised projection goes to C2.
+constexpr int EP_QKN = 512;
 
 __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
     const float x = v * 0.70710678118654752f, ax = fabsf(x);
@@ -207,8 +212,12 @@ __device__ __forceinline__ void epi_rows(EpiRows& p, const h16* __restrict__ R, 
 template <int EP>
 __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16& t01, const f32x16& t10, const f32x16& t11, h16* img,
                                                 const EpiCols& pc, const EpiRows& pr, const h16* __restrict__ R, h16* __restrict__ C, int ldc,
-                                                h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane) {
+                                                h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane,
+                                                const float* __restrict__ bias = nullptr, int ldr = 0) {
     const int hi = lane >> 5, l31 = lane & 31;
+    // EP_QKN: which third of the fused projection this part lies in (uniform over the wave) and that third's norm parameters
+    const int qkn_third = (EP & EP_QKN) ? n0 / (ldr / 3) : 0;
+    const float* qkn = (EP & EP_QKN) ? bias + 2 * ldr + 132 * qkn_third : nullptr;
 #pragma unroll
     for (int pass = (EP & EP_SAVEZ) ? 0 : 1; pass < 2; pass++) {   // pass 0: the pre-activation (EP_SAVEZ only); pass 1: the output
 #pragma unroll
@@ -239,8 +248,10 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            float v = t[4 * g + q] + b4[q];
-                            if (!(EP & EP_QNORM)) v *= scale;
+                            float v = t[4 * g + q];
+                            if (EP & EP_PREAFF) v = v * pr.rs[i] + (pc.s[jn * 4 + g][q] * -pr.mr[i] + b4[q]);
+                            else v += b4[q];
+                            if (!(EP & (EP_QNORM | EP_QKN))) v *= scale;
                             o[q] = (h16)v;
                         }
                     }
@@ -264,8 +275,8 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
             const int ml = q * 8 + (lane >> 3), ch = lane & 7;
             const int gm = m0 + ml, gn = n0 + ch * 8;
             half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
-            if ((EP & EP_QNORM) && pass == 1) {   // the row's 64 columns sit in 8 consecutive lanes
-                const float* qn = reinterpret_cast<const float*>(R);
+            if (((EP & EP_QNORM) || ((EP & EP_QKN) && qkn_third < 2)) && pass == 1) {   // the row's 64 columns sit in 8 consecutive lanes
+                const float* qn = (EP & EP_QKN) ? qkn : reinterpret_cast<const float*>(R);
                 float x[8], sm = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
     EpiRows pr;
     epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
     epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
-    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 #pragma unroll
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane);
+                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane, bias, ldr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -851,7 +862,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 #pragma unroll
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane);
+                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane, bias, ldr);
     P8_TL(4);
     P8_TL_DUMP(L);
     if (!more) break;
@@ -1449,8 +1460,9 @@ constexpr int DQQ = 128;   // queries per workgroup of k_geo_attn_dq
 __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ Qs, const h16* __restrict__ dO, int ldq, const h16* __restrict__ KV,
                                                         int ldkv, int width, const h16* __restrict__ Kt, int L, const float* __restrict__ nlse,
                                                         const float* __restrict__ ndelta, h16* __restrict__ dQ, int M, int heads,
-                                                        const h16* __restrict__ Vp = nullptr, int khs = 64) {
+                                                        const h16* __restrict__ Vp = nullptr, int khs = 64, int lddq = 0) {
     if (!Vp) Vp = KV + width;   // (K / V rows as in k_geo_attn_bwd)
+    if (lddq == 0) lddq = ldq;  // row stride of dQ (default: that of Qs / dO)
     __shared__ uint4 lds[2][3][AK * 8];  // [buffer][K | V | K^T][64 rows x 8 chunks] = 48 KB
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1577,7 +1589,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ 
                     half4 v;
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = (h16)(dq[qb][dt][4 * g + e] * 0.125f);
-                    *reinterpret_cast<half4*>(dQ + (size_t)row * ldq + head * 64 + dt * 32 + 8 * g + 4 * hi) = v;
+                    *reinterpret_cast<half4*>(dQ + (size_t)row * lddq + head * 64 + dt * 32 + 8 * g + 4 * hi) = v;
                 }
         }
     }
@@ -1616,7 +1628,9 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce(const float* __restrict_
 }
 
 // ... the same sum, handed out as two fp16 matrices (L x W each): dK and dV of foho_sdpa_bwd
-__global__ __launch_bounds__(256) void k_geo_dkv_reduce16(const float* __restrict__ part, int splits, int L, int W, h16* __restrict__ dk, h16* __restrict__ dv) {
+__global__ __launch_bounds__(256) void k_geo_dkv_reduce16(const float* __restrict__ part, int splits, int L, int W, h16* __restrict__ dk, h16* __restrict__ dv,
+                                                          int ldo = 0) {
+    if (ldo == 0) ldo = W;   // row stride of dk / dv (the ShapeVAE transformer writes them into its (tokens, 3 W) gradient of q | k | v)
     const size_t n4 = (size_t)L * 2 * W / 4, i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
@@ -1629,7 +1643,7 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce16(const float* __restric
     half4 o;
 #pragma unroll
     for (int e = 0; e < 4; e++) o[e] = (h16)a[e];
-    *reinterpret_cast<half4*>((c < (size_t)W ? dk + l * W + c : dv + l * W + (c - W))) = o;
+    *reinterpret_cast<half4*>((c < (size_t)W ? dk + l * ldo + c : dv + l * ldo + (c - W))) = o;
 }
 
 // ndelta[q][head] = - sum_d dO[q][head, d] O[q][head, d] (negated: the backward attention starts its dP accumulators there); one
@@ -1681,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_geo_ln_bwd(const h16* __restrict__ X, c
             for (int e = 0; e < 8; e++) {
                 x[c][e] = (float)h[e];
                 sum += x[c][e];
-                dy[c][e] = ((MODE == 0) ? (float)g[e] : gr * w_out[col + e]) * gamma[col + e];   // d / d xhat
+                dy[c][e] = ((MODE == 0) ? (float)g[e] : gr * w_out[col + e]) * (gamma ? gamma[col + e] : 1.0f);   // d / d xhat (gamma == NULL: all ones)
             }
         } else {
 #pragma unroll
@@ -2034,48 +2048,52 @@ static bool launch_ok(const char* what) {
     return true;
 }
 
-static bool g_force128 = false;  // unit tests / measurements: foho_geo_gemm(..., gelu | 2) keeps the 128 x 128 kernel
-static bool g_force_lockstep = false;   // ... gelu | 4: the lock-step 256 x 256 kernel instead of the phased one
-// FOHO_GEO_GEMM=lockstep: the whole chain on k_geo_gemm256 (A/B measurements); read once
-static bool env_lockstep() {
-    static const bool v = [] { const char* e = getenv("FOHO_GEO_GEMM"); return e && std::string(e) == "lockstep"; }();
-    return v;
+// Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
+// measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
+enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3 };
+static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
+    static const unsigned ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return (unsigned)(n & ~7);
+    }();
+    return ncu;
 }
 template <int EP>
-static void launch_gemm(bool big, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
+static void launch_gemm(int variant, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
-    // the phased kernel addresses its operands through 32-bit buffer offsets
-    const bool phased = big && K / GK >= 2 && !g_force_lockstep && !env_lockstep() && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31);
-    if (phased) {
-        // persistent: one workgroup per CU walks the tiles (a multiple of 8 workgroups: the tile order deals consecutive tiles to the 8 XCDs)
-        static const unsigned ncu = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-            return (unsigned)(n & ~7);
-        }();
-        const char* e = getenv("FOHO_GEO_GEMM");
-        const bool one_tile = e && std::string(e) == "onetile";   // A/B: one workgroup per tile, as before
-        hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(one_tile ? grid.x : std::min(grid.x, ncu)), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    }
-    else if (big) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
+        hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    else if (variant == GV_LOCKSTEP) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
 }
 
 // ep: bit mask of EP_*.  R: the residual (EP_RESID) or the saved pre-activation (EP_GELUBWD); C2: the pre-activation output
 // (EP_SAVEZ, leading dimension ldc2) or the transposed copy (EP_TRANS, row length ldc2).  Mdev: optional DEVICE row count (the
-// launch is sized for M, the kernel works on min(M, *Mdev) rows)
+// launch is sized for M, the kernel works on min(M, *Mdev) rows).  variant: GV_*.
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
-                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr) {
+                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr, int variant = GV_AUTO) {
     if (M <= 0) return FOHO_OK;
-    if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & EP_QNORM) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
+    if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & (EP_QNORM | EP_PREAFF)) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
     if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM | EP_PREAFF)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
     if ((ep & (EP_SAVEZ | EP_TRANS | EP_STATS | EP_LOGIT)) && !C2) return fail(FOHO_ERR_BAD_ARG, "geo gemm: second output missing");
-    if (((ep & EP_PREAFF) && ldr != N) || ((ep & (EP_STATS | EP_LOGIT)) && ldc2 * 64 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: folded-LayerNorm epilogue operands");
-    const bool big = N % HN == 0 && K >= 256 && M >= 2048 && !g_force128;  // the big GEMMs of the chain: 256 x 256 tiles
+    if (((ep & EP_PREAFF) && ldr != N) || ((ep & (EP_STATS | EP_LOGIT)) && ldc2 * 64 != N) || ((ep & EP_QKN) && (N % 192 || !(ep & EP_PREAFF))))
+        return fail(FOHO_ERR_BAD_ARG, "geo gemm: folded-LayerNorm epilogue operands");
+    const bool can_big = N % HN == 0 && K >= 256;
+    // the phased kernel addresses its operands through 32-bit buffer offsets
+    const bool can_phased = can_big && K / GK >= 2 && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31);
+    // the big GEMMs of the chain: 256 x 256 tiles -- when there are enough of them to occupy half the chip.  The ShapeVAE transformer's
+    // N = 1024 products at M = 3072 are 48 such tiles on 256 CUs: 21 / 66 / 50 us at K = 1024 / 4096 / 3072 against 13 / 43 / 35 on 192 tiles of
+    // 128 x 128 (scripts/dev/vae_bench.py --gemms)
+    const long tiles256 = (long)((M + HM - 1) / HM) * (N / HN);
+    if (variant == GV_AUTO) variant = (can_big && M >= 2048 && tiles256 >= 128) ? (can_phased ? GV_PHASED : GV_LOCKSTEP) : GV_128;
+    if (variant == GV_PHASED && !can_phased) variant = can_big ? GV_LOCKSTEP : GV_128;
+    if (variant == GV_LOCKSTEP && !can_big) variant = GV_128;
+    const bool big = variant != GV_128;
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
-#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(big, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev); break
+#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(variant, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev); break
     switch (ep) {
         GEO_GEMM_CASE(0);
         GEO_GEMM_CASE(EP_GELU);
@@ -2088,6 +2106,11 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
         GEO_GEMM_CASE(EP_RESID | EP_STATS);
         GEO_GEMM_CASE(EP_GELU | EP_PREAFF);
         GEO_GEMM_CASE(EP_RESID | EP_LOGIT);
+        // the ShapeVAE transformer's (foho_vae.inc): fused q | k | v behind a folded LayerNorm (+ qk_norm, + the un-normalised copy), fc1 keeping its pre-activation
+        GEO_GEMM_CASE(EP_PREAFF);
+        GEO_GEMM_CASE(EP_PREAFF | EP_QKN);
+        GEO_GEMM_CASE(EP_PREAFF | EP_QKN | EP_SAVEZ);
+        GEO_GEMM_CASE(EP_GELU | EP_PREAFF | EP_SAVEZ);
         default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
     }
 #undef GEO_GEMM_CASE
@@ -2139,20 +2162,14 @@ static Layout layout(const foho_geo_weights* w, int chunk) {
     l.total = off;
     return l;
 }
-// FOHO_GEO_LNFUSE=0: the forward chain with its LayerNorm kernels (A/B measurements, the parity test of the folded form); read at
-// every decode call, so that one process can compare the two forms
-static bool env_lnfuse() {
-    const char* e = getenv("FOHO_GEO_LNFUSE");
-    return !(e && e[0] == '0' && e[1] == 0);
-}
 struct Fold {   // device pointers of the folded operands in a prepared workspace (w1f == nullptr: chain with LayerNorm kernels)
     const h16* w1f = nullptr;
     const float *fold1 = nullptr, *fold2 = nullptr;
     float *stats = nullptr, *rowstat = nullptr;
 };
-static Fold fold_of(const Layout& l, char* base) {
+static Fold fold_of(const foho_geo_weights* w, const Layout& l, char* base) {
     Fold f;
-    if (!env_lnfuse()) return f;
+    if (w->flags & FOHO_GEO_NO_LNFUSE) return f;   // the forward chain with its LayerNorm kernels (A/B measurements, the parity test of the folded form)
     f.w1f = (const h16*)(base + l.w1f), f.fold1 = (const float*)(base + l.fold1), f.fold2 = (const float*)(base + l.fold2);
     f.stats = (float*)(base + l.stats), f.rowstat = (float*)(base + l.rowstat);
     return f;
@@ -2274,7 +2291,7 @@ extern "C" int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queri
     char* base = (char*)ws;
     const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
     h16 *E = (h16*)(base + l.e), *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
-    const Fold fold = fold_of(l, base);
+    const Fold fold = fold_of(w, l, base);
     for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
         const int M = (int)std::min<int64_t>(chunk_rows, n_queries - r0);
         const float* q = queries + 3 * r0;
@@ -2335,7 +2352,7 @@ extern "C" int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float
     char* base = (char*)ws;
     const h16 *kv = (const h16*)(base + l.kv), *vt = (const h16*)(base + l.vt);
     h16 *bA = (h16*)(base + l.a), *bB = (h16*)(base + l.b), *bC = (h16*)(base + l.c), *bH = (h16*)(base + l.h);
-    const Fold fold = fold_of(l, base);
+    const Fold fold = fold_of(w, l, base);
     const h16 *X0 = (const h16*)((const char*)cache + c.x0), *Qs = (const h16*)((const char*)cache + c.qs);
     const size_t W = w->width;
     for (int64_t r0 = 0; r0 < n_queries; r0 += chunk_rows) {
@@ -2700,6 +2717,32 @@ extern "C" int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void*
     }
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
+// The backward of one image: dQ, dK, dV from q / k / v where they lie, the forward's output and -lse, and dO (M, 64 heads; contiguous rows).
+// gq rows have stride ldgq, gk / gv rows ldgkv (heads side by side in all three).
+static int sdpa_bwd_image(const SdpaLayout& l, char* base, const h16* qb, int q_row, int q_head, const h16* kb, const h16* vb, int kvr, int kvh, const h16* O,
+                          const h16* dO, const float* nls, h16* gq, int ldgq, h16* gk, h16* gv, int ldgkv, int M, int L, int heads, hipStream_t s) {
+    const int W = heads * 64, nkb = L / 128;
+    h16 *kt = (h16*)(base + l.kt), *qs = (h16*)(base + l.qs), *qst = (h16*)(base + l.qst), *dot = (h16*)(base + l.dot);
+    float *delta = (float*)(base + l.delta), *part = (float*)(base + l.part);
+    hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, kb, kvr, W, L, kt, 0, kvh);      // K^T, key-permuted
+    if (M & 63) {   // columns of the transposed copies beyond M meet P = 0 and must be finite
+        const size_t n16 = (size_t)W * l.ldt * 2 / 16;
+        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)qst, n16);
+        hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dot, n16);
+    }
+    const unsigned tb = (unsigned)(((size_t)M * (W / 8) + 255) / 256);
+    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, qb, q_row, M, W, qst, l.ldt, q_head, SDPA_QSCALE, qs);
+    hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, dO, W, M, W, dot, l.ldt);
+    hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), dim3(256), 0, s, dO, O, W, heads, M, delta, (const int*)nullptr);
+    if (!launch_ok("sdpa backward (row kernels)")) return FOHO_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((heads * l.splits + 7) / 8) * nkb), dim3(256), 0, s, (const h16*)qs, (const h16*)qst, dO, (const h16*)dot, l.ldt, nls,
+                       (const float*)delta, kb, kvr, W, heads, M, l.splits, L, 0, part, (const int*)nullptr, vb, kvh);
+    const size_t n4 = (size_t)L * 2 * W / 4;
+    hipLaunchKernelGGL(k_geo_dkv_reduce16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, l.splits, L, W, gk, gv, ldgkv);
+    hipLaunchKernelGGL(k_geo_attn_dq, dim3(((M + DQQ - 1) / DQQ) * heads), dim3(256), 0, s, (const h16*)qs, dO, W, kb, kvr, W, (const h16*)kt, L, nls, (const float*)delta,
+                       gq, M, heads, vb, kvh, ldgq);
+    return launch_ok("k_geo_attn_dq") ? FOHO_OK : FOHO_ERR_LAUNCH;
+}
 extern "C" int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, const void* out, const float* nlse, const void* grad_out,
                              void* grad_q, void* grad_k, void* grad_v, void* ws, size_t ws_bytes, void* stream_) {
     if (int rc = sdpa_args("foho_sdpa_bwd", d, true)) return rc;
@@ -2708,35 +2751,15 @@ extern "C" int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void*
     const SdpaLayout l = sdpa_layout(M, L, heads);
     if (ws_bytes < l.total) return fail(FOHO_ERR_WORKSPACE, "foho_sdpa_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream_;
-    char* base = (char*)ws;
-    h16 *kt = (h16*)(base + l.kt), *qs = (h16*)(base + l.qs), *qst = (h16*)(base + l.qst), *dot = (h16*)(base + l.dot);
-    float *delta = (float*)(base + l.delta), *part = (float*)(base + l.part);
     const size_t nl = (size_t)((M + 63) & ~63) * heads;
-    const int nkb = L / 128, kvr = (int)d->kv_row, kvh = (int)d->kv_head;
     for (int b = 0; b < d->batch; b++) {
         const h16 *qb = (const h16*)q + (size_t)b * d->q_batch, *kb = (const h16*)k + (size_t)b * d->kv_batch, *vb = (const h16*)v + (size_t)b * d->kv_batch;
-        const h16 *dO = (const h16*)grad_out + (size_t)b * M * W, *O = (const h16*)out + (size_t)b * M * W;
-        const float* nls = nlse + b * nl;
-        hipLaunchKernelGGL(k_geo_pack_vt, dim3((W + 255) / 256, L / 16), dim3(256), 0, s, kb, kvr, W, L, kt, 0, kvh);      // K^T, key-permuted
-        if (M & 63) {   // columns of the transposed copies beyond M meet P = 0 and must be finite
-            const size_t n16 = (size_t)W * l.ldt * 2 / 16;
-            hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)qst, n16);
-            hipLaunchKernelGGL(k_geo_zero16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dot, n16);
-        }
-        const unsigned tb = (unsigned)(((size_t)M * (W / 8) + 255) / 256);
-        hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, qb, (int)d->q_row, M, W, qst, l.ldt, (int)d->q_head, SDPA_QSCALE, qs);
-        hipLaunchKernelGGL(k_geo_transpose_perm, dim3(tb), dim3(256), 0, s, dO, W, M, W, dot, l.ldt);
-        hipLaunchKernelGGL(k_geo_delta, dim3((((M + 63) & ~63) + 3) / 4), dim3(256), 0, s, dO, O, W, heads, M, delta, (const int*)nullptr);
-        if (!launch_ok("foho_sdpa_bwd (row kernels)")) return FOHO_ERR_LAUNCH;
-        hipLaunchKernelGGL(k_geo_attn_bwd, dim3(8 * ((heads * l.splits + 7) / 8) * nkb), dim3(256), 0, s, (const h16*)qs, (const h16*)qst, dO, (const h16*)dot, l.ldt, nls,
-                           (const float*)delta, kb, kvr, W, heads, M, l.splits, L, 0, part, (const int*)nullptr, vb, kvh);
-        const size_t n4 = (size_t)L * 2 * W / 4;
-        hipLaunchKernelGGL(k_geo_dkv_reduce16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, l.splits, L, W, (h16*)grad_k + (size_t)b * L * W,
-                           (h16*)grad_v + (size_t)b * L * W);
-        hipLaunchKernelGGL(k_geo_attn_dq, dim3(((M + DQQ - 1) / DQQ) * heads), dim3(256), 0, s, (const h16*)qs, dO, W, kb, kvr, W, (const h16*)kt, L, nls, (const float*)delta,
-                           (h16*)grad_q + (size_t)b * M * W, M, heads, vb, kvh);
+        if (int rc = sdpa_bwd_image(l, (char*)ws, qb, (int)d->q_row, (int)d->q_head, kb, vb, (int)d->kv_row, (int)d->kv_head, (const h16*)out + (size_t)b * M * W,
+                                    (const h16*)grad_out + (size_t)b * M * W, nlse + b * nl, (h16*)grad_q + (size_t)b * M * W, W, (h16*)grad_k + (size_t)b * L * W,
+                                    (h16*)grad_v + (size_t)b * L * W, W, M, L, heads, s))
+            return rc;
     }
-    return launch_ok("k_geo_attn_dq") ? FOHO_OK : FOHO_ERR_LAUNCH;
+    return FOHO_OK;
 }
 
 // Unit entry points (tests / profiling): the GEMM and the attention kernel on their own.
@@ -2744,12 +2767,10 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
                              int32_t gelu, float scale, void* stream) {
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
     if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
-    g_force128 = (gelu & 2) != 0;
-    g_force_lockstep = (gelu & 4) != 0;
-    struct Reset { ~Reset() { g_force128 = g_force_lockstep = false; } } reset;
+    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : GV_AUTO;
     gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
-                (hipStream_t)stream);
+                (hipStream_t)stream, nullptr, 0, nullptr, variant);
 }
 
 extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
@@ -2765,3 +2786,5 @@ extern "C" int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratc
                 (const int*)nullptr);
     return launch_ok("k_geo_attn") ? FOHO_OK : FOHO_ERR_LAUNCH;
 }
+
+#include "foho_vae.inc"

@@ -47,11 +47,11 @@ void foho_set_error(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* foho_last_error(void) { return g_err; }
-extern "C" int foho_version(void) { return 104; }
+extern "C" int foho_version(void) { return 105; }
 extern "C" int foho_abi_sizes(int64_t out[5]) {
     out[0] = sizeof(foho_image), out[1] = sizeof(foho_dims), out[2] = sizeof(foho_render_cfg), out[3] = sizeof(foho_step_cfg),
     out[4] = sizeof(foho_step_desc);
-    return 104;
+    return 105;
 }
 
 // optional per-kernel timing (foho_step_run_profiled): one hipEvent after every launch

@@ -24,7 +24,7 @@ from . import _lib as L
 
 
 class FohoGeoWeights(ctypes.Structure):
-    _fields_ = [("width", L.c_i), ("heads", L.c_i), ("n_latents", L.c_i), ("hidden", L.c_i), ("n_freqs", L.c_i), ("reserved", L.c_i),
+    _fields_ = [("width", L.c_i), ("heads", L.c_i), ("n_latents", L.c_i), ("hidden", L.c_i), ("n_freqs", L.c_i), ("flags", L.c_i),
                 ("freqs", L.vp), ("w_qproj", L.vp), ("b_qproj", L.vp), ("ln_q_g", L.vp), ("ln_q_b", L.vp), ("ln_kv_g", L.vp),
                 ("ln_kv_b", L.vp), ("w_q", L.vp), ("b_q", L.vp), ("w_kv", L.vp), ("b_kv", L.vp), ("w_proj", L.vp), ("b_proj", L.vp),
                 ("ln_2_g", L.vp), ("ln_2_b", L.vp), ("w_fc1", L.vp), ("b_fc1", L.vp), ("w_fc2", L.vp), ("b_fc2", L.vp),
@@ -204,6 +204,16 @@ class HipGeoDecoder:
         self._check(self.lib.foho_geo_set_kv(ctypes.byref(self.w), L.vp(kv.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
                                              ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_set_kv")
         self._prepared = None
+
+    @property
+    def ln_fuse(self):
+        """True (the product path): ln_2 runs inside fc1 and ln_post + output_proj inside fc2's epilogue; False: the forward chain with
+        its LayerNorm kernels (foho_geo_weights.flags & FOHO_GEO_NO_LNFUSE) -- A/B measurements, the parity test of the folded form."""
+        return not (self.w.flags & 1)
+
+    @ln_fuse.setter
+    def ln_fuse(self, on):
+        self.w.flags = (self.w.flags & ~1) | (0 if on else 1)
 
     @property
     def keep_activations(self):

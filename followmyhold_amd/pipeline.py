@@ -64,12 +64,25 @@ def vae_attention_backend():
     return stack
 
 
+def vae_tokens(vae, latents):
+    """`vae(latents)` of PL:295 (ShapeVAE.forward: post_kl -> transformer).  With `vae_transformer.install(vae)` the transformer -- and, under
+    autograd, its backward to the latents (PL:1391-1393, 1507-1509) -- runs on this package's kernels (`foho_vae_fwd/_bwd`); inputs they do
+    not take (another dtype, a token count that is not a multiple of 128) and VAEs without it go through the torch module, with the
+    attention backend of `vae_attention_backend()`."""
+    tr = getattr(vae, "hip_transformer", None)
+    if tr is not None:
+        x0 = vae.post_kl(latents)
+        if tr.accepts(x0):
+            return tr(x0)
+    with vae_attention_backend():
+        return vae(latents)
+
+
 def latent2sdf(pred, xyz_samples, grid_size, vae, device, num_chunks=8000):
     """PL:292-338 (return_mesh=False): rescale the latent, run the VAE transformer, query the geometry decoder in chunks of
     8000 grid points, negate the logits so that the field is negative inside.  -> (1, G, G, G) float32."""
     pred = 1 / vae.scale_factor * pred
-    with vae_attention_backend():
-        pred = vae(pred)
+    pred = vae_tokens(vae, pred)
     hip = getattr(vae, "hip_geo", None)          # geo_decode.install(vae): the decoder on the matrix cores
     if hip is not None:
         # all grid points in one call, no 8000-query chunks; under autograd (PL:1391-1393, 1507-1509) the gradient reaches

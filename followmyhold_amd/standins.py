@@ -104,6 +104,54 @@ class Hy3dgenLayoutDecoder(nn.Module):
         return self.output_proj(self.ln_post(x))
 
 
+class Hy3dgenLayoutShapeVAE(nn.Module):
+    """post_kl + transformer laid out like hy3dgen's ShapeVAE (hy3dgen/shapegen/models/autoencoders/{model,attention_blocks}.py, not in the
+    reference tree; restated from its published structure): transformer.resblocks[i] = ResidualAttentionBlock{ln_1, attn{c_qkv (bias per
+    qkv_bias), c_proj, attention{heads, q_norm, k_norm}}, ln_2, mlp{c_fc, c_proj}} -- c_qkv's output is viewed as (tokens, heads, 3 d) and
+    split into q | k | v per head (rows INTERLEAVE head by head), LayerNorms built with eps 1e-6, qk_norm = LayerNorm over the head
+    dimension of q and of k (the released config: qkv_bias False, qk_norm True).  `geo_decoder` is a Hy3dgenLayoutDecoder."""
+
+    def __init__(self, num_latents=3072, embed_dim=64, width=1024, heads=16, layers=16, num_freqs=8, qk_norm=True, qkv_bias=False,
+                 scale_factor=1.0):
+        super().__init__()
+        self.latent_shape = (num_latents, embed_dim)
+        self.scale_factor = scale_factor
+        self.post_kl = nn.Linear(embed_dim, width)
+        self.transformer = nn.Module()
+        blocks = []
+        d = width // heads
+        for _ in range(layers):
+            blk = nn.Module()
+            blk.ln_1, blk.ln_2 = nn.LayerNorm(width, eps=1e-6), nn.LayerNorm(width, eps=1e-6)
+            blk.attn = nn.Module()
+            blk.attn.c_qkv, blk.attn.c_proj = nn.Linear(width, 3 * width, bias=qkv_bias), nn.Linear(width, width)
+            blk.attn.attention = nn.Module()
+            blk.attn.attention.heads = heads
+            blk.attn.attention.q_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
+            blk.attn.attention.k_norm = nn.LayerNorm(d, elementwise_affine=True, eps=1e-6) if qk_norm else nn.Identity()
+            blk.mlp = nn.Module()
+            blk.mlp.c_fc, blk.mlp.c_proj = nn.Linear(width, 4 * width), nn.Linear(4 * width, width)
+            blocks.append(blk)
+        self.transformer.resblocks = nn.ModuleList(blocks)
+        self.geo_decoder = Hy3dgenLayoutDecoder(width, heads, num_freqs=num_freqs, qk_norm=qk_norm)
+        self.heads = heads
+
+    def block_forward(self, blk, x):
+        B, N, C = x.shape
+        qkv = blk.attn.c_qkv(blk.ln_1(x)).view(B, N, self.heads, -1)
+        q, k, v = torch.split(qkv, C // self.heads, dim=-1)
+        q, k = blk.attn.attention.q_norm(q), blk.attn.attention.k_norm(k)
+        a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(B, N, C)
+        x = x + blk.attn.c_proj(a)
+        return x + blk.mlp.c_proj(F.gelu(blk.mlp.c_fc(blk.ln_2(x))))
+
+    def forward(self, latents):
+        x = self.post_kl(latents)
+        for blk in self.transformer.resblocks:
+            x = self.block_forward(blk, x)
+        return x
+
+
 class StandInShapeVAE(nn.Module):
     def __init__(self, num_latents=64, embed_dim=8, width=32, heads=2, layers=1, num_freqs=4, radius=0.8, sharpness=4.0,
                  gain=0.15, scale_factor=1.0):

@@ -35,12 +35,20 @@
  *   foho_icp_run_surface     the same with on_surface=True: closest point on the target triangles (ICP:106-107)
  *   foho_mesh_decimate       hy3dgen FaceReducer = pymeshlab quadric edge collapse (RUN:163), host code
  *   foho_geo_decode_fwd      the chunked `vae.geo_decoder(queries, latents)` loop of latent2sdf (PL:298-308)
+ *   foho_vae_fwd/_bwd        `pred = vae(pred)` of latent2sdf (PL:295): the ShapeVAE transformer and its backward to the tokens
+ *   foho_sdpa_fwd/_bwd       torch.nn.functional.scaled_dot_product_attention inside that transformer (fallback route)
  */
 #ifndef FOHO_HIP_H
 #define FOHO_HIP_H
 
 #include <stddef.h>
 #include <stdint.h>
+
+/* Every entry point below is FOHO_API; the library is built with -fvisibility=hidden, so these (and nothing else: no kernel
+ * stubs, no helpers) are what `nm -D libfoho_hip.so` shows. */
+#ifndef FOHO_API
+#define FOHO_API __attribute__((visibility("default")))
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -53,13 +61,13 @@ typedef enum {
     FOHO_ERR_WORKSPACE = -3
 } foho_status;
 
-const char* foho_last_error(void);
-int foho_version(void);
+FOHO_API const char* foho_last_error(void);
+FOHO_API int foho_version(void);
 /* Layout check for bindings that mirror the structs (ctypes, cgo, JNI): fills out[0..4] with sizeof(foho_image),
  * sizeof(foho_dims), sizeof(foho_render_cfg), sizeof(foho_step_cfg), sizeof(foho_step_desc) of THIS build and returns
  * foho_version().  A caller whose own sizes differ is talking to another version of the ABI (fields are only ever
  * appended; entry points that gained parameters: foho_raster_bwd's blur_radius in 101). */
-int foho_abi_sizes(int64_t out[5]);
+FOHO_API int foho_abi_sizes(int64_t out[5]);
 
 /* ---- per-image constants (array of B of these lives in DEVICE memory) -------------------- */
 typedef struct {
@@ -216,22 +224,22 @@ enum {
     FOHO_WS_FRAG_COUNT, FOHO_WS_SEG_COUNT, FOHO_WS_HAND_ORDER, FOHO_WS_NREGIONS
 };
 
-size_t foho_step_workspace_bytes(const foho_dims* dims);
+FOHO_API size_t foho_step_workspace_bytes(const foho_dims* dims);
 /* byte offset and byte length of a named region inside the workspace (-1 on bad id) */
-int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
+FOHO_API int64_t foho_step_workspace_region(const foho_dims* dims, int region, int64_t* nbytes);
 /* One step (or the prefix of it that stage_mask names) on `stream`, asynchronously.  Everything that shapes the launches is in
  * desc / cfg (cfg->listed_cap: how the resolve pass finds its tiles); the process environment is not consulted. */
-int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
+FOHO_API int foho_step_run(const foho_step_desc* desc, const foho_step_cfg* cfg, int stage_mask, void* stream);
 /* Applies the update a deferred_update step left pending (no-op per image when nothing is pending): one small launch;
  * cfg->deferred_update must carry the number of the LAST step run. */
-int foho_step_finalize(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream);
+FOHO_API int foho_step_finalize(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream);
 /* Runs foho_step_run(FOHO_STAGE_STEP) TWICE: an un-timed iteration (with the other parity when cfg->deferred_update is
  * set), then the same iteration again with every launch bracketed by hipEvents on `stream`; synchronises the stream and
  * returns the duration of each launch of the second iteration in milliseconds (measurement aid for bench.py);
  * foho_kernel_name(i) names the i-th launch of the calling thread's last profiled run ("" past the end). */
 #define FOHO_N_KERNELS 10
-int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
-const char* foho_kernel_name(int i);
+FOHO_API int foho_step_run_profiled(const foho_step_desc* desc, const foho_step_cfg* cfg, void* stream, float* ms_out);
+FOHO_API const char* foho_kernel_name(int i);
 
 /* ---- stand-alone operators (facade level) -------------------------------------------------- */
 /* pytorch3d rasterize_meshes(faces_per_pixel=1) on NDC vertices of ONE mesh.
@@ -242,14 +250,14 @@ const char* foho_kernel_name(int i);
  * are culled, faces that straddle it are rasterised as the one or two sub-triangles pytorch3d's clip_faces cuts them into
  * (pix_to_face and bary refer to the unclipped face); *overflow_flag gets bit2 (4) when the K = 100 cut-off could not be
  * reproduced. */
-int foho_raster_fwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+FOHO_API int foho_raster_fwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     float blur_radius, float sigma, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                     float* sil_prod, int32_t* overflow_flag, void* workspace, size_t workspace_bytes, void* stream);
-size_t foho_raster_workspace_bytes(int32_t V, int32_t F, int32_t H, int32_t W);
+FOHO_API size_t foho_raster_workspace_bytes(int32_t V, int32_t F, int32_t H, int32_t W);
 /* backward of the K=1 fragments: grad_verts_ndc (V,3) += d(zbuf,bary,dists)/d verts_ndc.  blur_radius = the forward
  * call's (it decides which half of a near-clipped face left a fragment; for such faces grad_bary is taken w.r.t. the
  * sub-triangle's barycentrics) */
-int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+FOHO_API int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                     const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
                     const float* grad_dists, float* grad_verts_ndc, float blur_radius, void* stream);
 /* backward of sil_prod (version 102): grad_verts_ndc (V,3) += d(sil_prod)/d verts_ndc . grad_prod, i.e. the gradient of
@@ -257,19 +265,19 @@ int foho_raster_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int
  * carry one: d prod / d sdist_k = prod sigmoid(-sdist_k / sigma) / sigma).  sil_prod: foho_raster_fwd's output; blur_radius and
  * sigma: that call's.  The product over ALL fragments is differentiated -- identical to the K = 100 product unless a pixel
  * holds 100 fractional-coverage fragments or more. */
-int foho_raster_sil_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
+FOHO_API int foho_raster_sil_bwd(const float* verts_ndc, const int32_t* faces, int32_t V, int32_t F, int32_t H, int32_t W,
                         const float* sil_prod, const float* grad_prod, float* grad_verts_ndc, float blur_radius, float sigma,
                         void* stream);
 /* K=1 nearest neighbour: d2 (N1), idx (N1) int64; ties -> lowest index */
-int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
+FOHO_API int foho_knn1_fwd(const float* p1, int32_t N1, const float* p2, int32_t N2, float* d2, int64_t* idx, void* stream);
 
 /* kaolin.metrics.trianglemesh.point_to_mesh_distance (SDF:101): exact squared distance of N points to the
  * closest triangle of ONE mesh and that triangle's index (ties -> lowest index); face_idx may be NULL. */
-int foho_point_mesh_dist(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
+FOHO_API int foho_point_mesh_dist(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
                          float* d2, int64_t* face_idx, void* stream);
 /* kaolin.ops.mesh.check_sign (SDF:104): inside[n] = 1 when pts[n] is inside the closed mesh (+z ray parity,
  * rays through edges / vertices counted once). */
-int foho_inside_points(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
+FOHO_API int foho_inside_points(const float* verts, const int32_t* faces, int32_t V, int32_t F, const float* pts, int32_t N,
                        uint8_t* inside, void* stream);
 
 /* smplx MANOLayer(pose2rot=False) forward (hamer/models/hamer.py:125-130).  Model arrays (device,
@@ -277,14 +285,14 @@ int foho_inside_points(const float* verts, const int32_t* faces, int32_t V, int3
  * parents (16) int32.  betas (B,10), rot_mats (B,16,3,3) = [global_orient | hand_pose].  Outputs verts (B,V,3),
  * joints (B,16,3) posed joints (may be NULL).  use_mfma: 1 = pose-blend contraction on the f32 matrix cores,
  * 0 = per-vertex dot products, -1 = automatic (matrix cores when B >= 16). */
-size_t foho_lbs_workspace_bytes(int32_t B, int32_t V);
-int foho_lbs_fwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
+FOHO_API size_t foho_lbs_workspace_bytes(int32_t B, int32_t V);
+FOHO_API int foho_lbs_fwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
                  const float* lbs_weights, const int32_t* parents, int32_t V, const float* betas, const float* rot_mats,
                  int32_t B, int32_t use_mfma, float* verts, float* joints, void* workspace, size_t workspace_bytes,
                  void* stream);
 /* backward of the last foho_lbs_fwd run on the same workspace: grad_verts (B,V,3), grad_joints (B,16,3) or NULL
  * -> grad_betas (B,10), grad_rot_mats (B,16,3,3) */
-int foho_lbs_bwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
+FOHO_API int foho_lbs_bwd(const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
                  const float* lbs_weights, const int32_t* parents, int32_t V, const float* rot_mats, int32_t B,
                  const float* grad_verts, const float* grad_joints, float* grad_betas, float* grad_rot_mats,
                  void* workspace, size_t workspace_bytes, void* stream);
@@ -294,8 +302,8 @@ int foho_lbs_bwd(const float* v_template, const float* shapedirs, const float* p
  * trimesh-style procrustes (reflection=False, scale = !fixed_scale) -> T = next @ T -> scale clipped to
  * [min_scale, max_scale].  T_out (4x4 row-major) is the transform stored with the lowest mean inlier distance,
  * cost_out that distance, cost_history (n_iter) optional.  Asynchronous: 2 launches per iteration, no host sync. */
-size_t foho_icp_workspace_bytes(int32_t N, int32_t M);
-int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int32_t n_iter, int32_t n_outliers,
+FOHO_API size_t foho_icp_workspace_bytes(int32_t N, int32_t M);
+FOHO_API int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int32_t n_iter, int32_t n_outliers,
                  int32_t fixed_scale, double min_scale, double max_scale, double* T_out, double* cost_out,
                  double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -304,16 +312,16 @@ int foho_icp_run(const double* src, int32_t N, const double* tgt, int32_t M, int
  * iteration is 2 launches whose grids carry the start index, so the 17 coarse starts cost the launches of one.
  * T_out (n_starts, 16), cost_out (n_starts), cost_history (n_starts, n_iter) optional; per start identical to
  * foho_icp_run (which is this call with n_starts = 1). */
-size_t foho_icp_batch_workspace_bytes(int32_t n_starts, int32_t N, int32_t M);
-int foho_icp_run_batch(const double* src, int32_t n_starts, int32_t N, const double* tgt, int32_t M, int32_t n_iter,
+FOHO_API size_t foho_icp_batch_workspace_bytes(int32_t n_starts, int32_t N, int32_t M);
+FOHO_API int foho_icp_run_batch(const double* src, int32_t n_starts, int32_t N, const double* tgt, int32_t M, int32_t n_iter,
                        int32_t n_outliers, int32_t fixed_scale, double min_scale, double max_scale, double* T_out,
                        double* cost_out, double* cost_history, void* workspace, size_t workspace_bytes, void* stream);
 
 /* icp(..., on_surface=True) (ICP:106-107): q = trimesh.proximity.closest_point(target_mesh, p), the closest point ON the
  * target triangles (float64 brute force over all Ft triangles, Voronoi-region test per triangle) instead of the nearest
  * sampled target point; everything else as foho_icp_run_batch.  tgt_verts (Vt,3) float64, tgt_faces (Ft,3) int32. */
-size_t foho_icp_surface_workspace_bytes(int32_t n_starts, int32_t N, int32_t Ft);
-int foho_icp_run_surface(const double* src, int32_t n_starts, int32_t N, const double* tgt_verts, int32_t Vt,
+FOHO_API size_t foho_icp_surface_workspace_bytes(int32_t n_starts, int32_t N, int32_t Ft);
+FOHO_API int foho_icp_run_surface(const double* src, int32_t n_starts, int32_t N, const double* tgt_verts, int32_t Vt,
                          const int32_t* tgt_faces, int32_t Ft, int32_t n_iter, int32_t n_outliers, int32_t fixed_scale,
                          double min_scale, double max_scale, double* T_out, double* cost_out, double* cost_history,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -325,11 +333,11 @@ int foho_icp_run_surface(const double* src, int32_t n_starts, int32_t N, const d
  * faces (up to faces_cap x 3, int64, outward orientation), l_dev per vertex (optional), counts (device int32[3]:
  * vertices, triangles, overflow bits -- bit0 vertex capacity, bit1 face capacity).  Vertex order: (cube, patch); face
  * order: (axis, i, j, k) of the sign-change grid edge.  The workspace keeps what foho_flexi_bwd needs. */
-size_t foho_flexi_workspace_bytes(int32_t res);
-int foho_flexi_fwd(const float* x, const float* s, int32_t res, float* verts, int32_t verts_cap, int64_t* faces,
+FOHO_API size_t foho_flexi_workspace_bytes(int32_t res);
+FOHO_API int foho_flexi_fwd(const float* x, const float* s, int32_t res, float* verts, int32_t verts_cap, int64_t* faces,
                    int32_t faces_cap, float* l_dev, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 /* grad_s (G^3) and optional grad_x (G^3,3) must be zeroed by the caller; accumulated with float atomics. */
-int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* grad_verts, int32_t n_verts, float* grad_s,
+FOHO_API int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* grad_verts, int32_t n_verts, float* grad_s,
                    float* grad_x, const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- topology tables of a packed mesh, built on the device (at set-up, and every time the object's connectivity
@@ -340,8 +348,8 @@ int foho_flexi_bwd(const float* x, const float* s, int32_t res, const float* gra
  * form closed, consistently oriented 2-manifolds (then n_edges = 3 F_obj / 2); *flag != 0 afterwards means they do not
  * (bit1) or a valence exceeds 48 (bit0) and the caller must build the tables with a general sort.  obj_flag == NULL:
  * incidence lists only. */
-size_t foho_topology_workspace_bytes(int32_t V);
-int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8_t* obj_flag, int32_t* inc_off, int32_t* inc_fc,
+FOHO_API size_t foho_topology_workspace_bytes(int32_t V);
+FOHO_API int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8_t* obj_flag, int32_t* inc_off, int32_t* inc_fc,
                          int32_t* nbr_idx, int32_t* flag, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- capacity mode: a new object mesh (new vertex / face counts, new connectivity) every iteration without a host
@@ -362,8 +370,8 @@ int foho_topology_tables(const int32_t* faces, int32_t V, int32_t F, const uint8
  * caller must fall back to exact-size tables built by a general sort).  While any of these three bits is set the
  * step computes losses and gradients but leaves parameters and optimiser state alone; the caller clears the bits once
  * it has dealt with them.  obj_flag (Vtot bytes): 1 = object vertex slot. */
-size_t foho_object_workspace_bytes(int32_t Vtot, int32_t Ftot);   /* zero-fill it before the first use */
-int foho_object_update(const foho_step_desc* desc, const int32_t* counts, const int64_t* obj_faces, int32_t faces_cap,
+FOHO_API size_t foho_object_workspace_bytes(int32_t Vtot, int32_t Ftot);   /* zero-fill it before the first use */
+FOHO_API int foho_object_update(const foho_step_desc* desc, const int32_t* counts, const int64_t* obj_faces, int32_t faces_cap,
                        const uint8_t* obj_flag, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- mesh post-processing after the pipeline ------------------------------------------
@@ -372,7 +380,7 @@ int foho_object_update(const foho_step_desc* desc, const int32_t* counts, const 
  * involved (the reference's is MeshLab's serial CPU code; it runs once per image).  verts (V,3) float32, faces (F,3)
  * int64 -> out_verts (room for V x 3), out_faces (room for F x 3), out_counts[2] = {vertices, faces} written.
  * Vertices and faces keep their relative order; the same input gives the same output. */
-int foho_mesh_decimate(const float* verts, int32_t V, const int64_t* faces, int32_t F, int32_t target_faces,
+FOHO_API int foho_mesh_decimate(const float* verts, int32_t V, const int64_t* faces, int32_t F, int32_t target_faces,
                        float* out_verts, int64_t* out_faces, int32_t* out_counts);
 
 /* ---- the ShapeVAE geometry decoder of latent2sdf on the matrix cores ----------------------
@@ -385,7 +393,8 @@ int foho_mesh_decimate(const float* verts, int32_t V, const int64_t* faces, int3
  * in_features), fp32 biases / LayerNorm parameters.  Constraints (FOHO_ERR_BAD_ARG otherwise): head dimension 64
  * (width = 64 heads), width % 128 == 0 and <= 1024, n_latents % 64 == 0, hidden % 128 == 0, n_freqs <= 10. */
 typedef struct {
-    int32_t width, heads, n_latents, hidden, n_freqs, reserved;
+    int32_t width, heads, n_latents, hidden, n_freqs;
+    int32_t flags;                   /* FOHO_GEO_* bits below; 0 = the product path */
     const float* freqs;              /* (n_freqs) DEVICE: the embedder's frequencies (2^j pi, or 2^j with include_pi = False) */
     const void* w_qproj;             /* (width, 64) fp16: query_proj, columns 3 (2 n_freqs + 1) .. 63 zero      */
     const float* b_qproj;            /* (width)                                                                 */
@@ -424,26 +433,29 @@ typedef struct {
      * with eps 1e-6 and ln_post with torch's default 1e-5); 0 = the same as ln_eps, which stays ln_post's                      */
     float ln_q_eps, ln_kv_eps, ln_2_eps, reserved2;
 } foho_geo_weights;
+/* foho_geo_weights.flags.  FOHO_GEO_NO_LNFUSE: run the forward chain with its two LayerNorm kernels instead of the folded form (ln_2
+ * inside fc1, ln_post + output_proj inside fc2's epilogue): same logits to one fp16 ulp, 3 % slower -- for A/B measurements and the
+ * parity test of the folded form.  (Until version 104 this was the environment variable FOHO_GEO_LNFUSE, read at every call.) */
+#define FOHO_GEO_NO_LNFUSE 1
 
 /* sizeof(foho_geo_weights) of the loaded build (version 104): the Python side compares it with its ctypes mirror before the
  * first call, like foho_abi_sizes does for the step's structs */
-int64_t foho_geo_abi_size(void);
+FOHO_API int64_t foho_geo_abi_size(void);
 /* workspace for row blocks of `chunk_rows` queries: K / V of the latent tokens + the block's activations (14.5 KB per
  * query at width 1024 / hidden 4096; 16384 rows keep a block inside the 256 MB Infinity Cache).  0 on bad arguments. */
-size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
+FOHO_API size_t foho_geo_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
 /* once per set of latent tokens: LayerNorm + K/V projection of `latents` (n_latents, width) fp16 into the workspace
  * (V transposed and key-permuted for the attention kernel).  The same chunk_rows as the decode calls that follow.
  * Also rebuilds, from the weights as they are at this call, the operands of the forward's folded LayerNorms (fc1's weights
  * times ln_2's gain, their row sums, ln_post's gain times w_out: 8 MB, two small kernels) -- foho_geo_decode_fwd[_cached] run
  * ln_2 inside fc1 and ln_post + output_proj inside fc2's epilogue; weights changed AFTER the prepare call take effect with
- * the next one.  FOHO_GEO_LNFUSE=0 in the environment runs the chain with its LayerNorm kernels instead (same logits to one
- * fp16 ulp; read at every decode call). */
-int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chunk_rows, void* workspace, size_t workspace_bytes,
+ * the next one.  flags & FOHO_GEO_NO_LNFUSE runs the chain with its LayerNorm kernels instead (same logits to one fp16 ulp). */
+FOHO_API int foho_geo_prepare(const foho_geo_weights* w, const void* latents, int32_t chunk_rows, void* workspace, size_t workspace_bytes,
                      void* stream);
 /* logits[n] = geo_decoder(queries[n], latents) for n < n_queries: queries (N,3) fp32 (already rounded the way the caller's
  * pipeline rounds them: the reference casts them to fp16 first, PL:303), logits (N) fp32.  Uses the K / V that
  * foho_geo_prepare left in the workspace.  9 launches per row block, asynchronous, no host synchronisation. */
-int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
+FOHO_API int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
                         void* workspace, size_t workspace_bytes, void* stream);
 /* Gradients to the latent tokens: the decoder as a differentiable function of K / V.
  * foho_geo_set_kv installs K / V computed by the caller -- kv (n_latents, 2 width) fp16 = c_kv(ln(latents)), rows [K of all
@@ -458,13 +470,13 @@ int foho_geo_decode_fwd(const foho_geo_weights* w, const float* queries, int64_t
  *     5 GB for a 65^3 grid -- the part has 288), or
  *   - with saved = NULL, from a RECOMPUTATION of the forward chain per row block (+11 ms per 65^3 grid, no memory).
  * `bwd_workspace`: foho_geo_bwd_workspace_bytes(w, chunk_rows), used by both calls. */
-size_t foho_geo_bwd_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
-size_t foho_geo_saved_bytes(const foho_geo_weights* w, int32_t chunk_rows, int64_t n_queries);
-int foho_geo_set_kv(const foho_geo_weights* w, const void* kv, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
-int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
+FOHO_API size_t foho_geo_bwd_workspace_bytes(const foho_geo_weights* w, int32_t chunk_rows);
+FOHO_API size_t foho_geo_saved_bytes(const foho_geo_weights* w, int32_t chunk_rows, int64_t n_queries);
+FOHO_API int foho_geo_set_kv(const foho_geo_weights* w, const void* kv, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+FOHO_API int foho_geo_decode_fwd_keep(const foho_geo_weights* w, const float* queries, int64_t n_queries, float* logits, int32_t chunk_rows,
                              void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes, void* saved,
                              size_t saved_bytes, void* stream);
-int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+FOHO_API int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
                         int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace, size_t bwd_workspace_bytes,
                         const void* saved, size_t saved_bytes, void* stream);
 /* The query side, cached.  The grid the latent is decoded on never changes during a guidance run (PL:1125-1143: 65^3 points for
@@ -473,10 +485,10 @@ int foho_geo_decode_bwd(const foho_geo_weights* w, const float* queries, int64_t
  * x0 = query_proj(embed(q)) and the scaled attention queries of all rows once into `cache` (foho_geo_query_cache_bytes: 4 KB per
  * query at width 1024 -- 1.1 GB per 65^3 grid); foho_geo_decode_fwd_cached is foho_geo_decode_fwd from there on: the same kernels
  * on the same numbers, logits bitwise equal. */
-size_t foho_geo_query_cache_bytes(const foho_geo_weights* w, int64_t n_queries);
-int foho_geo_prepare_queries(const foho_geo_weights* w, const float* queries, int64_t n_queries, int32_t chunk_rows, void* workspace,
+FOHO_API size_t foho_geo_query_cache_bytes(const foho_geo_weights* w, int64_t n_queries);
+FOHO_API int foho_geo_prepare_queries(const foho_geo_weights* w, const float* queries, int64_t n_queries, int32_t chunk_rows, void* workspace,
                              size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream);
-int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float* queries, int64_t n_queries, const void* cache, size_t cache_bytes,
+FOHO_API int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float* queries, int64_t n_queries, const void* cache, size_t cache_bytes,
                                float* logits, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
 /* foho_geo_decode_bwd over the ACTIVE rows only.  The gradient that reaches latent2sdf in the guidance loop comes out of the
  * FlexiCubes backward (PL:1507-1509, 1600) and is non-zero only at the end points of the grid edges the iso-surface crosses
@@ -488,8 +500,8 @@ int foho_geo_decode_fwd_cached(const foho_geo_weights* w, const float* queries, 
  * a hipGraph.  row_cap: the caller's upper bound on the number of active rows (<= 0 or > n_queries: n_queries, which can never
  * overflow); rows beyond it are dropped and COUNTED.  stats_out: optional DEVICE int32[2] = {active rows, rows dropped}.
  * rows_workspace: foho_geo_rows_workspace_bytes(n_queries, row_cap, chunk_rows); workspace / bwd_workspace as for foho_geo_decode_bwd. */
-size_t foho_geo_rows_workspace_bytes(int64_t n_queries, int64_t row_cap, int32_t chunk_rows);
-int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
+FOHO_API size_t foho_geo_rows_workspace_bytes(int64_t n_queries, int64_t row_cap, int32_t chunk_rows);
+FOHO_API int foho_geo_decode_bwd_rows(const foho_geo_weights* w, const float* queries, int64_t n_queries, const float* grad_logits, float* grad_kv,
                              int64_t row_cap, int32_t chunk_rows, void* workspace, size_t workspace_bytes, void* bwd_workspace,
                              size_t bwd_workspace_bytes, void* rows_workspace, size_t rows_workspace_bytes, int32_t* stats_out, void* stream);
 /* Attention as an operator, forward and backward (version 104): O = softmax(Q K^T / sqrt(64)) V per head of 64 -- what
@@ -509,21 +521,67 @@ typedef struct foho_sdpa_desc {
     int64_t q_batch, q_row, q_head;       /* strides of q in halfs */
     int64_t kv_batch, kv_row, kv_head;    /* strides of k and of v in halfs */
 } foho_sdpa_desc;
-size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads);
-int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, void* out, float* nlse, float* lse_natural,
+FOHO_API size_t foho_sdpa_workspace_bytes(int32_t M, int32_t L, int32_t heads);
+FOHO_API int foho_sdpa_fwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, void* out, float* nlse, float* lse_natural,
                   void* workspace, size_t workspace_bytes, void* stream);
-int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, const void* out, const float* nlse,
+FOHO_API int foho_sdpa_bwd(const foho_sdpa_desc* d, const void* q, const void* k, const void* v, const void* out, const float* nlse,
                   const void* grad_out, void* grad_q, void* grad_k, void* grad_v, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- the ShapeVAE transformer of latent2sdf, forward and backward to its input (version 105) ----------------------------
+ * Replaces `pred = vae(pred)` of latent2sdf (PL:295; hy3dgen ShapeVAE.forward = post_kl -> Transformer: n_layers
+ * ResidualAttentionBlocks  x = x + c_proj(attention(qk_norm(c_qkv(ln_1(x)))));  x = x + mlp.c_proj(gelu(mlp.c_fc(ln_2(x))))  over the
+ * 3072 latent tokens), which the reference runs AND back-propagates in every one of the 550 inner iterations per image
+ * (PL:1391-1393, 1507-1509, 1600: the guidance gradient reaches the noise prediction through it).  The weights are constants of the
+ * guidance (only the noise prediction and the pose are optimised): the backward returns the gradient with respect to the INPUT tokens
+ * only.  post_kl (a 64 -> width Linear) stays with the caller.
+ * x0 / out / grad_out / grad_x0: (batch x n_tokens, width) fp16, images one after the other.  fp16 storage, fp32 accumulation.
+ * Per layer 4 GEMMs + the attention kernels: both LayerNorms are FOLDED into the GEMM behind them (the GEMM runs on the
+ * un-normalised rows with gamma folded into the weights; mean / rstd per row -- left behind by the epilogue of the GEMM in front --
+ * are applied in the epilogue), GELU, residuals, qk_norm and the statistics are epilogues.  The caller prepares, once:
+ *   w_qkv     (3 width, width) fp16 = rows [Q of all heads | K of all heads | V of all heads] of c_qkv, each times ln_1's gain
+ *             (hy3dgen interleaves q | k | v per head: the caller permutes the rows)
+ *   fold_qkv  fp32: [b' (3 width) = bias + W beta | s (3 width) = row sums of the ROUNDED folded weights |
+ *             q_norm: gain (64), bias (64), eps, 3 pad | k_norm: the same]  (the last 264 only when qk_norm != 0)
+ *   w_qkv_t   (width, 3 width) fp16 = w_qkv^T (of the folded weights: the backward GEMM then yields d / d xhat directly)
+ *   w_proj (width, width), b_proj, w_proj_t = w_proj^T
+ *   w_fc1 (hidden, width) folded with ln_2's gain, fold_fc1 = [b' (hidden) | s (hidden)], w_fc1_t = w_fc1^T (folded)
+ *   w_fc2 (width, hidden), b_fc2, w_fc2_t = w_fc2^T
+ * Constraints: head dimension 64, width % 128 == 0 and <= 1024, hidden % 128 == 0, n_tokens % 128 == 0. */
+typedef struct foho_vae_layer {
+    const void* w_qkv; const float* fold_qkv; const void* w_qkv_t;
+    const void* w_proj; const float* b_proj; const void* w_proj_t;
+    const void* w_fc1; const float* fold_fc1; const void* w_fc1_t;
+    const void* w_fc2; const float* b_fc2; const void* w_fc2_t;
+    float eps1, eps2;                 /* of ln_1 / ln_2 */
+    int32_t qk_norm, reserved;        /* != 0: LayerNorm over the 64 head dimensions of q and of k (parameters at the end of fold_qkv) */
+} foho_vae_layer;
+typedef struct foho_vae_desc {
+    int32_t width, heads, hidden, n_layers, n_tokens, batch;
+    const foho_vae_layer* layers;     /* HOST array of n_layers records (the pointers inside are DEVICE pointers) */
+    const float* zeros;               /* DEVICE: max(hidden, 3 width) fp32 zeros (the backward GEMMs have no bias) */
+} foho_vae_desc;
+/* sizeof(foho_vae_layer) * 1000 + sizeof(foho_vae_desc): bindings that mirror the structs compare it with their own */
+FOHO_API int64_t foho_vae_abi_size(void);
+/* scratch of either direction / what foho_vae_fwd keeps for foho_vae_bwd (per layer: input, q | k | v (+ their un-normalised copy
+ * with qk_norm), attention output and log-sum-exp, the MLP's input and pre-activation: 65-84 MB at 3072 tokens x 1024).  0 on bad arguments. */
+FOHO_API size_t foho_vae_workspace_bytes(const foho_vae_desc* d);
+FOHO_API size_t foho_vae_saved_bytes(const foho_vae_desc* d);
+/* out = transformer(x0).  saved == NULL: nothing is kept (inference).  Asynchronous, 8 launches per layer and image, no host synchronisation. */
+FOHO_API int foho_vae_fwd(const foho_vae_desc* d, const void* x0, void* out, void* workspace, size_t workspace_bytes, void* saved, size_t saved_bytes,
+                          void* stream);
+/* grad_x0 = d sum(grad_out . out) / d x0 for the forward that filled `saved`. */
+FOHO_API int foho_vae_bwd(const foho_vae_desc* d, const void* grad_out, void* grad_x0, void* workspace, size_t workspace_bytes, const void* saved,
+                          size_t saved_bytes, void* stream);
 /* building blocks on their own (unit tests, profiling).  foho_geo_gemm: C (M,N) fp16 = epilogue(A (M,K) . Wt (N,K)^T + bias)
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
- * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles unless `gelu & 2` asks for the 128 x 128 kernel.
+ * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles (the phased, persistent kernel) unless `gelu & 2` asks
+ * for the 128 x 128 kernel or `gelu & 4` for the lock-step 256 x 256 one (arguments of THIS call: the library keeps no mode state).
  * foho_geo_attention: O (M, 64 heads) = softmax(Q K^T) V per head with Q (M, 64 heads) pre-scaled by log2(e) / 8, KV
  * (n_latents, 128 heads) = [K | V] as the projection leaves them, Vt_scratch room for 64 heads x n_latents fp16. */
-int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
+FOHO_API int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,
                   int32_t gelu, float scale, void* stream);
-int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
+FOHO_API int foho_geo_attention(const void* Q, const void* KV, void* Vt_scratch, void* O, int32_t M, int32_t n_latents, int32_t heads,
                        void* stream);
-const char* foho_geo_last_error(void);
+FOHO_API const char* foho_geo_last_error(void);
 
 #ifdef __cplusplus
 }

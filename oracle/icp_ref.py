@@ -2,9 +2,13 @@
 (src/foho/alignment/mesh_align.py; ICP below) and of the trimesh / scipy pieces it calls
 (trimesh.registration.procrustes, Trimesh.centroid / .scale, transformations).
 
-PARITY UNPINNED for trimesh internals (not installed here); `sample_surface_even` is additionally unseeded in
-the reference (ICP:79, ICP:85), so parity is defined on the deterministic part: given the sampled source and
-target point sets, the sequence of transforms is reproduced exactly.
+PINNED for the loop itself: tests/golden/ref_icp.npz holds what the REFERENCE's own `icp()` / `compute_init_transform` (imported from
+/root/reference by tests/golden/make_icp_golden.py, with scipy's real cKDTree) return on seeded point clouds -- identity, reflection and
+rotation starts, trimmed and untrimmed, clipped scale, on_surface -- and tests/test_icp_golden.py holds `icp` / `icp_points` below to it
+at 1e-9.  PARITY UNPINNED for trimesh's internals (not installed here: procrustes, closest_point, transformations are restated from
+their published algorithms and bound into the reference for that run); `sample_surface_even` is additionally unseeded in the reference
+(ICP:79, ICP:85), so parity is defined on the deterministic part: given the sampled source and target point sets, the sequence of
+transforms is reproduced.
 """
 import numpy as np
 
@@ -25,6 +29,34 @@ def scale_matrix(factor, origin):
 
 def transform_points(p, M):
     return p @ M[:3, :3].T + M[:3, 3]
+
+
+def rotation_matrix(angle, axis):
+    """trimesh.transformations.rotation_matrix(angle, direction) (Gohlke's transformations.py): cos I + (1 - cos) d d^T + sin [d]x."""
+    d = np.asarray(axis, np.float64)[:3]
+    d = d / np.linalg.norm(d)
+    c, s_ = np.cos(angle), np.sin(angle)
+    R = np.diag([c, c, c]) + np.outer(d, d) * (1.0 - c)
+    R = R + s_ * np.array([[0.0, -d[2], d[1]], [d[2], 0.0, -d[0]], [-d[1], d[0], 0.0]])
+    M = np.eye(4)
+    M[:3, :3] = R
+    return M
+
+
+def axis_aligned_rotations():
+    """ICP:37-44: +-90 and 180 degrees about each axis."""
+    out = []
+    for coord in range(3):
+        axis = np.zeros(3)
+        axis[coord] = 1
+        for angle in (-np.pi / 2, np.pi, np.pi / 2):
+            out.append(rotation_matrix(angle, axis))
+    return out
+
+
+def axis_aligned_reflections():
+    """ICP:46-54."""
+    return [np.eye(4) * np.append(d, 1) for d in ([1, 1, -1], [1, -1, 1], [-1, 1, 1], [-1, -1, 1], [-1, 1, -1], [1, -1, -1], [-1, -1, -1])]
 
 
 def mesh_centroid_scale(verts, faces=None):
@@ -71,11 +103,17 @@ def procrustes(a, b, reflection=True, scale=True):
     return M
 
 
-def nearest(p, q):
-    """Brute-force stand-in for scipy cKDTree(q).query(p): (distance, index), ties -> lowest index."""
-    d2 = ((p[:, None, :] - q[None, :, :]) ** 2).sum(-1)
-    idx = d2.argmin(1)
-    return np.sqrt(d2[np.arange(len(p)), idx]), idx
+def nearest(p, q, chunk=512):
+    """Brute-force stand-in for scipy cKDTree(q).query(p): (distance, index), ties -> lowest index.  (Row blocks of `chunk` points: the
+    same numbers as one (N, M, 3) array, without its memory.)"""
+    dist, idx = np.zeros(len(p)), np.zeros(len(p), np.int64)
+    for s0 in range(0, len(p), chunk):
+        pc = p[s0:s0 + chunk]
+        d2 = ((pc[:, None, :] - q[None, :, :]) ** 2).sum(-1)
+        i = d2.argmin(1)
+        idx[s0:s0 + chunk] = i
+        dist[s0:s0 + chunk] = np.sqrt(d2[np.arange(len(pc)), i])
+    return dist, idx
 
 
 def closest_point_on_triangles(tri, p):
@@ -126,16 +164,34 @@ def closest_point(verts, faces, p, chunk=256):
     return q, dist
 
 
+def icp(source_points, target_points, n_iter, test_reflections=False, test_rotations=False, fixed_scale=False, outliers=0.0, min_scale=0.5,
+        max_scale=2.0, target_faces=None, record=None):
+    """ICP:56-175 on already-sampled point sets (point-cloud inputs: ICP:76-77, 82-83), all start transforms: every 'cube' runs the loop of
+    `icp_points` from transform = cube (ICP:92), the first strictly lowest best cost wins (ICP:147-151).  -> (best transform, best cost)."""
+    cubes = [np.eye(4)]
+    if test_reflections:
+        cubes += axis_aligned_reflections()
+    if test_rotations:
+        cubes += axis_aligned_rotations()
+    best_T, best_cost = np.eye(4), np.inf
+    for cube in cubes:
+        T, cost = icp_points(source_points, target_points, n_iter, outliers=outliers, fixed_scale=fixed_scale, min_scale=min_scale,
+                             max_scale=max_scale, record=record, target_faces=target_faces, start=cube)
+        if cost < best_cost:
+            best_cost, best_T = cost, T
+    return best_T, best_cost
+
+
 def icp_points(source_points, target_points, n_iter, outliers=0.0, fixed_scale=False, min_scale=0.5, max_scale=2.0,
-               record=None, target_faces=None):
-    """ICP:91-142 for one 'cube' (identity start), on already-sampled point sets.
+               record=None, target_faces=None, start=None):
+    """ICP:91-142 for one 'cube' (`start`, default the identity), on already-sampled point sets.
     Returns (best_transform, best_cost) with the reference's bookkeeping: the cost of an iteration is measured
     BEFORE that iteration's update while `best_transform` stores the transform AFTER it (ICP:129, ICP:140-142).
     target_faces given = on_surface (ICP:106-107): `target_points` are the target mesh's vertices."""
     src = np.asarray(source_points, np.float64)
     tgt = np.asarray(target_points, np.float64)
     n_out = int(outliers * len(src))
-    transform = np.eye(4)
+    transform = np.eye(4) if start is None else np.asarray(start, np.float64)
     best_cost, best_transform = np.inf, transform.copy()
     for _ in range(n_iter):
         p = transform_points(src, transform)

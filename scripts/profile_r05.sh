@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b1 -- 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b8 -- $B1 --images-per-gpu 8 --streams 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c1 -- python $R/scripts/run_steps.py --crop hoi --steps 300 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c8 -- python $R/scripts/run_steps.py --crop hoi --images 8 --streams 1 --steps 100 > /dev/null 2>&1
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_geo -- python $R/scripts/dev_geo_trace.py > $O/geo_trace_run.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_geo -- python $R/scripts/dev/dev_geo_trace.py > $O/geo_trace_run.log 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_geod -- python $R/scripts/geo_bench.py --fb > /dev/null 2>&1
 for t in b1 b8; do
   X=""; [ $t = b8 ] && X="--images-per-gpu 8 --streams 1"
@@ -29,7 +29,7 @@ for t in b1 b8; do
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $O/d_sqb_$t -- $NG $X > /dev/null 2>&1
 done
 # the geometry decoder: matrix-core busy cycles, VALU / LDS instruction mix, waits
-GB="python $R/scripts/dev_geo_trace.py"   # HIP decoder only: five cached forwards, three forward + active-row backward pairs
+GB="python $R/scripts/dev/dev_geo_trace.py"   # HIP decoder only: five cached forwards, three forward + active-row backward pairs
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/d_geo1 -- $GB > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/d_geo2 -- $GB > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/d_geo3 -- $GB > /dev/null 2>&1

@@ -1,7 +1,7 @@
-"""profiles/rNN_sq_summary.md from the two SQ-counter summaries (scripts/dev_profile_rNN.sh): `python scripts/sq_summary.py r03`."""
+"""profiles/rNN_sq_summary.md from the two SQ-counter summaries (scripts/dev/dev_profile_rNN.sh): `python scripts/sq_summary.py r03`."""
 import csv, collections, sys
 RN = sys.argv[1] if len(sys.argv) > 1 else "r02"
-print(f"# SQ counters of the guidance step, round {RN[1:].lstrip('0')} (rocprofv3 --pmc, two passes, `scripts/profile_{RN}.sh` (round 3: `scripts/dev_profile_r03.sh`))\n")
+print(f"# SQ counters of the guidance step, round {RN[1:].lstrip('0')} (rocprofv3 --pmc, two passes, `scripts/profile_{RN}.sh` (round 3: `scripts/dev/dev_profile_r03.sh`))\n")
 print("`python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-graph [--images-per-gpu 8 --streams 1]`; means per launch.")
 print("dur = GRBM_GUI_ACTIVE / 8 XCDs at 2.4 GHz (inflated by the counter collection: 1.5-2x the un-profiled kernel time);")
 print("resident = SQ_WAVE_CYCLES x 4 / cycles (average waves in flight on the chip); wave life = SQ_WAVE_CYCLES x 4 / SQ_WAVES;")

@@ -223,7 +223,7 @@ def test_full_size_properties(obj_kind):
 def test_full_size_step_matches_the_oracle():
     """configs[1] itself -- 512x512, 778-vertex hand, 10 242-vertex / 20 480-face object, 65^3 grid -- one joint step against
     the CPU oracle: face ids, depth and edge distances bit-exact, losses 1e-4, parameter / vertex gradients 5e-4 (the
-    bound of the small scenes; measured 1e-5 here, scripts/dev_traj50.py)."""
+    bound of the small scenes; measured 1e-5 here, scripts/dev/dev_traj50.py)."""
     from followmyhold_amd import engine as E
     from oracle import clib
     import os

@@ -430,7 +430,7 @@ def test_config1_fifty_steps_track_the_oracle():
     makes single silhouette pixels contribute gradients of 1e5 and BCE jumps of 84; Adam with eps = 1e-4 amplifies
     rounding noise to learning-rate-sized steps) -- two runs of the CPU oracle itself on identical inputs (different
     thread interleaving in torch's reductions) ended 50 steps at total losses of 14.6 and 37.3
-    (scripts/dev_traj50.py)."""
+    (scripts/dev/dev_traj50.py)."""
     from followmyhold_amd import engine as E
     _threads()
     sc = _scene("20k")

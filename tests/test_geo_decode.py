@@ -163,12 +163,12 @@ def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk)
     assert torch.equal(out, out2)
     # the forward folds ln_2 into fc1 and ln_post + output_proj into fc2's epilogue; the chain with LayerNorm KERNELS (what the
     # backward routes recompute) gives the same logits up to one fp16 rounding of an intermediate, and is as close to torch
-    os.environ["FOHO_GEO_LNFUSE"] = "0"
+    hip.ln_fuse = False
     try:
         out_ln = hip(q.float(), lat)
         torch.cuda.synchronize()
     finally:
-        del os.environ["FOHO_GEO_LNFUSE"]
+        hip.ln_fuse = True
     scale = max(learned.abs().max().item(), 1.0) * dec.gain
     assert not torch.equal(out, out_ln) or width < 0          # (they are different computations)
     # (the second term: the result is handed back in fp16, the analytic prior included)
@@ -213,11 +213,11 @@ def test_folded_layernorms_do_not_cancel_on_rows_with_a_large_common_offset():
     q = (torch.rand(1, 4000, 3, generator=g) * 2.2 - 1.1).half().cuda()
     hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)
     out = hip(q.float(), lat).float()
-    os.environ["FOHO_GEO_LNFUSE"] = "0"
+    hip.ln_fuse = False
     try:
         out_ln = hip(q.float(), lat).float()
     finally:
-        del os.environ["FOHO_GEO_LNFUSE"]
+        hip.ln_fuse = True
     with torch.no_grad():
         q32 = q.float()
         emb = (q32[..., None] * dec.freqs).flatten(-2)
@@ -268,11 +268,11 @@ def test_decoder_backward_against_torch_autograd(width, heads, n_lat, n_q, chunk
     out_k, saved = hip.decode_keep(q.float())
     # (the keeping forward is another instantiation of the GEMM epilogue: where the compiler folds "times scale, to fp16" into
     # one v_fma_mixlo_f16 it rounds once, elsewhere twice -- a handful of logits differ in the last fp16 bit of an activation)
-    os.environ["FOHO_GEO_LNFUSE"] = "0"          # ... against the plain forward in the same form (LayerNorm kernels) ...
+    hip.ln_fuse = False          # ... against the plain forward in the same form (LayerNorm kernels) ...
     try:
         out_plain = hip.decode(q.float())
     finally:
-        del os.environ["FOHO_GEO_LNFUSE"]
+        hip.ln_fuse = True
     assert (out_k - out_plain).abs().max().item() <= 1e-3 * dec.gain
     # ... and against the forward the loop runs (LayerNorms folded into the GEMMs: another rounding of one intermediate)
     assert (out_k - hip.decode(q.float())).abs().max().item() <= 2e-3 * dec.gain * 8

@@ -231,7 +231,7 @@ def _tame(cfg, a, b, c):
     """A short schedule with learning rates 1/500 of the reference's: at its own settings (quaternion learning rate 0.5
     with eps 1e-4, CFG:21-26) the reference's optimisation is chaotic -- the 1e-7 noise of atomic float sums decides single
     Adam steps -- and two runs of the SAME code on the same inputs part ways within a few iterations.
-    (scripts/dev_determinism.py: at the reference's rates a fresh runner and the exact-size driver end 4 + 2 + 9 x 2
+    (scripts/dev/dev_determinism.py: at the reference's rates a fresh runner and the exact-size driver end 4 + 2 + 9 x 2
     iterations 4e-2 m apart, at a fiftieth of them 1.6e-4 m).  Tests that compare two executions of a schedule (batched
     against one by one, slot re-use against a fresh slot) run it where the trajectory is a function of the inputs."""
     cfg.optimization_steps_hand, cfg.optimization_steps_scale, cfg.optimization_steps_joint = a, b, c

@@ -331,13 +331,13 @@ def test_f16_run_hunyuan_w_guid_matches_the_reference(tmp_path, monkeypatch):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only mounted in the build container")
 def test_golden_files_regenerate_from_the_reference(tmp_path):
-    """Provenance of tests/golden/: both generator scripts, run again on /root/reference, reproduce the committed files --
-    the helper vectors bit for bit, the pipeline trajectory (a float32 optimisation on all host cores) to 1e-5."""
+    """Provenance of tests/golden/: the three generator scripts, run again on /root/reference, reproduce the committed files --
+    the helper vectors and the ICP results bit for bit, the pipeline trajectory (a float32 optimisation on all host cores) to 1e-5."""
     import subprocess
     import sys
     gdir = os.path.join(HERE, "golden")
     env = dict(os.environ, OMP_NUM_THREADS="8")
-    for script in ("make_golden.py", "make_pipeline_golden.py"):
+    for script in ("make_golden.py", "make_pipeline_golden.py", "make_icp_golden.py"):
         r = subprocess.run([sys.executable, os.path.join(gdir, script), str(tmp_path)], capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
     new = np.load(str(tmp_path / "ref_helpers.npz"))
@@ -345,6 +345,11 @@ def test_golden_files_regenerate_from_the_reference(tmp_path):
     for k in G.files:
         assert np.array_equal(new[k], G[k], equal_nan=True), k
     assert json.load(open(tmp_path / "ref_meta.json")) == META
+    # the reference's icp() on the seeded point clouds (float64, scipy's kd-tree): bit for bit
+    old_i, new_i = np.load(os.path.join(gdir, "ref_icp.npz")), np.load(str(tmp_path / "ref_icp.npz"))
+    assert sorted(old_i.files) == sorted(new_i.files)
+    for k in old_i.files:
+        assert np.array_equal(new_i[k], old_i[k]), k
     for tag in ("", "_v1"):
         old_p, new_p = np.load(os.path.join(gdir, f"ref_pipeline{tag}.npz")), np.load(str(tmp_path / f"ref_pipeline{tag}.npz"))
         assert sorted(old_p.files) == sorted(new_p.files)
