@@ -31,7 +31,7 @@ class FohoVaeLayer(ctypes.Structure):
 class FohoVaeDesc(ctypes.Structure):
     """include/foho_hip.h: foho_vae_desc"""
     _fields_ = [("width", L.c_i), ("heads", L.c_i), ("hidden", L.c_i), ("n_layers", L.c_i), ("n_tokens", L.c_i), ("batch", L.c_i),
-                ("layers", ctypes.POINTER(FohoVaeLayer)), ("zeros", L.vp)]
+                ("layers", ctypes.POINTER(FohoVaeLayer)), ("zeros", L.vp), ("flags", L.c_i), ("reserved", L.c_i)]
 
 
 def _f32(t, dev):
@@ -146,6 +146,7 @@ class HipVaeTransformer:
             fn.restype = ctypes.c_size_t
             fn.argtypes = [ctypes.POINTER(FohoVaeDesc)]
         self.lib.foho_geo_last_error.restype = ctypes.c_char_p
+        self.flags = 0                    # foho_vae_desc.flags (A/B switches; 0 = the product path)
         self.calls = 0                    # forwards served (pipeline diagnostics: was the HIP route taken?)
         d = self._desc(1, 128)
         if int(self.lib.foho_vae_workspace_bytes(ctypes.byref(d))) == 0:
@@ -160,6 +161,7 @@ class HipVaeTransformer:
         d.width, d.heads, d.hidden, d.n_layers, d.n_tokens, d.batch = self.width, self.heads, self.hidden, len(self.layers), tokens, batch
         d.layers = ctypes.cast(self.layers, ctypes.POINTER(FohoVaeLayer))
         d.zeros = self.zeros.data_ptr()
+        d.flags = self.flags
         return d
 
     def accepts(self, x):

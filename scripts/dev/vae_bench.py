@@ -75,12 +75,12 @@ if a.gemms:
     lib = L.lib()
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for M in (3072, 12288):
+    for M in (3072, 6144, 12288):
         for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (1024, 3072)):
             A = torch.randn(M, K, device=dev).half(); W = torch.randn(N, K, device=dev).half() * 0.03
             b = torch.zeros(N, device=dev); C = torch.empty(M, N, device=dev).half()
             res = []
-            for name, flag in (("auto", 0), ("128", 2), ("lockstep256", 4)):
+            for name, flag in (("auto", 0), ("128", 2), ("deep128", 8), ("deep128s", 32), ("phased256", 16)):
                 t = timed(lambda: lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, flag, ctypes.c_float(1.0), st), reps=20)
                 res.append(f"{name} {t * 1e3:.1f} us ({2 * M * N * K / t / 1e9:.0f} TF)")
             t = timed(lambda: torch.nn.functional.linear(A, W), reps=20)
