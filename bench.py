@@ -29,6 +29,7 @@ record -- everything below -- goes to stderr as one line prefixed `bench-detail:
   driver_on_files     foho.guidance.run.run() on scene folders in the reference's file formats, wall time per image
   topology_changing   the step as the real pipeline sees it: a new FlexiCubes mesh (new topology) every iteration
   geo_decode          the ShapeVAE geometry decoder of latent2sdf (65^3 queries x 3072 tokens) on the matrix cores vs torch
+  vae_transformer     `vae(pred)` of latent2sdf (16 layers x 3072 tokens) forward + backward: foho_vae_fwd/_bwd against the torch module
   pipeline_iteration  one inner iteration of the real pipeline (VAE transformer -> geometry decoder -> FlexiCubes -> step -> backward)
                       with Hunyuan-shaped stand-in networks: torch decoder vs the HIP decoder
 """
@@ -487,6 +488,7 @@ def main():
                             ("obj_40k", lambda: obj40k_record(E, torch, synthetic, render_fn, args, dev, cfg)),
                             ("geo_decode", lambda: geo_decode_record(torch, dev)),
                             ("vae_attention", lambda: vae_attention_record(torch, dev)),
+                            ("vae_transformer", lambda: vae_transformer_record(torch, dev)),
                             ("icp", lambda: icp_record(torch, np, dev)),
                             ("lbs", lambda: lbs_record(torch, np, synthetic, dev)),
                             ("pipeline_iteration", lambda: pipeline_iteration_record(E, torch, scenes[0], dev)),
@@ -541,10 +543,20 @@ def headline(out):
             sec["geo_decode"] = {"fwd_ms": _r(g["fwd_ms"]), "mfma_frac": _r(get(g, "roofline", "frac"), 3), "fwd_bwd_rows_ms": _r(g.get("fwd_bwd_rows_ms")),
                                  "fwd_bwd_dense_ms": _r(g.get("fwd_bwd_ms"))}
         pi = out.get("pipeline_iteration") or {}
-        if "hip_decoder" in pi:
-            sec["pipeline_iteration"] = {"ms": _r(get(pi, "hip_decoder", "iteration_ms")), "bwd_ms": _r(get(pi, "hip_decoder", "backward_ms")),
-                                         "torch_ms": _r(get(pi, "torch_decoder", "iteration_ms")), "active_rows": _r(pi.get("active_row_frac"), 3),
-                                         "b4_ms": _r(get(pi, "batch_of_4", "iteration_ms"))}
+        if "hip_transformer" in pi:
+            sec["pipeline_iteration"] = {"ms": _r(get(pi, "hip_transformer", "iteration_ms")), "bwd_ms": _r(get(pi, "hip_transformer", "backward_ms")),
+                                         "torch_vae_ms": _r(get(pi, "hip_decoder", "iteration_ms")), "torch_ms": _r(get(pi, "torch_decoder", "iteration_ms")),
+                                         "active_rows": _r(pi.get("active_row_frac"), 3), "b4_ms": _r(get(pi, "batch_of_4", "iteration_ms"))}
+        vt = out.get("vae_transformer") or {}
+        if "fwd_ms" in vt:
+            sec["vae_transformer"] = {k: _r(vt.get(k), 3) for k in ("fwd_ms", "bwd_ms", "mfma_frac", "torch_fwd_bwd_ms", "b4_fwd_bwd_ms")}
+        fd0 = out.get("final_decode") or {}
+        if "hip_transformer" in pi and "latent2sdf_ms" in fd0 and "phase_a_step_ms" in pi:
+            # what ONE IMAGE costs on the path (CFG:12-18, PL:1269-1662; stand-in networks; the DiT's 20 forwards are not part of it): 550 inner
+            # iterations through latent2sdf (100 of phase B + 9 x 50 of phase C), 200 of phase A, 19 no-gradient decodes on the 65^3 grid, the last
+            # decode on 385^3 -- every term measured in this run
+            sec["image_s"] = _r((550 * pi["hip_transformer"]["iteration_ms"] + 200 * pi["phase_a_step_ms"] + 19 * pi["step_decode_nograd_ms"]
+                                 + fd0["latent2sdf_ms"] + fd0["flexicubes_ms"]) / 1e3, 4)
         cu = out.get("closeup") or {}
         if "one_image" in cu:
             sec["closeup"] = {"b1": _r(get(cu, "one_image", "value")), "b32": _r(get(cu, "in_flight_32", "value"))}
@@ -571,7 +583,7 @@ def headline(out):
         lb = out.get("lbs") or {}
         if "b8192" in lb:
             sec["lbs"] = {"b1_us": _r(get(lb, "b1", "fwd_bwd_us")), "b8192_frac": _r(get(lb, "b8192", "poseblend_frac_of_fp32_matrix_peak"), 3)}
-        for k in ("geo_decode", "pipeline_iteration", "final_decode", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs", "vae_attention"):
+        for k in ("geo_decode", "vae_transformer", "pipeline_iteration", "final_decode", "closeup", "batched", "obj_40k", "topology_changing", "job", "driver_on_files", "icp", "lbs", "vae_attention"):
             if isinstance(out.get(k), dict) and "error" in out[k]:
                 sec[k] = {"error": out[k]["error"][:60]}
         if sec:
@@ -954,9 +966,12 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     lat = torch.randn(1, 3072, 64, device=dev, dtype=torch.float16)
     gsz = (res + 1, res + 1, res + 1)
     out, sdfs = {}, {}
-    for name in ("torch_decoder", "hip_decoder"):
+    for name in ("torch_decoder", "hip_decoder", "hip_transformer"):
         if name == "hip_decoder":
             geo_decode.install(vae, device=dev)
+        if name == "hip_transformer":      # ... and `vae(pred)` itself (PL:295) on foho_vae_fwd / foho_vae_bwd: the product's default route
+            from followmyhold_amd import vae_transformer
+            vae_transformer.install(vae, device=dev)
         noise = torch.zeros_like(lat).requires_grad_(True)
         def one():
             if noise.grad is not None:
@@ -967,7 +982,7 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
             torch.cuda.synchronize(dev); t["latent2sdf_fwd_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
             sdfs[name] = sdf.detach()
             loss = obj(sdf.reshape(1, -1), cfg)
-            if name == "hip_decoder":      # what the pipeline does at its per-iteration read-back: the exact count of rows with a gradient
+            if name != "torch_decoder":    # what the pipeline does at its per-iteration read-back: the exact count of rows with a gradient
                 PLN._bound_active_rows(vae, obj.active_rows()[0])
             torch.cuda.synchronize(dev); t["flexicubes_step_ms"] = (time.perf_counter() - a) * 1e3; a = time.perf_counter()
             loss.sum().backward()
@@ -992,8 +1007,7 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         def one4():
             noise4.grad = None
             torch.cuda.synchronize(dev); a = time.perf_counter()
-            with PLN.vae_attention_backend():
-                pred = vae((1 / vae.scale_factor) * (lat4 + 0.1 * noise4))
+            pred = PLN.vae_tokens(vae, (1 / vae.scale_factor) * (lat4 + 0.1 * noise4))
             sdf4 = torch.stack([-hip(hip.grid_queries(xyz), pred[b:b + 1]).view(-1).float() for b in range(B4)], 0)
             loss = obj4(sdf4, cfg)
             gb4.flags.cpu()
@@ -1003,11 +1017,33 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
             return (time.perf_counter() - a) * 1e3
         one4(); one4()
         t4 = float(np.median([one4() for _ in range(iters)]))
-        out["batch_of_4"] = {"iteration_ms": t4, "ms_per_image": t4 / B4, "vs_one_image": t4 / out["hip_decoder"]["iteration_ms"],
+        out["batch_of_4"] = {"iteration_ms": t4, "ms_per_image": t4 / B4, "vs_one_image": t4 / out["hip_transformer"]["iteration_ms"],
                              "grad_finite": bool(torch.isfinite(noise4.grad).all())}
         del gb4, obj4
     except Exception as e:  # noqa: BLE001
         out["batch_of_4"] = {"error": f"{type(e).__name__}: {e}"}
+    # the decode WITHOUT gradients that closes every denoising step (PL:1613-1641: 19 of the 20 on the 65^3 grid, the last one on 385^3 --
+    # `final_decode`): latent -> transformer -> decoder -> FlexiCubes, and one iteration of phase A (hand only, PL:1320-1358: no decode)
+    from followmyhold_amd import ops
+    def nograd():
+        with torch.no_grad():
+            sdf = PLN.latent2sdf(lat, xyz, gsz, vae, dev)
+            ops.flexicubes(xyz, sdf[0].flatten(), res)
+    nograd(); nograd()
+    torch.cuda.synchronize(dev); a = time.perf_counter()
+    for _ in range(3):
+        nograd()
+    torch.cuda.synchronize(dev)
+    out["step_decode_nograd_ms"] = (time.perf_counter() - a) * 1e3 / 3
+    cfgA, _ = E.phase_cfg("A", denoise_i=9, do_update=True)
+    gbA = E.GuidanceBatch([scene], device=dev)
+    gA = gbA.capture(cfgA, steps_per_graph=50)
+    gA.replay(); torch.cuda.synchronize(dev); a = time.perf_counter()
+    for _ in range(4):
+        gA.replay()
+    torch.cuda.synchronize(dev)
+    out["phase_a_step_ms"] = (time.perf_counter() - a) * 1e3 / 200
+    del gA, gbA
     nv, nf, flags = obj.status()[0]
     st_rows = vae.hip_geo.last_row_stats
     if st_rows is not None:
@@ -1017,10 +1053,68 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
     out["faces"] = nf
     out["sdf_max_abs_diff_between_decoders"] = float((sdfs["torch_decoder"] - sdfs["hip_decoder"]).abs().max())
     out["sdf_abs_max"] = float(sdfs["torch_decoder"].abs().max())
-    out["speedup"] = out["torch_decoder"]["iteration_ms"] / out["hip_decoder"]["iteration_ms"]
-    out["what"] = ("latent -> 16-layer VAE transformer (torch) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
+    out["speedup"] = out["torch_decoder"]["iteration_ms"] / out["hip_transformer"]["iteration_ms"]
+    out["sdf_max_abs_diff_hip_transformer"] = float((sdfs["hip_decoder"] - sdfs["hip_transformer"]).abs().max())
+    out["vae_transformer_calls"] = vae.hip_transformer.calls
+    out["what"] = ("latent -> 16-layer VAE transformer (torch_decoder / hip_decoder: torch; hip_transformer: foho_vae_fwd/_bwd) -> geometry decoder on 65^3 points -> FlexiCubes -> object install -> fused joint "
                    "step -> backward to the noise prediction; stand-in networks of the Hunyuan3D-2 shape, fp16")
     return out
+
+
+def vae_transformer_record(torch, dev, reps=10):
+    """`pred = vae(pred)` of latent2sdf (PL:295) at the Hunyuan3D-2 shape -- 3072 tokens x 1024, 16 heads of 64, hidden 4096, sixteen layers,
+    qk_norm, hy3dgen's module layout (standins.Hy3dgenLayoutShapeVAE) -- forward and backward to the tokens, run in every one of the 550 inner
+    iterations per image (PL:1391-1393, 1507-1509): foho_vae_fwd / foho_vae_bwd (followmyhold_amd.vae_transformer) against the torch module
+    under `pipeline.vae_attention_backend()` (fp16, this package's attention forward, torch's memory-efficient backward: round 5's route).
+    mfma_frac: 1.86 TFLOP forward + 2.78 TFLOP backward (dX only: GEMMs 2 x 77 GFLOP, attention 39 + 97 GFLOP per layer) / time / the
+    2.5 PFLOP/s dense fp16 matrix peak."""
+    from followmyhold_amd import pipeline as PLN, standins, vae_transformer
+    torch.manual_seed(0)
+    vae = standins.Hy3dgenLayoutShapeVAE().to(dev).half().eval().requires_grad_(False)
+    tr = vae_transformer.HipVaeTransformer.from_module(vae, device=dev)
+    L_, W_, F_, nl = 3072, 1024, 4096, 16
+    flop_f = nl * (2 * L_ * W_ * (3 * W_ + W_ + 2 * F_) + 4 * L_ * L_ * W_)
+    flop_b = nl * (2 * L_ * W_ * (3 * W_ + W_ + 2 * F_) + 10 * L_ * L_ * W_)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+    rec = {"shape": "3072 tokens x 1024, 16 heads, hidden 4096, 16 layers, qk_norm", "flop_fwd": flop_f, "flop_bwd": flop_b}
+    for B in (1, 4):
+        lat = torch.randn(B, L_, 64, device=dev, dtype=torch.float16)
+        x0 = vae.post_kl(lat).detach()
+        go = torch.randn_like(x0)
+        saved = [None]
+
+        def f_keep():
+            saved[0] = tr.forward_raw(x0, keep=True)[1]
+
+        def f_b():
+            tr.backward_raw(go, tr.forward_raw(x0, keep=True)[1], tuple(x0.shape))
+
+        def t_fb():
+            l = lat.clone().requires_grad_(True)
+            with PLN.vae_attention_backend():
+                vae(l).backward(go)
+        t_f, t_fb_ = timed(f_keep), timed(f_b)
+        t_t = timed(t_fb)
+        k = "" if B == 1 else f"b{B}_"
+        rec.update({f"{k}fwd_ms": t_f, f"{k}bwd_ms": t_fb_ - t_f, f"{k}fwd_bwd_ms": t_fb_, f"{k}torch_fwd_bwd_ms": t_t,
+                    f"{k}mfma_frac": B * (flop_f + flop_b) / (t_fb_ * 1e-3) / 2.5e15, f"{k}tflops": B * (flop_f + flop_b) / (t_fb_ * 1e-3) / 1e12})
+        if B == 1:
+            with torch.no_grad(), PLN.vae_attention_backend():
+                ref = vae(lat)
+            got = tr(x0)
+            rec["max_rel_diff_vs_torch_fp16"] = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
+    return rec
 
 
 def final_decode_record(torch, np, dev):
@@ -1112,6 +1206,21 @@ def vae_attention_record(torch, dev):
             rec[name] = {"forward_us": timed(fwd), "forward_backward_us": timed(fb)}
         except Exception as e:  # noqa: BLE001
             rec[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    # ... and a batch of four (call_batch's transformer pass): which backward should follow the HIP forward?
+    base4 = [torch.randn(4, 3072, 16, 64, device=dev, dtype=torch.float16, requires_grad=True) for _ in range(3)]
+    q4, k4, v4 = (t.transpose(1, 2) for t in base4)
+    go4 = torch.randn(4, 3072, 16, 64, device=dev, dtype=torch.float16).transpose(1, 2)
+    rec["b4"] = {}
+    for name, route in (("hip", "torch"), ("hip_bwd", "hip")):
+        def fb4():
+            for t in base4:
+                t.grad = None
+            sdpa.backward_route = route
+            sdpa.attention(q4, k4, v4).backward(go4)
+        try:
+            rec["b4"][name] = {"forward_backward_us": timed(fb4, n=10)}
+        except Exception as e:  # noqa: BLE001
+            rec["b4"][name] = {"error": f"{type(e).__name__}: {e}"[:200]}
     sdpa.backward_route = saved_route
     rec["hip_backward_by_torch_refused"] = bool(sdpa._torch_route_refused)
     with torch.no_grad():

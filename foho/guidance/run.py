@@ -240,9 +240,11 @@ def _build_pipeline(device):
                            "to run the full guided pipeline on random-initialised stand-ins, FOHO_MESH_LEVEL_GUIDANCE=1 "
                            "to run phases A/B/C on the fixed Hunyuan mesh, or use followmyhold_amd.pipeline / "
                            "followmyhold_amd.engine directly.") from e
-    # FOHO_HIP_GEO_DECODER=0 keeps the ShapeVAE's geometry decoder on its torch module (default: foho_geo_decode_fwd / _bwd)
+    # FOHO_HIP_GEO_DECODER=0 keeps the ShapeVAE's geometry decoder on its torch module (default: foho_geo_decode_fwd / _bwd),
+    # FOHO_HIP_VAE_TRANSFORMER=0 its transformer (default: foho_vae_fwd / _bwd)
     _PIPELINE = GuidedShapePipeline.from_hy3dgen(Hunyuan3DDiTFlowMatchingPipeline.from_pretrained("tencent/Hunyuan3D-2"),
-                                                 hip_geo_decoder=os.environ.get("FOHO_HIP_GEO_DECODER", "1") != "0")
+                                                 hip_geo_decoder=os.environ.get("FOHO_HIP_GEO_DECODER", "1") != "0",
+                                                 hip_vae_transformer=os.environ.get("FOHO_HIP_VAE_TRANSFORMER", "1") != "0")
     return _PIPELINE
 
 

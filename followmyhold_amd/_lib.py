@@ -68,7 +68,7 @@ LOSS_NAMES = ["total", "intersection", "contact", "kps", "trans_hand", "trans_ob
 WS_REGIONS = ["world", "ndc", "vn", "p2f", "zbuf", "sdist", "prod", "knn_idx", "knn_d2", "gworld", "frac_count",
               "stats", "parity", "frag_count", "seg_count", "hand_order"]
 N_KERNELS = 10
-ABI_VERSION = 104     # 104 = foho_geo_weights.ln_{q,kv,2}_eps, foho_geo_decode_bwd_rows, foho_geo_prepare_queries / _decode_fwd_cached; include/foho_hip.h: 102 = foho_step_cfg.listed_cap, foho_step_desc.hand_order_valid, foho_abi_sizes; 103 = foho_geo_weights.q_norm / k_norm, foho_geo_abi_size
+ABI_VERSION = 105     # 105 = foho_vae_fwd / _bwd, foho_geo_weights.flags, foho_geo_gemm variant bits, FOHO_API visibility; 104 = foho_geo_weights.ln_{q,kv,2}_eps, foho_geo_decode_bwd_rows, foho_geo_prepare_queries / _decode_fwd_cached; include/foho_hip.h: 102 = foho_step_cfg.listed_cap, foho_step_desc.hand_order_valid, foho_abi_sizes; 103 = foho_geo_weights.q_norm / k_norm, foho_geo_abi_size
 
 
 def build(force=False):

@@ -143,6 +143,7 @@ class HipGeoDecoder:
         self.backward_mode = "rows"
         self.row_cap = None               # upper bound on the active rows a caller can vouch for (None: all rows -- cannot overflow)
         self.last_row_stats = None        # device int32[2] of the last "rows" backward: active rows, rows dropped for lack of capacity
+        self.rows_dropped_total = None    # device int32[1]: rows dropped by ALL "rows" backwards since the last take_rows_dropped()
         self.query_cache_limit = 4 << 30  # bytes: grids whose cached query side (4 KB per point at width 1024) fits are cached
         self._qcache = None               # (weakref to the query tensor, its version, shape, cache buffer)
         self._prepared = None
@@ -287,7 +288,18 @@ class HipGeoDecoder:
                                                       L.vp(self._rows_ws.data_ptr()), ctypes.c_size_t(self._rows_ws.numel()), L.vp(stats.data_ptr()),
                                                       L.vp(stream)), "foho_geo_decode_bwd_rows")
         self.last_row_stats = stats
+        if self.rows_dropped_total is None:
+            self.rows_dropped_total = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.rows_dropped_total += stats[1:2]      # (on the device: no synchronisation; every backward of a phase counts, not only the last)
         return out
+
+    def take_rows_dropped(self):
+        """Rows dropped for lack of `row_cap` by all "rows" backwards since the last call (one read-back), and reset."""
+        if self.rows_dropped_total is None:
+            return 0
+        n = int(self.rows_dropped_total.item())
+        self.rows_dropped_total.zero_()
+        return n
 
     def prepare_queries(self, queries):
         """Cache the latent-independent half of the chain (embedding -> query_proj -> ln_1 -> c_q) for this query tensor: decodes of the

@@ -40,17 +40,18 @@ def vae_attention_backend():
     3072 tokens, 64) fp16, sixteen layers, run and back-propagated in every inner iteration (PL:295, 1391-1393, 1507-1509) -- torch's
     scaled_dot_product_attention is a quarter of an iteration: forward + backward per layer on an MI355X 509-548 us with ROCm's default
     (flash, AOTriton) backend, 350 us with the memory-efficient one (139 forward, 212 backward: `vae_attention` bench record).
-    FOHO_VAE_SDPA selects:
-      hip (default)  the forward on this package's attention kernels (followmyhold_amd.sdpa: 68 us, operands read where the projections
-                     left them), the backward by torch's memory-efficient kernels from that forward's output and log-sum-exp -- the
-                     faster side of each pair, one image or a batch; calls the kernels do not take (a mask, another head size) and
-                     everything outside this context stay torch's, with the memory-efficient backend preferred;
-      hip_bwd        ... with the package's own backward kernels as well (level for one image, slower for a batch);
+    This is the FALLBACK route: with `vae_transformer.install(vae)` (what `from_hy3dgen` does) the whole transformer runs on foho_vae_fwd / _bwd
+    and no torch attention is called.  FOHO_VAE_SDPA selects, for a VAE that stays on its torch module:
+      hip (default)  forward AND backward on this package's attention kernels (followmyhold_amd.sdpa: 71 us forward, operands read where the
+                     projections left them; backward 190 us, dK / dV written directly); calls the kernels do not take (a mask, another head size)
+                     and everything outside this context stay torch's, with the memory-efficient backend preferred;
+      hip_torch_bwd  the HIP forward with torch's memory-efficient backward fed from it (a private torch operator: 181 us; round 5's default);
+      hip_bwd        = hip (the name of round 5);
       efficient      torch's memory-efficient backend first, the others allowed behind it;
       default        torch's own choice, as the reference runs."""
     import contextlib
     mode = os.environ.get("FOHO_VAE_SDPA", "hip")
-    if mode not in ("efficient", "hip", "hip_bwd") or not torch.cuda.is_available():
+    if mode not in ("efficient", "hip", "hip_bwd", "hip_torch_bwd") or not torch.cuda.is_available():
         return contextlib.nullcontext()
     stack = contextlib.ExitStack()
     try:
@@ -60,7 +61,7 @@ def vae_attention_backend():
         pass
     if mode != "efficient":
         from . import sdpa
-        stack.enter_context(sdpa.hip_sdpa(backward="hip" if mode == "hip_bwd" else "torch"))
+        stack.enter_context(sdpa.hip_sdpa(backward="torch" if mode == "hip_torch_bwd" else "hip"))
     return stack
 
 
@@ -110,11 +111,15 @@ def _bound_active_rows(vae, n_rows):
 
 
 def _check_rows_dropped(hip):
-    if hip is not None and hip.last_row_stats is not None:
-        n_act, dropped = hip.last_row_stats.tolist()
+    """End of a phase: did ANY backward of it (every iteration, every image of a batch) drop rows?  Also lifts the bound again -- `row_cap`
+    is state on the shared decoder, and a backward outside the loop (a dense gradient from user code) must not inherit the last
+    iteration's count."""
+    if hip is not None:
+        cap, hip.row_cap = hip.row_cap, None
+        dropped = hip.take_rows_dropped()
         if dropped:
-            raise E.L.FohoError(f"geometry decoder backward: {dropped} of {n_act} active rows exceeded row_cap = {hip.row_cap}: the gradient "
-                                "of this phase is incomplete (raise obj_capacity or set vae.hip_geo.row_cap = None)")
+            raise E.L.FohoError(f"geometry decoder backward: {dropped} active rows exceeded row_cap (last: {cap}) during this phase: its gradient "
+                                "is incomplete (raise obj_capacity or leave vae.hip_geo.row_cap = None)")
 
 
 def similarity_about_center(verts, scale, quat, trans):
@@ -156,11 +161,12 @@ class GuidedShapePipeline:
         self.to(device, dtype)
 
     @classmethod
-    def from_hy3dgen(cls, pipe, hip_geo_decoder=True):
+    def from_hy3dgen(cls, pipe, hip_geo_decoder=True, hip_vae_transformer=True):
         """Adopt the networks of an (unpatched) hy3dgen `Hunyuan3DDiTFlowMatchingPipeline` object.  The ShapeVAE's geometry
         decoder -- the 65^3-point decode and its backward inside every inner iteration, PL:292-313, 1391-1393, 1507-1509 -- is
-        taken over by the matrix-core kernels (`geo_decode.install`); a decoder outside the shapes they take raises `FohoError`
-        here, `hip_geo_decoder=False` keeps the torch module."""
+        taken over by the matrix-core kernels (`geo_decode.install`), and so is the transformer in front of it (`vae(pred)`, PL:295:
+        `vae_transformer.install`); a module outside the shapes / layouts they take raises `FohoError` here,
+        `hip_geo_decoder=False` / `hip_vae_transformer=False` keep the torch modules."""
         from .scheduler import FlowMatchEulerDiscreteScheduler
         sch = FlowMatchEulerDiscreteScheduler(num_train_timesteps=pipe.scheduler.config.num_train_timesteps,
                                               shift=getattr(pipe.scheduler.config, "shift", 1.0))
@@ -168,6 +174,9 @@ class GuidedShapePipeline:
         if hip_geo_decoder:
             from . import geo_decode
             geo_decode.install(self.vae, device=self.device)
+        if hip_vae_transformer:
+            from . import vae_transformer
+            vae_transformer.install(self.vae, device=self.device)
         return self
 
     def to(self, device=None, dtype=None):
@@ -308,6 +317,13 @@ class GuidedShapePipeline:
         LEAVE, EMPTY = 1 | 16 | 32, 64      # flag bits: NaN loss, capacity overflow, not a closed manifold | empty iso-surface
 
         def latent_phase(phase, iters, i, t, noise_pred, lr):
+            try:
+                return latent_phase_body(phase, iters, i, t, noise_pred, lr)
+            finally:          # however the phase ends (an exception included), the shared decoder's active-row bound does not outlive it
+                if hip_dec is not None:
+                    hip_dec.row_cap = None
+
+        def latent_phase_body(phase, iters, i, t, noise_pred, lr):
             cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
             gb.set_n_renders(n_renders)
             gb.reset_optimizer()
@@ -325,7 +341,7 @@ class GuidedShapePipeline:
                 fl = gb.flags.cpu().tolist()                            # the iteration's read-back (NaN is bit 0 of the flags) ...
                 if hip_dec is not None:                                 # ... with the rows the decoder's backward will find a gradient on
                     _bound_active_rows(self.vae, max(fobj.active_rows()))
-                go = torch.zeros(B, device=device)
+                go_host = [0.0] * B                                     # (host list, uploaded once: no per-image device synchronisation)
                 for b in range(B):
                     if b in left:
                         continue
@@ -338,12 +354,13 @@ class GuidedShapePipeline:
                         stats["skipped_empty"] += 1
                         gb.flags[b] &= ~EMPTY
                     else:
-                        go[b] = 1.0
+                        go_host[b] = 1.0
                 if len(left) == B:
                     break
+                go = torch.tensor(go_host, device=device)
                 (loss * go).sum().backward()         # _SdfObjectiveFn.backward returns exact zeros for go = 0 (also past a NaN)
                 for b in range(B):
-                    if go[b] == 0:
+                    if go_host[b] == 0:
                         noise[b].grad = None
                 opt.step()
                 stats["inner_iterations"] += 1
@@ -513,6 +530,14 @@ class GuidedShapePipeline:
                 getattr(dst, name).copy_(getattr(src, name))
 
         def latent_phase(phase, iters, i, t, noise_pred, lr, nan_returns_none):
+            try:
+                return latent_phase_body(phase, iters, i, t, noise_pred, lr, nan_returns_none)
+            finally:          # however the phase ends (a NaN return, an exception), the shared decoder's active-row bound does not outlive it
+                hip_ = getattr(self.vae, "hip_geo", None)
+                if hip_ is not None:
+                    hip_.row_cap = None
+
+        def latent_phase_body(phase, iters, i, t, noise_pred, lr, nan_returns_none):
             """Phases B / C (PL:1362-1453 / 1456-1601): `iters` iterations of decode -> fused step -> AdamW."""
             cfg, n_renders = E.phase_cfg(phase, cfg0, denoise_i=i, do_update=True)
             gb.set_n_renders(n_renders)

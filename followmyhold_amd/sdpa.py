@@ -50,8 +50,10 @@ def _workspace(lib, dev, M, Lk, H):
 
 def _in_place(q, k, v):
     """(B, H, N, 64) views whose memory the kernels can read directly: unit stride in d, 16-byte aligned strides, k and v laid out alike."""
-    def ok(t):
-        return t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) and t.data_ptr() % 16 == 0
+    def ok(t):      # (strides below 64 -- expand()ed views -- are refused by the C side: those operands are copied)
+        span = (t.shape[2] - 1) * t.stride(2) + (t.shape[1] - 1) * t.stride(1) + 64
+        return (t.stride(3) == 1 and all(st % 8 == 0 for st in t.stride()[:3]) and t.stride(1) >= 64 and t.stride(2) >= 64 and t.data_ptr() % 16 == 0
+                and span * 2 < 2 ** 31)
     return ok(q) and ok(k) and ok(v) and k.stride() == v.stride()
 
 
@@ -64,11 +66,14 @@ def _stream(t):
     return L.vp(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-# Which backward follows the HIP forward.  "torch": torch's own memory-efficient attention backward, fed with this forward's output and
-# log-sum-exp (aten::_scaled_dot_product_efficient_attention_backward -- measured level with the HIP backward for one image, 212 against
-# 219 us per layer at 16 x 3072 x 64, and ahead of it for a batch, which it takes in one launch); "hip": foho_sdpa_bwd (k_geo_attn_bwd +
-# k_geo_attn_dq).  If the private torch operator is missing or refuses the call, the HIP backward takes over for the rest of the process.
-backward_route = "torch"
+# Which backward follows the HIP forward.  "hip" (default): foho_sdpa_bwd -- k_geo_attn_bwd (dK / dV written directly, one workgroup per
+# (head, key block)) + k_geo_attn_dq: this package's own kernels, bitwise repeatable.  "torch" (opt-in, FOHO_VAE_SDPA=hip_torch_bwd): torch's
+# memory-efficient attention backward fed with this forward's output and log-sum-exp -- a PRIVATE operator
+# (aten::_scaled_dot_product_efficient_attention_backward) whose signature may change with a torch upgrade; measured 181 against 190 us per
+# layer at 16 x 3072 x 64 and 7 % ahead for a batch of four (it takes the batch in one launch).  If the operator is missing or refuses the
+# call, a warning is printed ONCE and the HIP backward takes over for the rest of the process.  (With `vae_transformer.install` -- the
+# product's default -- none of this runs: the whole transformer is foho_vae_fwd / _bwd.)
+backward_route = "hip"
 _torch_route_refused = False      # set by the first backward the torch operator refuses
 
 
@@ -116,7 +121,11 @@ class _HipSdpaFn(torch.autograd.Function):
                 gq, gk, gv, _ = _torch_backward_op()(g, q, k, v, None, out.view(B, M, H, 64).transpose(1, 2), ctx.saved_tensors[5], zero, zero, 0.0,
                                                      [True, True, True, False], False)
                 return gq, gk, gv
-            except (RuntimeError, TypeError):
+            except (RuntimeError, TypeError) as e:
+                if not _torch_route_refused:
+                    import warnings
+                    warnings.warn(f"followmyhold_amd.sdpa: torch's private attention backward refused the call ({type(e).__name__}: {e}); "
+                                  "the HIP backward (foho_sdpa_bwd) serves this process from here on")
                 _torch_route_refused = True        # this build's operator does not take the call: the HIP backward from here on
         Lk, W = k.shape[2], H * 64
         go = g.transpose(1, 2).reshape(B, M, W)
@@ -147,7 +156,21 @@ def eligible(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None
         return False
     if k.shape[2] % 128 or k.shape[2] < 128 or M < 1:
         return False
+    if not (torch.is_tensor(k) and torch.is_tensor(v) and k.is_cuda and v.is_cuda and k.device == q.device == v.device and k.dim() == 4 and v.dim() == 4):
+        return False
+    # the limits of sdpa_args (csrc/foho_geo.hip): operands within 32-bit buffer offsets; views with a zero / tiny stride (expand()) are
+    # copied by _HipSdpaFn.forward (not _in_place), which makes them (B, N, H, 64) contiguous -- that copy must fit, too
+    for t in (q, k):
+        if t.shape[1] * t.shape[2] * 64 * 2 >= 2 ** 31:
+            return False
     return scale is None or abs(float(scale) - 0.125) < 1e-12
+
+
+hits = 0          # eligible calls served by the HIP kernels through hip_sdpa() (diagnostics: was the patch reached at all?)
+# Modules that bind the function at import time (`scaled_dot_product_attention = nn.functional.scaled_dot_product_attention` at module
+# level -- what hy3dgen's attention_blocks.py / attention_processors.py are believed to do; the files are not in the reference tree) never
+# look F.scaled_dot_product_attention up again: hip_sdpa() rebinds these module-level names too, when the modules are importable.
+PATCH_MODULES = ("hy3dgen.shapegen.models.autoencoders.attention_blocks", "hy3dgen.shapegen.models.autoencoders.attention_processors")
 
 
 def attention(q, k, v):
@@ -171,13 +194,24 @@ def hip_sdpa(backward=None):
         backward_route = backward
 
     def dispatch(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        global hits
         if eligible(query, key, value, attn_mask, dropout_p, is_causal, scale, **kw):
+            hits += 1
             return _HipSdpaFn.apply(query, key, value)
         return orig(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale, **kw)
 
+    import sys
+    rebound = []          # (module, previous value) of the import-time bindings of the SAME function
+    for name in PATCH_MODULES:
+        mod = sys.modules.get(name)
+        if mod is not None and getattr(mod, "scaled_dot_product_attention", None) is orig:
+            rebound.append((mod, orig))
+            mod.scaled_dot_product_attention = dispatch
     F.scaled_dot_product_attention = dispatch
     try:
         yield
     finally:
         F.scaled_dot_product_attention = orig
+        for mod, prev in rebound:
+            mod.scaled_dot_product_attention = prev
         backward_route = saved_route

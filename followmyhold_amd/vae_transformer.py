@@ -165,8 +165,10 @@ class HipVaeTransformer:
         return d
 
     def accepts(self, x):
-        """Can this input go through the kernels?  (B, L, width) fp16 on the device, L a multiple of 128."""
-        return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16 and x.dim() == 3 and x.shape[2] == self.width
+        """Can this input go through the kernels?  (B, L, width) on the device, L a multiple of 128; fp16, or fp32 (a pipeline held in
+        float32: the tokens are rounded to fp16 on the way in -- the kernels' storage type, and the reference's own VAE dtype, PL:522 -- and
+        handed back as fp32, like HipGeoDecoder does with its latents)."""
+        return (torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.dim() == 3 and x.shape[2] == self.width
                 and x.shape[1] >= 128 and x.shape[1] % 128 == 0 and (self.device.index is None or x.device.index == self.device.index))
 
     def _workspace(self, d):
@@ -187,7 +189,7 @@ class HipVaeTransformer:
 
     def forward_raw(self, x, keep):
         """-> (out (B, L, width) fp16, saved or None)"""
-        if not self.accepts(x):
+        if not self.accepts(x) or x.dtype != torch.float16:
             raise L.FohoError("HipVaeTransformer: (B, L, width) fp16 tokens on the transformer's device, L a multiple of 128")
         x = x.contiguous()
         d = self._desc(x.shape[0], x.shape[1])
@@ -214,9 +216,10 @@ class HipVaeTransformer:
         return gx
 
     def __call__(self, x):
+        x16 = x if x.dtype == torch.float16 else x.to(torch.float16)
         if torch.is_grad_enabled() and x.requires_grad:
-            return _VaeFn.apply(x, self)
-        return self.forward_raw(x, keep=False)[0]
+            return _VaeFn.apply(x16, self).to(x.dtype)
+        return self.forward_raw(x16, keep=False)[0].to(x.dtype)
 
 
 class _VaeFn(torch.autograd.Function):

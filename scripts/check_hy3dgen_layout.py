@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Real-module readiness check of the HIP geometry decoder (run it once on a machine where Hunyuan3D-2 is installed).
+"""Real-module readiness check of the HIP geometry decoder and VAE transformer (run it once on a machine where Hunyuan3D-2 is installed).
 
 `followmyhold_amd.geo_decode._parts` reads hy3dgen's `CrossAttentionDecoder` by attribute name (query_proj, cross_attn_decoder.{ln_1,
 ln_2, ln_3, attn.{c_q, c_kv, c_proj, attention.{heads, q_norm, k_norm}}, mlp.{c_fc, c_proj}}, ln_post, output_proj, fourier_embedder.
@@ -84,6 +84,50 @@ def main():
     print(f"forward: max |diff| {err:.3e} at a logit scale of {scale:.3e};  latent gradient: rel {gerr:.3e}, cosine {cos:.7f}")
     ok = err <= 3e-3 * max(scale, 1.0) and gerr <= 1e-2 and cos >= 1 - 1e-4
     print("OK: the HIP decoder reproduces hy3dgen's CrossAttentionDecoder" if ok else "FAIL: mismatch against hy3dgen's module")
+    return (0 if ok else 1) | check_transformer(vae, n_lat)
+
+
+def check_transformer(vae, n_lat):
+    """... and the transformer in front of it (`vae(latents)` = post_kl -> transformer, PL:295): followmyhold_amd.vae_transformer reads
+    `vae.transformer.resblocks[i].{ln_1, attn.{c_qkv, c_proj, attention.{heads, q_norm, k_norm}}, ln_2, mlp.{c_fc, c_proj}}` (c_qkv's rows
+    interleave q | k | v per head).  Tokens and latent gradient of the kernels against the module in float32; then the fallback route:
+    does `sdpa.hip_sdpa()` reach the module's attention calls at all (hy3dgen binds `scaled_dot_product_attention` at import time)?"""
+    import torch
+    from followmyhold_amd import _lib as L, sdpa
+    from followmyhold_amd.vae_transformer import HipVaeTransformer
+    with torch.no_grad():
+        for p in vae.parameters():
+            p.copy_(p.half().float())
+    try:
+        tr = HipVaeTransformer.from_module(vae)
+    except (AttributeError, L.FohoError) as e:
+        print(f"FAIL: vae_transformer._blocks does not fit this hy3dgen's ShapeVAE.transformer: {type(e).__name__}: {e}")
+        print("      attributes of a block:", [n for n, _ in vae.transformer.resblocks[0].named_children()] if hasattr(vae.transformer, "resblocks") else dir(vae.transformer))
+        return 1
+    embed = vae.post_kl.in_features
+    g = torch.Generator().manual_seed(2)
+    lat = torch.randn(1, n_lat, embed, generator=g).cuda()
+    go = torch.randn(1, n_lat, tr.width, generator=g).cuda()
+    lr = lat.clone().requires_grad_(True)
+    ref = vae(lr)
+    (ref * go).sum().backward()
+    lh = lat.clone().requires_grad_(True)
+    n0 = tr.calls
+    out = tr(vae.post_kl(lh).half())
+    (out.float() * go).sum().backward()
+    assert tr.calls == n0 + 1
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    gerr = (lh.grad - lr.grad).abs().max().item() / max(lr.grad.abs().max().item(), 1e-30)
+    cos = torch.nn.functional.cosine_similarity(lh.grad.flatten(), lr.grad.flatten(), dim=0).item()
+    print(f"transformer: tokens rel {err:.3e};  latent gradient: rel {gerr:.3e}, cosine {cos:.7f}")
+    ok = err <= 1e-2 and gerr <= 3e-2 and cos >= 1 - 2e-4
+    print("OK: foho_vae_fwd / _bwd reproduce hy3dgen's transformer" if ok else "FAIL: transformer mismatch against hy3dgen's module")
+    vae16 = vae.half()
+    h0 = sdpa.hits
+    with torch.no_grad(), sdpa.hip_sdpa():
+        vae16(lat.half())
+    print(f"fallback route: sdpa.hip_sdpa() served {sdpa.hits - h0} of the module's {len(vae.transformer.resblocks)} attention calls"
+          + ("" if sdpa.hits - h0 else "  <-- the patch does not reach this hy3dgen build (only the backend priority applies)"))
     return 0 if ok else 1
 
 

@@ -3,7 +3,7 @@ the iteration's wall time is kernel time?  python scripts/dev/dev_pipe_trace.py"
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
-from followmyhold_amd import engine as E, geo_decode, pipeline as PLN, standins, synthetic
+from followmyhold_amd import engine as E, geo_decode, pipeline as PLN, standins, synthetic, vae_transformer
 dev = torch.device("cuda", 0)
 scene = dict(synthetic.build_scene(E.hip_render_fn(dev), obj_kind="20k", H=512, W=512, seed=0))
 res = 64
@@ -17,6 +17,8 @@ torch.manual_seed(0)
 vae = standins.StandInShapeVAE(num_latents=3072, embed_dim=64, width=1024, heads=16, layers=16, num_freqs=8).to(dev).half().eval()
 vae.requires_grad_(False)
 geo_decode.install(vae, device=dev)
+if os.environ.get("FOHO_TORCH_VAE") != "1":
+    vae_transformer.install(vae, device=dev)
 lat = torch.randn(1, 3072, 64, device=dev, dtype=torch.float16)
 noise = torch.zeros_like(lat).requires_grad_(True)
 gsz = (res + 1,) * 3

@@ -50,6 +50,14 @@ VARIANTS.append(dict(tag="_tame", scene=dict(obj_kind="ico2", H=64, W=64, seed=3
                      config=dict(phase1_hand_lrs={"scale": 2e-5, "trans": 2e-5, "rot": 1e-3}),
                      schedule=dict(num_inference_steps=4, guidance_start_step=2, handopt_start_step=1, guidance_end_step=4,
                                    optimization_steps_hand=6, optimization_steps_scale=2, optimization_steps_joint=2)))
+# variant 3: variant 2 with a ShapeVAE the matrix-core kernels take -- width 128, 2 heads of 64, 128 latent tokens -- so that the replay on
+# the GPU runs `vae(pred)` on foho_vae_fwd / _bwd and the decodes on foho_geo_decode_* INSIDE a trajectory that is compared with the
+# reference's (the reference side is float32 torch on the CPU, as for the other variants; the kernels store fp16)
+VAE_KW_HD64 = dict(num_latents=128, embed_dim=4, width=128, heads=2, layers=2, num_freqs=3, radius=RADIUS, sharpness=4.0, gain=0.1)
+VARIANTS.append(dict(tag="_hd64", scene=dict(obj_kind="ico2", H=64, W=64, seed=3), vae_kw=VAE_KW_HD64,
+                     config=dict(phase1_hand_lrs={"scale": 2e-5, "trans": 2e-5, "rot": 1e-3}),
+                     schedule=dict(num_inference_steps=4, guidance_start_step=2, handopt_start_step=1, guidance_end_step=4,
+                                   optimization_steps_hand=6, optimization_steps_scale=2, optimization_steps_joint=2)))
 SCENE, SCHEDULE = VARIANTS[0]["scene"], VARIANTS[0]["schedule"]
 
 
@@ -124,9 +132,10 @@ def main():
         setattr(PL, k, v)
     sys.modules["pytorch3d.io.experimental_gltf_io"] = types.SimpleNamespace(_read_header=None, MeshGlbFormat=lambda: None)
 
-    only = os.environ.get("FOHO_GOLDEN_ONLY")          # e.g. "_tame": regenerate one variant, leave the others' files alone
+    only = os.environ.get("FOHO_GOLDEN_ONLY")          # e.g. "_tame" or "base,_hd64": regenerate these variants, leave the others' files alone
+    only = None if only is None else [("" if t == "base" else t) for t in only.split(",")]
     for variant in VARIANTS:
-        if only is None or variant["tag"] == only:
+        if only is None or variant["tag"] in only:
             run_variant(variant, PL, SCH, OptimizationConfig, P, standins)
 
 
@@ -142,7 +151,8 @@ def run_variant(variant, PL, SCH, OptimizationConfig, P, standins):
         os.chdir(root)
         stack.callback(os.chdir, cwd)
 
-        net = standins.make_standin_pipeline(device="cpu", dtype=torch.float32, seed=1, **VAE_KW)
+        vae_kw = variant.get("vae_kw", VAE_KW)
+        net = standins.make_standin_pipeline(device="cpu", dtype=torch.float32, seed=1, **vae_kw)
         # the reference holds its networks with requires_grad at torch's default (GuidedShapePipeline switches it off: the guidance
         # optimises no weight); autograd then also forms the weight gradients, through other kernels for LayerNorm / Linear whose
         # input gradients differ in the last bit -- the committed trajectories are the reference's, so run it the reference's way
@@ -194,7 +204,7 @@ def run_variant(variant, PL, SCH, OptimizationConfig, P, standins):
             arrays[f"opt{n}_noise"] = big[0].detach().float().numpy()
     np.savez_compressed(os.path.join(OUT, f"ref_pipeline{variant['tag']}.npz"), **arrays)
     with open(os.path.join(OUT, f"ref_pipeline{variant['tag']}.json"), "w") as f:
-        json.dump(dict(scene=variant["scene"], radius=RADIUS, schedule=variant["schedule"], config=variant["config"], vae_kw=VAE_KW, log=lines, optimizers=[m[0] for m in made],
+        json.dump(dict(scene=variant["scene"], radius=RADIUS, schedule=variant["schedule"], config=variant["config"], vae_kw=variant.get("vae_kw", VAE_KW), log=lines, optimizers=[m[0] for m in made],
                        torch=torch.__version__), f, indent=1)
     print("hand", arrays["hand_verts"].shape, "object", arrays["obj_counts"], arrays["obj_stats"])
 

@@ -44,6 +44,17 @@ def test_every_declared_symbol_is_exported(lib):
     assert not missing, f"declared in include/*.h but not exported by libfoho_hip.so: {missing}"
 
 
+def test_nothing_but_the_declared_entry_points_is_exported():
+    """-fvisibility=hidden + FOHO_API on the declarations: `nm -D` shows the header's functions and nothing else (no kernel stubs, no helpers)."""
+    import subprocess
+    from followmyhold_amd import _lib
+    _lib.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in ("T", "t", "W", "V", "B", "D"))
+    exported = [n for n in exported if not n.startswith(("_init", "_fini", "__bss_start", "_edata", "_end", "__hip_"))]
+    assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))
+
+
 def test_host_only_queries_work_without_a_gpu(lib):
     from followmyhold_amd import _lib as L
     lib.foho_version.restype = ctypes.c_int

@@ -586,3 +586,56 @@ def test_active_row_backward_is_graph_capturable():
         torch.cuda.synchronize()
         assert stats_static.tolist() == [n_act, 0]
         assert torch.equal(out_static, ref), n_act
+
+
+@gpu
+def test_unit_gemm_variants_beside_a_decode_on_another_thread_leave_its_bits_alone():
+    """The library keeps no mode state (re-entrant): while one thread hammers `foho_geo_gemm` with every kernel-variant bit
+    (`gelu | 2` = 128 x 128 tiles, `| 4` lock-step, `| 8` deep ring, `| 16` phased) on its own stream, decodes on another thread give the
+    bits they give alone.  (Until round 5 the variant was a process-global the unit entry point set and reset around its launch.)"""
+    import threading
+    from followmyhold_amd.geo_decode import HipGeoDecoder
+    L, lib = _lib()
+    dec = _decoder(256, 4, 256)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 256, 256, generator=g).half().cuda()
+    q = (torch.rand(1, 6000, 3, generator=g) * 2.2 - 1.1).half().cuda()
+    hip = HipGeoDecoder.from_module(dec, chunk_rows=2048)      # 2048-row blocks: the chain's GEMMs take the 256 x 256 route by shape
+    alone = hip(q.float(), lat).clone()
+    torch.cuda.synchronize()
+    M, N, K = 2304, 512, 512
+    A = torch.randn(M, K, generator=g).half().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    b = torch.zeros(N).cuda()
+    ref = (A.float() @ W.float().t()).half()
+    stop, errors, count = threading.Event(), [], [0]
+
+    def hammer():
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            C = torch.empty(M, N, dtype=torch.float16, device="cuda")
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    for flag in (2, 4, 8, 16, 0):
+                        rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), None, _p(C), M, N, K, flag, ctypes.c_float(1.0), ctypes.c_void_p(st.cuda_stream))
+                        assert rc == 0, lib.foho_geo_last_error()
+                        count[0] += 1
+                    st.synchronize()
+                    assert (C.float() - ref.float()).abs().max().item() <= 2e-2 * ref.float().abs().max().item()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        for _ in range(30):
+            lat2 = lat.clone()                       # a new tensor object: K / V are projected again, the whole chain runs
+            out = hip(q.float(), lat2)
+            torch.cuda.synchronize()
+            assert torch.equal(out, alone)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    assert count[0] >= 10

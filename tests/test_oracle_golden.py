@@ -336,7 +336,7 @@ def test_golden_files_regenerate_from_the_reference(tmp_path):
     import subprocess
     import sys
     gdir = os.path.join(HERE, "golden")
-    env = dict(os.environ, OMP_NUM_THREADS="8")
+    env = dict(os.environ, OMP_NUM_THREADS="8", FOHO_GOLDEN_ONLY="base,_v1,_hd64")      # (the "_tame" trajectory is variant 0's scene again)
     for script in ("make_golden.py", "make_pipeline_golden.py", "make_icp_golden.py"):
         r = subprocess.run([sys.executable, os.path.join(gdir, script), str(tmp_path)], capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -350,7 +350,7 @@ def test_golden_files_regenerate_from_the_reference(tmp_path):
     assert sorted(old_i.files) == sorted(new_i.files)
     for k in old_i.files:
         assert np.array_equal(new_i[k], old_i[k]), k
-    for tag in ("", "_v1"):
+    for tag in ("", "_v1", "_hd64"):
         old_p, new_p = np.load(os.path.join(gdir, f"ref_pipeline{tag}.npz")), np.load(str(tmp_path / f"ref_pipeline{tag}.npz"))
         assert sorted(old_p.files) == sorted(new_p.files)
         for k in old_p.files:

@@ -334,14 +334,17 @@ def test_guidance_stage_driver_with_standin_networks(tmp_path, monkeypatch):
 
 
 @gpu
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     """tests/golden/ref_pipeline*.npz hold what the REFERENCE's own `__call__` (PL:1044-1679) returned and printed when it
     was executed in the build container on these scenes with the CPU restatement standing in for pytorch3d / kaolin
     (tests/golden/make_pipeline_golden.py; variant 1 has two joint denoising steps and the intersection term off).  The
     same inputs through GuidedShapePipeline on the GPU must give the same first-iteration losses of every phase (they
     depend on everything before them: DiT call, CFG mix, scheduler, latent -> SDF -> FlexiCubes, the optimisation of the
-    earlier phases, scheduler.step), the same per-phase parameters, the same final hand and the same final object."""
+    earlier phases, scheduler.step), the same per-phase parameters, the same final hand and the same final object.
+    Variant 3 ("_hd64") has a ShapeVAE of width 128 with two heads of 64 over 128 latent tokens: here BOTH `vae_transformer.install` and
+    `geo_decode.install` are applied, so `vae(pred)` (PL:295) runs on foho_vae_fwd / _bwd and every decode on foho_geo_decode_* INSIDE
+    the compared trajectory -- fp16 kernels against the reference's float32 torch: tolerances x `F16`."""
     import json
     import re
     import sys
@@ -356,7 +359,13 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     sc, paths = MPG.build_inputs(tmp_path, var["scene"])
     chk = np.array([float(np.abs(sc[k].astype(np.float64)).sum()) for k in ("hand_verts", "obj_verts", "moge_normal", "moge_disp", "kps_2d", "T_h2m")])
     assert np.allclose(chk, ref["scene_checksum"], rtol=1e-6), "the synthetic scene differs from the one the fixture was made on"
-    pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1, **MPG.VAE_KW)
+    pipe = standins.make_standin_pipeline(device="cuda", dtype=torch.float32, seed=1, **var.get("vae_kw", MPG.VAE_KW))
+    F16 = 1.0
+    if var["tag"] == "_hd64":
+        from followmyhold_amd import geo_decode, vae_transformer
+        geo_decode.install(pipe.vae)
+        tr = vae_transformer.install(pipe.vae)
+        F16 = 8.0
     wchk = np.array([float(sum(p.detach().double().abs().sum() for p in m.parameters())) for m in (pipe.vae, pipe.model, pipe.conditioner)])
     assert np.allclose(wchk, ref["weights_checksum"], rtol=1e-6), "stand-in network initialisation differs"
     cfg = E.OptimizationConfig()
@@ -382,8 +391,8 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
                           + n_joint * sch["optimization_steps_joint"], "skipped_empty": 0}
     # variant 2 runs phase A at 1 / 500 of the reference's learning rates, where the trajectory itself is comparable
     d_a = np.abs(after_a["params"].cpu().numpy() - ref["opt0_small"]).max()
-    assert d_a < (2e-5 if var["tag"] == "_tame" else 6e-3), d_a
-    if var["tag"] == "_tame":
+    assert d_a < (2e-5 if var["tag"] in ("_tame", "_hd64") else 6e-3), d_a
+    if var["tag"] in ("_tame", "_hd64"):
         assert np.abs(ref["opt0_small"] - np.array([1, 0, 0, 0, 1, 0, 0, 0], np.float32)).max() > 1e-4      # it did move
     # first-iteration losses the reference printed (PL:1351-1355, 1446-1450, 1594-1598)
     num = lambda line: dict((k.strip(), float(v)) for k, v in re.findall(r"([A-Za-z_ 0-9]+): ([-+0-9.eE]+)", line.split(",", 1)[1]))
@@ -393,40 +402,44 @@ def test_replay_of_the_reference_loop_trajectory(tmp_path, variant):
     la, lb = pipe.loss_log[0][3], pipe.loss_log[1][3]
     assert close(la["kps"], opt[0]["loss_2d_kps"], 1e-4) and close(la["normal0"], opt[0]["loss_normal_hand"], 1e-4)
     assert close(la["disp0"], opt[0]["loss_disp_hand"], 1e-4)
-    assert close(lb["edge"], opt[1]["object loss"], 1e-4) and close(lb["normal0"], opt[1]["loss_normal_obj"], 1e-4)
-    assert close(lb["disp0"], opt[1]["loss_disp"], 1e-4)
+    assert close(lb["edge"], opt[1]["object loss"], 1e-4 * F16 ** 2) and close(lb["normal0"], opt[1]["loss_normal_obj"], 1e-4 * F16 ** 2), (lb, opt[1])
+    assert close(lb["disp0"], opt[1]["loss_disp"], 1e-4 * F16 ** 2)
     for j in range(n_joint):
         lc, rc = pipe.loss_log[2 + j][3], opt[2 + j]
-        tol = 2e-3 * (1 + 4 * j)          # each further joint step inherits the differences of the one before
+        tol = 2e-3 * (1 + 4 * j) * F16    # each further joint step inherits the differences of the one before
         assert close(lc["edge"], rc["object loss"], tol) and close(lc["normal1"], rc["loss_normal_hoi"], tol), (j, lc, rc)
         assert close(lc["disp1"], rc["loss_disp"], tol)
         if cfg.use_intersection_loss:
-            assert close(lc["n_intersect"] / 1000.0, rc["loss_intersection"], 2e-2)
+            assert close(lc["n_intersect"] / 1000.0, rc["loss_intersection"], 2e-2 * (F16 / 2 if F16 > 1 else 1))
         else:
             assert rc["loss_intersection"] == 0.0
     # parameters each phase ended with (the reference's per-phase leaf tensors, PL:1300-1318, 1366-1384, 1461-1478)
     assert len(pipe.param_log) == 2 + n_joint and meta["optimizers"] == ["Adam"] + ["AdamW"] * (1 + n_joint)
     _, _, pb_, nb = pipe.param_log[1]
-    assert np.allclose(pb_[8:].cpu().numpy(), ref["opt1_small"], atol=2e-4) and np.allclose(nb.cpu().numpy(), ref["opt1_noise"], atol=2e-4)
+    assert np.allclose(pb_[8:].cpu().numpy(), ref["opt1_small"], atol=2e-4 * F16) and np.allclose(nb.cpu().numpy(), ref["opt1_noise"], atol=2e-4 * F16), \
+        (np.abs(pb_[8:].cpu().numpy() - ref["opt1_small"]).max(), np.abs(nb.cpu().numpy() - ref["opt1_noise"]).max())
     # The first joint phase starts from matched states and is compared tightly.  A later one inherits 1e-4-level differences,
     # and where a gradient component is near zero Adam (eps 1e-4) turns those into a different step of size lr (1e-2 for the
     # object translation / rotation): only the hand (lr 1e-4 / 1e-2, well-conditioned) stays tight there.
     for j in range(n_joint):
         _, _, pc_, nc = pipe.param_log[2 + j]
-        atol = np.full(16, 5e-4) if j == 0 else np.concatenate([np.full(8, 2e-3), np.full(8, 2.5e-2)])
+        # (fp16 kernels in the loop, variant 3: the object's near-zero gradient components get the Adam treatment from the first joint step on)
+        atol = np.full(16, 5e-4) if (j == 0 and F16 == 1.0) else np.concatenate([np.full(8, 2e-3 * min(F16, 2.0)), np.full(8, 2.5e-2)])
         diff = np.abs(pc_.cpu().numpy() - ref[f"opt{2 + j}_small"])
         assert (diff <= atol).all(), (j, pc_.cpu().numpy(), ref[f"opt{2 + j}_small"])
-        assert np.allclose(nc.cpu().numpy(), ref[f"opt{2 + j}_noise"], atol=5e-3 if j == 0 else 5e-2)
+        assert np.allclose(nc.cpu().numpy(), ref[f"opt{2 + j}_noise"], atol=(5e-3 if j == 0 else 5e-2) * min(F16, 2.0))
     # final hand: the MoGe-space MANO under the optimised similarity; final object: res-384 decode under its similarity
-    tol_v = 2e-4 * (1 + 10 * (n_joint - 1))
+    tol_v = 2e-4 * (1 + 10 * (n_joint - 1)) * F16
+    if var["tag"] == "_hd64":      # the kernels were in the loop: every latent iteration went through foho_vae_fwd (+ _bwd), none through torch
+        assert tr.calls >= sch["optimization_steps_scale"] + n_joint * sch["optimization_steps_joint"] + sch["num_inference_steps"], tr.calls
     hv = hand.verts_packed().cpu().numpy()
     assert np.array_equal(hand.faces_packed().cpu().numpy(), ref["hand_faces"])
     assert np.abs(hv - ref["hand_verts"]).max() < tol_v, np.abs(hv - ref["hand_verts"]).max()
     ov, of = obj.verts_packed().cpu().numpy(), obj.faces_packed().cpu().numpy()
-    assert abs(len(ov) - ref["obj_counts"][0]) <= 0.002 * ref["obj_counts"][0]
+    assert abs(len(ov) - ref["obj_counts"][0]) <= 0.002 * F16 * ref["obj_counts"][0]
     st, want = MPG.object_stats(ov, of), ref["obj_stats"]
-    assert np.abs(st[:9] - want[:9]).max() < (1e-3 if n_joint == 1 else 2.5e-2)      # centroid and bounding box (metres)
-    assert np.allclose(st[9:], want[9:], rtol=2e-2 if n_joint == 1 else 0.15)        # radius mean / std, area, volume
+    assert np.abs(st[:9] - want[:9]).max() < (1e-3 if n_joint == 1 else 2.5e-2) * min(F16, 3.0)      # centroid and bounding box (metres)
+    assert np.allclose(st[9:], want[9:], rtol=(2e-2 if n_joint == 1 else 0.15) * min(F16, 2.0))        # radius mean / std, area, volume
 
 
 @gpu
