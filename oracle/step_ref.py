@@ -262,3 +262,107 @@ def loss_without_silhouette(phase, scene, params, denoise_i=19, num_inference_st
     if phase != "A":
         grads["obj_verts"] = ov.grad.detach().clone()
     return rest.detach(), grads
+
+
+def grads_f64(phase, scene, params, renders, denoise_i=19, num_inference_steps=20, grid_res=64, without_silhouette=False, knn_idx=None):
+    """THE gradient referee of the parity tests: d total / d (similarity parameters, obj_verts) of one iteration of `phase` with the
+    differentiable part of this oracle in FLOAT64, on the fragments of the float32 run.  `renders`: the render records of that run in
+    call order (phase A / B: [aux["render"]]; phase C: [aux["hand"]["render"], aux["render"]]).  Two things of the float32 run are
+    injected, because the reference's objective is DEFINED through them:
+      * the rasteriser's selection (`sel`: face ids, K-buffers) -- so all sides differentiate the very same fragments;
+      * the VALUES of the silhouette alphas (`sil`), straight-through: BCE'(alpha) = 1 / (1 - alpha) is evaluated at the float32 alpha the
+        reference's loss sees (a pixel whose alpha sits one float32 step below 1 carries 1e4 of phase A's translation gradient -- a
+        float64 alpha there is a different objective, 1e3 x off), while d alpha / d vertices is formed in float64.
+      * (phase C, `knn_idx`: aux["knn_idx"]) the nearest object vertex of every hand vertex: on the regular synthetic meshes two object
+        vertices are often equally near, and which one wins decides where the contact term's gradient lands -- a discrete choice like the
+        rasteriser's, not something a float64 run may re-decide.
+    float32 torch autograd through normalize / cross / index_add loses 3-4 digits on the vertices with the largest normal gradient
+    (NOTEBOOK round 5); the kernels' hand-derived backward does not, so a float32-vs-float32 comparison measures the ORACLE's error there.
+    -> (total (float64 tensor), {name: float64 tensor}); without_silhouette: the total minus the phase's silhouette BCE term
+    (loss_without_silhouette's comparison)."""
+    sc64 = {k: (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v) for k, v in scene.items()}
+    sel_q = [r["sel"] for r in renders]
+    sil_q = [r["sil"] for r in renders if r.get("sil") is not None]
+    real_sel, real_sil, real_knn, real_center = R.rasterize_select, R.render_silhouette, R.knn1, R.bbox_center
+    # ... and the vertices that ARE the bounding box (PL:111: the similarity's centre is (min + max) / 2 over the vertices, so its gradient
+    # lands on the six extremal vertices; on the synthetic meshes several vertices share an extreme coordinate and rounding picks): the
+    # float32 run's choice, found by repeating its float32 arithmetic -- hand vertices as given, object vertices through T_h2m
+    centers = []
+    with torch.no_grad():
+        clouds = []
+        if phase in ("A", "C"):
+            clouds.append(scene["hand_verts"].float())
+        if phase in ("B", "C"):
+            clouds.append(R.transform_hunyuan2moge(scene["obj_verts"].detach().float(), scene["T_h2m"].float()))
+        for v32 in clouds:
+            centers.append((v32.min(dim=0)[1], v32.max(dim=0)[1]))
+
+    def center_injected(verts):
+        imin, imax = centers.pop(0)
+        cols = torch.arange(3)
+        return (verts[imin, cols] + verts[imax, cols]) / 2.0
+
+    def sil_straight_through(*a, **kw):
+        alpha = real_sil(*a, **kw)
+        a32 = sil_q.pop(0).detach().to(alpha.dtype).reshape(alpha.shape)
+        return alpha + (a32 - alpha).detach()
+
+    # ... and the SIGN of every disparity residual (F.l1_loss, PL:1340, 1422, 1497, 1568): the synthetic targets are this oracle's own
+    # renders, so at the first step of a scene most residuals are EXACTLY zero in float32 (subgradient 0) where a float64 render differs
+    # from the float32 target in its last bits (subgradient +-1 at random): 11 % of the disparity term's vertex gradient
+    disp_q = [r["disp"] for r in renders]
+    real_l1 = torch.nn.functional.l1_loss
+
+    def l1_injected(pred, target):
+        r32 = disp_q.pop(0).detach().float().reshape(pred.shape)
+        sign = torch.sign(r32 - target.detach().float()).to(pred.dtype)
+        return (sign * (pred - target)).mean()
+
+    def knn_injected(p1, p2):
+        idx = knn_idx if isinstance(knn_idx, torch.Tensor) else torch.as_tensor(knn_idx)
+        d = p1 - p2[idx.long()]
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], idx
+
+    R.rasterize_select = lambda *a, **kw: sel_q.pop(0)
+    R.render_silhouette = sil_straight_through
+    R.bbox_center = center_injected
+    torch.nn.functional.l1_loss = l1_injected
+    if knn_idx is not None:
+        R.knn1 = knn_injected
+    try:
+        p64 = leafify({k: v.detach().double() for k, v in params.items()}, PARAM_KEYS)
+        ov64 = sc64["obj_verts"].detach().clone().requires_grad_(phase != "A")
+        edges = R.unique_edges(scene["obj_faces"])
+        if phase == "A":
+            total, terms, _ = phase_a_loss(sc64, p64)
+            keys = ["scale_hand", "trans_hand", "rot_hand"]
+        elif phase == "B":
+            total, terms, _ = phase_b_loss(sc64, p64, ov64, edges)
+            keys = ["scale_obj", "trans_obj", "rot_obj"]
+        else:
+            total, terms, _ = phase_c_loss(sc64, p64, ov64, edges, denoise_i, num_inference_steps, grid_res=grid_res)
+            keys = PARAM_KEYS
+        if without_silhouette:
+            name, w = SIL_TERM[phase]
+            total = total - w * terms[name]
+        total.backward()
+    finally:
+        R.rasterize_select, R.render_silhouette, R.knn1, R.bbox_center = real_sel, real_sil, real_knn, real_center
+        torch.nn.functional.l1_loss = real_l1
+    grads = {k: p64[k].grad.detach().clone() for k in keys}
+    if phase != "A":
+        grads["obj_verts"] = ov64.grad.detach().clone()
+    return total.detach(), grads
+
+
+def referee_grads(phase, scene, params, renders, grads32, denoise_i=19, num_inference_steps=20, grid_res=64, knn_idx=None):
+    """The gradient reference of the parity tests for a WHOLE iteration: every term but the silhouette's from `grads_f64` (float64
+    derivatives on the float32 run's fragments), the silhouette term's own gradient from the float32 oracle -- `grads32` (the float32
+    autograd of the total, a Stepper's `grads`) minus the float32 autograd of the total without it.  The silhouette BCE at sigma = 1e-8 is
+    a function of float32 ROUNDINGS (sigmoids that are exactly 0 or 1 in float32 are not in float64, 1 / (1 - alpha) at alphas one float32
+    step below 1): there is no float64 version of it to referee with, and its backward is plain arithmetic on edge distances (no
+    cancellation to lose digits in).  What float32 autograd does lose -- the normal / disparity / key-point / edge routes through
+    normalize, cross, index_add -- is float64 here."""
+    _, g32_rest = loss_without_silhouette(phase, scene, params, denoise_i, num_inference_steps, grid_res)
+    _, g64_rest = grads_f64(phase, scene, params, renders, denoise_i, num_inference_steps, grid_res, without_silhouette=True, knn_idx=knn_idx)
+    return {k: g64_rest[k] + (grads32[k].double() - g32_rest[k].double()) for k in g64_rest}
