@@ -50,7 +50,7 @@ MIN_TIMED_S = 0.25     # the timed region of --steps iterations is repeated unti
 # another object / size / batch gets null, never a borrowed number
 def _prof(name):
     """Committed rocprofv3 summaries of a workload, newest round first."""
-    return [os.path.join("profiles", f"{r}_{name}") for r in ("r05", "r04", "r03", "r02")]
+    return [os.path.join("profiles", f"{r}_{name}") for r in ("r06", "r05", "r04", "r03", "r02")]
 
 
 PMC_CSVS = {("20k", 512, 1): _prof("rocprofv3_pmc_fetch_write_b1.csv"), ("20k", 512, 8): _prof("rocprofv3_pmc_fetch_write_b8.csv")}

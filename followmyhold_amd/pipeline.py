@@ -299,8 +299,7 @@ class GuidedShapePipeline:
 
         def sdf_of(x1, xyz, gsz):
             """latent2sdf (PL:292-313) for B latents: the VAE transformer on all of them, the geometry decoder per image."""
-            with vae_attention_backend():
-                pred = self.vae(1 / self.vae.scale_factor * x1)
+            pred = vae_tokens(self.vae, 1 / self.vae.scale_factor * x1)      # all images through ONE foho_vae_fwd (rows = images x tokens)
             out = []
             hip = getattr(self.vae, "hip_geo", None)
             for b in range(x1.shape[0]):
