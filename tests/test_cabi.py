@@ -34,9 +34,9 @@ def lib():
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ["foho_step_run", "foho_step_workspace_bytes", "foho_step_workspace_region", "foho_last_error",
-                 "foho_version", "foho_step_run_profiled"]:
+                 "foho_version", "foho_step_run_profiled", "foho_geo_decode_fwd", "foho_vae_fwd", "foho_vae_bwd", "foho_sdpa_fwd", "foho_icp_run"]:
         assert must in names
-    assert len(names) >= 8
+    assert len(names) == 58, len(names)
 
 
 def test_every_declared_symbol_is_exported(lib):
