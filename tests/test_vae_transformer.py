@@ -194,3 +194,41 @@ def test_latent2sdf_routes_through_the_hip_transformer_and_falls_back():
     with torch.no_grad():
         out = PLN.vae_tokens(vae, short)
     assert tr.calls == n1 and out.shape == (1, 100, 256)
+
+
+@gpu
+def test_forward_and_backward_are_capturable_in_a_hip_graph():
+    """foho_vae_fwd / foho_vae_bwd make no host synchronisation and allocate nothing: both directions of a two-layer stack captured into ONE
+    hipGraph and replayed give the bits of the eager calls (the guidance loop replays whole iterations as graphs)."""
+    from followmyhold_amd.vae_transformer import HipVaeTransformer
+    vae = _hy3d(256, 4, 2)
+    tr = HipVaeTransformer.from_module(vae)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 256, 256, generator=g).half().cuda()
+    go = torch.randn(2, 256, 256, generator=g).half().cuda()
+    out_e, saved_e = tr.forward_raw(x, keep=True)
+    gx_e = tr.backward_raw(go, saved_e, tuple(x.shape))
+    torch.cuda.synchronize()
+    import ctypes
+    from followmyhold_amd import _lib as L
+    d = tr._desc(2, 256)
+    ws = tr._workspace(d)
+    saved = torch.empty_like(saved_e)
+    out, gx = torch.empty_like(x), torch.empty_like(x)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        st = L.vp(side.cuda_stream)
+        rc1 = tr.lib.foho_vae_fwd(ctypes.byref(d), L.vp(x.data_ptr()), L.vp(out.data_ptr()), L.vp(ws.data_ptr()), ctypes.c_size_t(ws.numel()), L.vp(saved.data_ptr()),
+                                  ctypes.c_size_t(saved.numel()), st)
+        rc2 = tr.lib.foho_vae_bwd(ctypes.byref(d), L.vp(go.data_ptr()), L.vp(gx.data_ptr()), L.vp(ws.data_ptr()), ctypes.c_size_t(ws.numel()), L.vp(saved.data_ptr()),
+                                  ctypes.c_size_t(saved.numel()), st)
+        graph.capture_end()
+    assert rc1 == 0 and rc2 == 0
+    for _ in range(2):
+        out.zero_(), gx.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, out_e) and torch.equal(gx, gx_e)
