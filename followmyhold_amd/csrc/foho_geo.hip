@@ -1009,6 +1009,12 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 // Workgroup = 4 waves x 64 queries of ONE head; 64-key tiles of K and V^T double-buffered in LDS, brought by LDS-DMA (buffer_load ... lds:
 // tile t + 1 is in flight while tile t is computed; no staging registers, which is what pays for four score buffers -- see inside).
 // ------------------------------------------------------------------------------------------------
+// Images of a batch in ONE launch (round 6: the ShapeVAE transformer's attention for B images; a launch per image leaves the chip
+// under-filled -- 192 / 384 workgroups at 16 heads x 3072 tokens).  Per operand of a kernel, the distance between two images in
+// elements of the operand's type; the image is blockIdx.y (k_geo_pack_vt: blockIdx.z).  All zero with gridDim.y == 1: one image.
+struct AttnB {
+    long a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, g = 0, h = 0;
+};
 constexpr int AQ = 256, AK = 64;
 constexpr float RESCALE_THR = 6.0f;  // log2 domain: P <= 2^6 while the running max lags behind
 
@@ -1028,7 +1034,11 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 __global__ __launch_bounds__(256, 2) void k_geo_attn(const h16* __restrict__ Q, int ldq, const h16* __restrict__ Kp, int ldk,
                                                      const h16* __restrict__ Vt, int L, h16* __restrict__ O, int ldo, int M,
                                                      int heads, float* __restrict__ nlse, const int* __restrict__ Mdev, int qhs = 64, int khs = 64,
-                                                     float qscale = 1.0f, float* __restrict__ lse_nat = nullptr) {
+                                                     float qscale = 1.0f, float* __restrict__ lse_nat = nullptr, AttnB bs = AttnB{}) {
+    // bs: a = Q, b = Kp, c = Vt, d = O, e = nlse, f = lse_nat
+    Q += blockIdx.y * bs.a, Kp += blockIdx.y * bs.b, Vt += blockIdx.y * bs.c, O += blockIdx.y * bs.d;
+    if (nlse) nlse += blockIdx.y * bs.e;
+    if (lse_nat) lse_nat += blockIdx.y * bs.f;
     // lse_nat: optional (heads, M) fp32 -- the NATURAL-log log-sum-exp of the scaled scores per head and query, the form torch's
     // attention backward kernels take (foho_sdpa_fwd)
     // qhs / khs: distance of two heads inside a row of Q / K (64: heads side by side; 192: hy3dgen's interleaved q | k | v per head);
@@ -1291,7 +1301,9 @@ __global__ void k_geo_knorm(h16* __restrict__ KV, int ldkv, int L, int heads, co
 // V half of the KV projection (L rows, row stride ldkv, columns width + head*64 + d) -> Vt[head][d][pos(l)]: within every
 // block of 16 keys, key kq goes to position (kq & 3) | ((kq & 4) << 1) | ((kq & 8) >> 1) (keys 4-7 and 8-11 swap places):
 // the order in which a lane of the P^T fragment holds its 8 keys (C layout of the 32x32 MFMA: rows (r & 3) + 8 (r >> 2) + 4 hi).
-__global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt, int col0 = -1, int hs = 64) {
+__global__ __launch_bounds__(256) void k_geo_pack_vt(const h16* __restrict__ KV, int ldkv, int width, int L, h16* __restrict__ Vt, int col0 = -1, int hs = 64,
+                                                     AttnB bs = AttnB{}) {
+    KV += blockIdx.z * bs.a, Vt += blockIdx.z * bs.b;   // (bs: a = KV, b = Vt; the image is blockIdx.z here)
     // one thread per (column, block of 16 keys): sixteen strided reads (coalesced across the threads of a wave: consecutive columns),
     // one 32-byte row segment written in the permuted order.  (One thread per ELEMENT, 3072 x 1024 two-byte stores, took 19 us.)
     const int c = blockIdx.x * 256 + threadIdx.x;  // head * 64 + d
@@ -1347,7 +1359,15 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_bwd(const h16* __restrict__
                                                          const float* __restrict__ ndelta, const h16* __restrict__ KV, int ldkv, int width,
                                                          int heads, int M, int splits, int L, int accumulate, float* __restrict__ part,
                                                          const int* __restrict__ Mdev, const h16* __restrict__ Vp = nullptr, int khs = 64,
-                                                         h16* __restrict__ dk16 = nullptr, h16* __restrict__ dv16 = nullptr, int ld16 = 0) {
+                                                         h16* __restrict__ dk16 = nullptr, h16* __restrict__ dv16 = nullptr, int ld16 = 0, AttnB bs = AttnB{}) {
+    // bs (with dk16 / dv16 only: the partial-sum route stays one image per launch): a = Qs, b = QsT, c = dO, d = dOT, e = nlse, f = ndelta,
+    // g = KV and Vp, h = dk16 and dv16
+    if (blockIdx.y) {
+        Qs += blockIdx.y * bs.a, QsT += blockIdx.y * bs.b, dO += blockIdx.y * bs.c, dOT += blockIdx.y * bs.d, nlse += blockIdx.y * bs.e, ndelta += blockIdx.y * bs.f;
+        KV += blockIdx.y * bs.g;
+        if (Vp) Vp += blockIdx.y * bs.g;
+        if (dk16) dk16 += blockIdx.y * bs.h, dv16 += blockIdx.y * bs.h;
+    }
     // K rows at KV + key ldkv + head khs; V rows at Vp + ... (default: the V half of the decoder's K | V projection, KV + width)
     // dk16 / dv16 (with splits == 1: this workgroup's sums ARE the gradient): dK / dV as fp16 rows of stride ld16, heads side by side,
     // instead of the fp32 partial sums in `part` -- no reduction pass
@@ -1590,7 +1610,13 @@ constexpr int DQQ = 128;   // queries per workgroup of k_geo_attn_dq
 __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ Qs, const h16* __restrict__ dO, int ldq, const h16* __restrict__ KV,
                                                         int ldkv, int width, const h16* __restrict__ Kt, int L, const float* __restrict__ nlse,
                                                         const float* __restrict__ ndelta, h16* __restrict__ dQ, int M, int heads,
-                                                        const h16* __restrict__ Vp = nullptr, int khs = 64, int lddq = 0) {
+                                                        const h16* __restrict__ Vp = nullptr, int khs = 64, int lddq = 0, AttnB bs = AttnB{}) {
+    // bs: a = Qs, b = dO, c = KV and Vp, d = Kt, e = nlse, f = ndelta, g = dQ
+    if (blockIdx.y) {
+        Qs += blockIdx.y * bs.a, dO += blockIdx.y * bs.b, KV += blockIdx.y * bs.c, Kt += blockIdx.y * bs.d, nlse += blockIdx.y * bs.e, ndelta += blockIdx.y * bs.f;
+        dQ += blockIdx.y * bs.g;
+        if (Vp) Vp += blockIdx.y * bs.c;
+    }
     if (!Vp) Vp = KV + width;   // (K / V rows as in k_geo_attn_bwd)
     if (lddq == 0) lddq = ldq;  // row stride of dQ (default: that of Qs / dO)
     __shared__ uint4 lds[2][3][AK * 8];  // [buffer][K | V | K^T][64 rows x 8 chunks] = 48 KB
@@ -1730,7 +1756,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_attn_dq(const h16* __restrict__ 
 // hs: distance of two heads inside a row of X; scale != 1: the values are multiplied (and rounded to fp16 again) first, and Xs (M x W,
 // heads side by side) receives the scaled rows as well -- the scaled copy of Q the backward attention kernels stream
 __global__ __launch_bounds__(256) void k_geo_transpose_perm(const h16* __restrict__ X, int ldx, int M, int W, h16* __restrict__ XT, int ldt, int hs = 64,
-                                                            float scale = 1.0f, h16* __restrict__ Xs = nullptr) {
+                                                            float scale = 1.0f, h16* __restrict__ Xs = nullptr, AttnB bs = AttnB{}) {
+    X += blockIdx.y * bs.a, XT += blockIdx.y * bs.b;   // (bs: a = X, b = XT -- a column offset inside the batch's transposed image --, c = Xs)
+    if (Xs) Xs += blockIdx.y * bs.c;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int m = i % M, c8 = i / M;
     if (c8 * 8 >= W) return;
@@ -1779,7 +1807,8 @@ __global__ __launch_bounds__(256) void k_geo_dkv_reduce16(const float* __restric
 // ndelta[q][head] = - sum_d dO[q][head, d] O[q][head, d] (negated: the backward attention starts its dP accumulators there); one
 // wave per row, 8 lanes per head and half row; rows M .. the next multiple of 64 (the padding of the last query tile) get 0
 __global__ __launch_bounds__(256) void k_geo_delta(const h16* __restrict__ dO, const h16* __restrict__ O, int width, int heads, int M,
-                                                   float* __restrict__ ndelta, const int* __restrict__ Mdev) {
+                                                   float* __restrict__ ndelta, const int* __restrict__ Mdev, AttnB bs = AttnB{}) {
+    dO += blockIdx.y * bs.a, O += blockIdx.y * bs.b, ndelta += blockIdx.y * bs.c;   // (bs: a = dO, b = O, c = ndelta)
     if (Mdev) M = min(M, *Mdev);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2350,8 +2379,8 @@ extern "C" int foho_geo_prepare(const foho_geo_weights* w, const void* latents, 
 }
 
 static void launch_attn(dim3 grid, hipStream_t s, const h16* Q, int ldq, const h16* Kp, int ldk, const h16* Vt, int L, h16* O, int ldo, int M, int heads, float* nlse,
-                        const int* Mdev, int qhs = 64, int khs = 64, float qscale = 1.0f, float* lse_nat = nullptr) {
-    hipLaunchKernelGGL(k_geo_attn, grid, dim3(256), 0, s, Q, ldq, Kp, ldk, Vt, L, O, ldo, M, heads, nlse, Mdev, qhs, khs, qscale, lse_nat);
+                        const int* Mdev, int qhs = 64, int khs = 64, float qscale = 1.0f, float* lse_nat = nullptr, AttnB bs = AttnB{}) {
+    hipLaunchKernelGGL(k_geo_attn, grid, dim3(256), 0, s, Q, ldq, Kp, ldk, Vt, L, O, ldo, M, heads, nlse, Mdev, qhs, khs, qscale, lse_nat, bs);
 }
 
 // ---- the forward chain in two halves: what depends only on the query points (Fourier embedding -> query projection -> ln_q ->

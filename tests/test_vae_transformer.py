@@ -164,6 +164,7 @@ def test_full_hunyuan_shape_one_layer_and_sixteen():
     """3072 tokens x 1024, 16 heads, hidden 4096, qk_norm -- one layer, then the sixteen-layer stack, tokens and latent gradient."""
     vae = _hy3d(1024, 16, 1, latents=3072, embed=64)
     _compare(vae, 1, 3072)
+    _compare(vae, 2, 3072, seed=4)       # two images: ONE attention launch per kernel for both (blockIdx.y = image), dK / dV written directly
     del vae
     vae = _hy3d(1024, 16, 16, latents=3072, embed=64)
     e_f, e_g, cos = _compare(vae, 1, 3072, tol_fwd=1e-2, tol_grad=3e-2)
