@@ -991,7 +991,24 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
         one(); one()
         ts = [one() for _ in range(iters)]
         rec = {k: float(np.median([x[k] for x in ts])) for k in ts[0]}
-        rec["iteration_ms"] = sum(rec.values())
+        rec["sections_sum_ms"] = sum(rec.values())       # (three device synchronisations per iteration: the sections' own clock)
+        # the iteration as the pipeline's loop runs it (pipeline.latent_phase_body): nothing waits for the device but the read-back of the
+        # iteration's flags / active-row count between the objective and the backward
+        def loop_body():
+            if noise.grad is not None:
+                noise.grad = None
+            sdf = PLN.latent2sdf(lat + 0.1 * noise, xyz, gsz, vae, dev)
+            loss = obj(sdf.reshape(1, -1), cfg)
+            rows = obj.active_rows()[0]                  # the loop's one host round trip
+            if name != "torch_decoder":
+                PLN._bound_active_rows(vae, rows)
+            loss.sum().backward()
+        loop_body()
+        torch.cuda.synchronize(dev); a = time.perf_counter()
+        for _ in range(iters):
+            loop_body()
+        torch.cuda.synchronize(dev)
+        rec["iteration_ms"] = (time.perf_counter() - a) * 1e3 / iters
         rec["grad_finite"] = bool(torch.isfinite(noise.grad).all())     # (fp16 leaf, random networks: its magnitude means nothing)
         out[name] = rec
     # ... and four images through one iteration the way GuidedShapePipeline.call_batch runs them ("batch the rank's images

@@ -462,11 +462,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
 // is held ~80 cycles per piece, and with ONE wave per SIMD (one workgroup per CU) nothing else feeds the matrix pipe meanwhile:
 // 0.65 us per K tile against 0.21 us of matrix work (0.93 us inside the transformer chain: 59 us for K = 4096).  A deeper ring ALONE
 // changed nothing (measured: the latency was never the limit).  Here tile t + 3 is issued while tile t is multiplied (4 x 32 KB of
-// LDS) -- far enough ahead that its pieces can go out two at a time BEHIND each k step's matrix instructions -- and a wave waits for
+// LDS) and a wave waits for
 // its OWN oldest tile with a counted s_waitcnt vmcnt(16) (two newer tiles of 8 pieces stay in flight) before the barrier that
 // publishes the tile to the other waves.  Same fragments, same epilogue as k_geo_gemm.
 // ------------------------------------------------------------------------------------------------
-template <int EP, bool SPREAD>
+template <int EP>
 __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                         h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
@@ -524,12 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
         // ring at every tile (the first build of this kernel did: no faster than two stages).  This wave's own reads of stage (t - 1) & 3
         // completed with the lgkmcnt(0) of the previous tile's last k step.
         __builtin_amdgcn_s_barrier();  // tile t has landed for every wave, and everybody is done reading stage (t - 1) & 3 -- where tile t + 3 goes
-        // tile t + 3 is needed three tiles from now: its eight pieces go out two at a time BEHIND the matrix instructions of each k step
-        // (a wave is held ~80 cycles per piece it issues: in one block in front of the loop that is 640 cycles of an idle matrix pipe
-        // per tile at one wave per SIMD -- the whole difference between 0.65 and 0.3 us per K tile)
-        const bool more = t + 3 < nk;
-        const int sb3 = (t + 3) & 3, k3 = (t + 3) * GK;
-        if (!SPREAD && more) D4_ISSUE(t + 3);
+        if (t + 3 < nk) D4_ISSUE(t + 3);   // (in ONE block: two pieces behind each k step's matrix instructions measured 55.6 against 41.8 us at K = 4096)
         asm volatile("" ::: "memory");
         const unsigned bo = (unsigned)(t & 3) << 15;  // 32 KB per stage
         half8 fa[2][2], fw[2][2];
@@ -558,10 +553,6 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
                 for (int i = 0; i < 2; i++)
                     acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][jn], fa[kk & 1][i], acc[jn][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (SPREAD && more) {
-                glds16(asrc[kk] + k3, &lds[sb3][0][(w * 4 + kk) * 64]);
-                glds16(wsrc[kk] + k3, &lds[sb3][1][(w * 4 + kk) * 64]);
-            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -2209,7 +2200,7 @@ static bool launch_ok(const char* what) {
 
 // Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
 // measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
-enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_DEEP_SPREAD = 5 };   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
+enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4 };   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
 static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
     static const unsigned ncu = [] {
         int dev = 0, n = 0;
@@ -2223,8 +2214,7 @@ static void launch_gemm(int variant, dim3 grid, hipStream_t s, const h16* A, int
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
     if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
         hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else if (variant == GV_DEEP_SPREAD) hipLaunchKernelGGL((k_geo_gemm_d4<EP, true>), grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else if (variant == GV_DEEP) hipLaunchKernelGGL((k_geo_gemm_d4<EP, false>), grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    else if (variant == GV_DEEP) hipLaunchKernelGGL(k_geo_gemm_d4<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else if (variant == GV_LOCKSTEP) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
 }
@@ -2253,7 +2243,7 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     if (variant == GV_LOCKSTEP && !can_big) variant = GV_128;
     // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, nobody to hide the DMA's latency -> the four-deep ring
     if (variant == GV_128 && auto_choice && 8L * (((M + GM - 1) / GM + 7) / 8) * (N / GN) <= (long)cu_count() && K / GK >= 4) variant = GV_DEEP;
-    const bool big = variant != GV_128 && variant != GV_DEEP && variant != GV_DEEP_SPREAD;
+    const bool big = variant != GV_128 && variant != GV_DEEP;
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
@@ -2937,7 +2927,7 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
                              int32_t gelu, float scale, void* stream) {
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
     if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
-    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : (gelu & 32) ? GV_DEEP_SPREAD : GV_AUTO;
+    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : GV_AUTO;
     gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
                 (hipStream_t)stream, nullptr, 0, nullptr, variant);
