@@ -515,18 +515,25 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
         }                                                                   \
     } while (0)
     for (int t = 0; t < 3 && t < nk; t++) D4_ISSUE(t);
+    P8_STAMP_DECL;   // (development builds -DP8_STAMPS: per-wave sums of a K tile's segments, foho_geo_stamps.h; empty otherwise)
     for (int t = 0; t < nk; t++) {
         // this wave's pieces of tile t have landed when at most the pieces of the newer tiles in flight remain outstanding
         if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P8_STAMP(1);
         // RAW barrier: __syncthreads() fences with s_waitcnt vmcnt(0) -- an LDS-DMA in flight is a pending LDS write -- and would drain the
         // ring at every tile (the first build of this kernel did: no faster than two stages).  This wave's own reads of stage (t - 1) & 3
         // completed with the lgkmcnt(0) of the previous tile's last k step.
         __builtin_amdgcn_s_barrier();  // tile t has landed for every wave, and everybody is done reading stage (t - 1) & 3 -- where tile t + 3 goes
+        P8_STAMP(2);
         if (t + 3 < nk) D4_ISSUE(t + 3);   // (in ONE block: two pieces behind each k step's matrix instructions measured 55.6 against 41.8 us at K = 4096)
+        P8_STAMP(3);
         asm volatile("" ::: "memory");
         const unsigned bo = (unsigned)(t & 3) << 15;  // 32 KB per stage
+#ifdef D4_FILL_ONLY   // (development build: the ring's fill alone -- no fragment reads, no matrix instructions; results are garbage)
+        continue;
+#endif
         half8 fa[2][2], fw[2][2];
         {
             const unsigned pa = aa[0] + bo, pw = aw[0] + bo;
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
                 GEO_DSR(fw[(kk + 1) & 1][0], pw, 16384);
                 GEO_DSR(fw[(kk + 1) & 1][1], pw, 16384 + 4096);
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+                if (kk == 0) P8_STAMP(4);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
             }
@@ -553,9 +561,12 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
                 for (int i = 0; i < 2; i++)
                     acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][jn], fa[kk & 1][i], acc[jn][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 1) P8_STAMP(5);
         }
+        P8_STAMP(6);
+        P8_ACC();
     }
+    P8_STAMP_DUMP(w, nk);
 #undef D4_ISSUE
     __syncthreads();  // every wave is done with the ring: it becomes the epilogue's transpose image
     h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);

@@ -4,10 +4,11 @@
 // The phased GEMM (k_geo_gemm8p).  -DP8_STAMPS: per-wave sums of the K loop's segment durations (shader clocks),
 // workgroup 0 -> foho_geo_p8_stamps() (scripts/dev_p8_stamps.py; ~40 cycles per stamp, and the stamp's wait retires LDS reads early).
 // -DP8_TIMELINE: per tile, stamps of {entry, first matrix instruction, K loop end, wave groups re-joined, exit} + HW_ID / XCC_ID ->
-// foho_geo_p8_timeline() (scripts/dev_p8_timeline.py).  Without either the hooks are empty.
+// foho_geo_p8_timeline() (scripts/dev_p8_timeline.py).  Without either the hooks are empty.  k_geo_gemm_d4 carries the P8_STAMP hooks too
+// (scripts/dev/d4_stamps.py) and a -DD4_FILL_ONLY ablation (scripts/dev/d4_fill.py: the ring's fill without the matrix work).
 #ifdef P8_STAMPS
 __device__ unsigned long long g_p8[8][8];
-extern "C" void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8), sizeof(g_p8)); }
+extern "C" __attribute__((visibility("default"))) void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8), sizeof(g_p8)); }
 #define P8_STAMP_DECL                                  \
     unsigned long long ts[7];                          \
     int seg[6] = {0, 0, 0, 0, 0, 0};                   \
@@ -35,7 +36,7 @@ extern "C" void foho_geo_p8_stamps(unsigned long long* out) { (void)hipMemcpyFro
 #endif
 #ifdef P8_TIMELINE
 __device__ unsigned long long g_p8tl[4096][8];
-extern "C" void foho_geo_p8_timeline(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8tl), sizeof(g_p8tl)); }
+extern "C" __attribute__((visibility("default"))) void foho_geo_p8_timeline(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8tl), sizeof(g_p8tl)); }
 #define P8_TL_DECL unsigned long long tl_[8]
 #define P8_TL(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_[i]))
 #define P8_TL_DUMP(L)                                                                                                             \
