@@ -578,6 +578,117 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_geo_gemm_d4 with the FILL and the MATRIX work on different waves (round 6): a CU fills its LDS at ~86 GB/s (382 ns per 32 KB K tile)
+// and a wave that issues LDS-DMA issues nothing else, so at one wave per SIMD fill time and matrix time add (0.68 us per K tile,
+// NOTEBOOK round 6).  Eight waves: waves 4-7 only fill the four-deep ring, waves 0-3 only read fragments and multiply; one raw barrier
+// per K tile hands tile t over and frees stage (t - 1) & 3.  The consumers run the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int EP>
+__global__ __launch_bounds__(512, 1) void k_geo_gemm_pc(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
+                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
+                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
+                                                        int ldc2, const int* __restrict__ Mdev) {
+    __shared__ uint4 lds[4][2][GM * GK * 2 / 16];  // [stage][A | W][128 rows x 8 chunks] = 128 KB
+    if (Mdev) M = min(M, *Mdev);
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;   // waves 4-7 only FILL the ring (each the eight pieces wave wv - 4 would), waves 0-3 only multiply
+    const int w = wv & 3;
+    const int ntn = N / GN, ntm = (M + GM - 1) / GM;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int mp = (j / ntn) * 8 + xcd, nt = j % ntn;
+    if (mp >= ntm) return;
+    const int m0 = mp * GM, n0 = nt * GN;
+    const int wr = w >> 1, wc = w & 1;
+    const int srow = lane >> 3, sslot = lane & 7;
+    const h16* asrc[4];
+    const h16* wsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int row = (w * 4 + p) * 8 + srow;
+        const int c = sslot ^ swz(row);
+        asrc[p] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        wsrc[p] = Wt + (size_t)(n0 + row) * ldw + c * 8;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+    const int ra = wr * 64 + l31, rw = wc * 64 + l31;
+    const unsigned base = lds_addr(&lds[0][0][0]);
+    unsigned aa[4], aw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        aa[kk] = base + ra * 128 + (((2 * kk + hi) ^ swz(ra)) << 4);
+        aw[kk] = base + rw * 128 + (((2 * kk + hi) ^ swz(rw)) << 4);
+    }
+    const int nk = K / GK;
+#define D4_ISSUE(t_)                                                        \
+    do {                                                                    \
+        const int sb_ = (t_) & 3, k0_ = (t_) * GK;                          \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                     \
+            glds16(asrc[p] + k0_, &lds[sb_][0][(w * 4 + p) * 64]);          \
+            glds16(wsrc[p] + k0_, &lds[sb_][1][(w * 4 + p) * 64]);          \
+        }                                                                   \
+    } while (0)
+    if (producer) {
+        for (int t = 0; t < 3 && t < nk; t++) D4_ISSUE(t);
+        for (int t = 0; t < nk; t++) {
+            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // tile t has landed (every producer waited for its pieces); the consumers are done with tile t - 1
+            if (t + 3 < nk) D4_ISSUE(t + 3);
+        }
+        __syncthreads();
+        return;
+    }
+    for (int t = 0; t < nk; t++) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned bo = (unsigned)(t & 3) << 15;  // 32 KB per stage
+        half8 fa[2][2], fw[2][2];
+        {
+            const unsigned pa = aa[0] + bo, pw = aw[0] + bo;
+            GEO_DSR(fa[0][0], pa, 0);
+            GEO_DSR(fa[0][1], pa, 4096);
+            GEO_DSR(fw[0][0], pw, 16384);
+            GEO_DSR(fw[0][1], pw, 16384 + 4096);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            if (kk < 3) {
+                const unsigned pa = aa[kk + 1] + bo, pw = aw[kk + 1] + bo;
+                GEO_DSR(fa[(kk + 1) & 1][0], pa, 0);
+                GEO_DSR(fa[(kk + 1) & 1][1], pa, 4096);
+                GEO_DSR(fw[(kk + 1) & 1][0], pw, 16384);
+                GEO_DSR(fw[(kk + 1) & 1][1], pw, 16384 + 4096);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[kk & 1][0]), "+v"(fa[kk & 1][1]), "+v"(fw[kk & 1][0]), "+v"(fw[kk & 1][1]));
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+                    acc[jn][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][jn], fa[kk & 1][i], acc[jn][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef D4_ISSUE
+    __syncthreads();  // every wave is done with the ring: it becomes the epilogue's transpose image
+    h16* img = reinterpret_cast<h16*>(&lds[0][0][0]) + w * (64 * CPAD);
+    EpiCols pc;
+    EpiRows pr;
+    epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
+    epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same GEMM on 256 x 256 x 64 tiles, 8 waves x (128 x 64): per K-tile a wave still issues 8 LDS-DMA pieces, but 64 MFMAs
 // instead of 16 -- on the 128-wide tile the DMA issue (60-180 cycles per piece beside MFMAs) cost as much as the matrix work
 // it fed -- and 6 fragment reads per 8 MFMAs instead of 4 per 4.  128 KB of LDS, one workgroup per CU (two waves per SIMD).
@@ -2211,7 +2322,7 @@ static bool launch_ok(const char* what) {
 
 // Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
 // measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
-enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4 };   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
+enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5 };   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
 static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
     static const unsigned ncu = [] {
         int dev = 0, n = 0;
@@ -2225,6 +2336,7 @@ static void launch_gemm(int variant, dim3 grid, hipStream_t s, const h16* A, int
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
     if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
         hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+    else if (variant == GV_PC) hipLaunchKernelGGL(k_geo_gemm_pc<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else if (variant == GV_DEEP) hipLaunchKernelGGL(k_geo_gemm_d4<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else if (variant == GV_LOCKSTEP) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
     else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
@@ -2252,9 +2364,10 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     if (variant == GV_AUTO) variant = (can_big && M >= 2048 && tiles256 >= 128) ? (can_phased ? GV_PHASED : GV_LOCKSTEP) : GV_128;
     if (variant == GV_PHASED && !can_phased) variant = can_big ? GV_LOCKSTEP : GV_128;
     if (variant == GV_LOCKSTEP && !can_big) variant = GV_128;
-    // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, nobody to hide the DMA's latency -> the four-deep ring
-    if (variant == GV_128 && auto_choice && 8L * (((M + GM - 1) / GM + 7) / 8) * (N / GN) <= (long)cu_count() && K / GK >= 4) variant = GV_DEEP;
-    const bool big = variant != GV_128 && variant != GV_DEEP;
+    // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, and with one wave per SIMD the ring's fill and the matrix
+    // work add up (NOTEBOOK round 6) -> the eight-wave kernel whose waves 4-7 fill while waves 0-3 multiply
+    if (variant == GV_128 && auto_choice && 8L * (((M + GM - 1) / GM + 7) / 8) * (N / GN) <= (long)cu_count() && K / GK >= 4) variant = GV_PC;
+    const bool big = variant != GV_128 && variant != GV_DEEP && variant != GV_PC;
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
@@ -2938,7 +3051,7 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
                              int32_t gelu, float scale, void* stream) {
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
     if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
-    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : GV_AUTO;
+    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : (gelu & 32) ? GV_PC : GV_AUTO;
     gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
                 (hipStream_t)stream, nullptr, 0, nullptr, variant);

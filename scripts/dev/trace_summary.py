@@ -9,7 +9,7 @@ seg = rows[idx[-2]:idx[-1]]
 
 
 def short(n):
-    m = re.search(r"k_geo_gemm(8p|256|_d4)?ILi(\d+)E", n)
+    m = re.search(r"k_geo_gemm(8p|256|_d4|_pc)?ILi(\d+)E", n)
     if m:
         return f"gemm{m.group(1) or '128'}<{m.group(2)}>"
     m = re.search(r"(k_[a-z_0-9]+)", n)

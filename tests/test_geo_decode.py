@@ -591,7 +591,7 @@ def test_active_row_backward_is_graph_capturable():
 @gpu
 def test_unit_gemm_variants_beside_a_decode_on_another_thread_leave_its_bits_alone():
     """The library keeps no mode state (re-entrant): while one thread hammers `foho_geo_gemm` with every kernel-variant bit
-    (`gelu | 2` = 128 x 128 tiles, `| 4` lock-step, `| 8` deep ring, `| 16` phased) on its own stream, decodes on another thread give the
+    (`gelu | 2` = 128 x 128 tiles, `| 4` lock-step, `| 8` deep ring, `| 16` phased, `| 32` fill + matrix waves) on its own stream, decodes on another thread give the
     bits they give alone.  (Until round 5 the variant was a process-global the unit entry point set and reset around its launch.)"""
     import threading
     from followmyhold_amd.geo_decode import HipGeoDecoder
@@ -617,7 +617,7 @@ def test_unit_gemm_variants_beside_a_decode_on_another_thread_leave_its_bits_alo
             C = torch.empty(M, N, dtype=torch.float16, device="cuda")
             with torch.cuda.stream(st):
                 while not stop.is_set():
-                    for flag in (2, 4, 8, 16, 0):
+                    for flag in (2, 4, 8, 16, 32, 0):
                         rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), None, _p(C), M, N, K, flag, ctypes.c_float(1.0), ctypes.c_void_p(st.cuda_stream))
                         assert rc == 0, lib.foho_geo_last_error()
                         count[0] += 1
