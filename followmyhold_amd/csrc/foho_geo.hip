@@ -2322,7 +2322,7 @@ static bool launch_ok(const char* what) {
 
 // Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
 // measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
-enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5 };   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
+enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5 };   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
 static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
     static const unsigned ncu = [] {
         int dev = 0, n = 0;
