@@ -157,6 +157,10 @@ def test_stack_and_batch_match_the_float32_module():
     _compare(vae, 3, 384, tol_fwd=6e-3, tol_grad=2e-2)
     vae = _standin(128, 2, 3)
     _compare(vae, 2, 128, tol_fwd=6e-3, tol_grad=2e-2)
+    # eight images x 16 heads x 2 key blocks = 256 (image, head, key block) workgroups: the batched DIRECT backward (blockIdx.y = image up to 7,
+    # dK / dV written by the workgroup itself) at a small token count; and a width / head count between the two shapes above
+    _compare(_hy3d(1024, 16, 1, latents=256, embed=16), 8, 256, seed=5)
+    _compare(_hy3d(512, 8, 2, latents=640, embed=16, qk_norm=False, qkv_bias=True), 2, 640, seed=6, tol_fwd=6e-3, tol_grad=2e-2)
 
 
 @gpu
