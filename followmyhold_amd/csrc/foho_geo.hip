@@ -140,6 +140,23 @@ constexpr int EP_STATS = 64, EP_PREAFF = 128, EP_LOGIT = 256;
 // third are LayerNorm-ed with q_norm's gain / bias / eps, of a part in the second third with k_norm's, the last third is left alone:
 // 129 floats each at bias[2 N ..] and bias[2 N + 132 ..] (hy3dgen's qk_norm).  With EP_SAVEZ the un-normalised projection goes to C2.
 constexpr int EP_QKN = 512;
+// Fused for the ShapeVAE transformer (round 6, foho_vae.inc) -- what used to be four row kernels per layer around the attention:
+// EP_PACK (with EP_PREAFF, N = 3 width: the fused q | k | v projection): besides the output, the copies the attention kernels stream --
+//   of the Q third the rows scaled by aux.qscale (aux.qs, row-major, width columns) and their transpose (aux.qst[c][pos(m)], row length
+//   aux.ldqst: all images side by side), of the K and V thirds the transposes per image (aux.kt / aux.vt [image][c][pos(l)], row length
+//   aux.lt = tokens per image); pos() as under EP_TRANS.  Any of the four may be null.  M % 64 == 0, aux.lt % 64 == 0.
+// EP_DELTA (with EP_TRANS; R = the attention's output O, ldr its row length): aux.ndelta[m * heads + n0 / 64] = - sum over the part's 64
+//   columns of (rounded output) x O -- the delta of the attention backward, from the GEMM that produces dO.
+// (Merging EP_STATS' records inside the consuming GEMM instead of k_geo_rowstat_finish was tried and dropped: at one tile per CU the merge sits
+//   in the tile's exposed prologue and cost 4.3-6.5 us per launch against the 5.4 us of the kernel it replaced -- NOTEBOOK round 6.)
+constexpr int EP_PACK = 1024, EP_DELTA = 2048;
+struct EpiAux {
+    h16 *qs = nullptr, *qst = nullptr, *kt = nullptr, *vt = nullptr;
+    int lt = 0, ldqst = 0;
+    float qscale = 1.0f;
+    float* ndelta = nullptr;
+    int heads = 0;
+};
 
 __device__ __forceinline__ float gelu_grad(float v) {   // d/dv [0.5 v (1 + erf(v / sqrt 2))] = Phi(v) + v phi(v)
     const float x = v * 0.70710678118654752f, ax = fabsf(x);
@@ -200,7 +217,7 @@ __device__ __forceinline__ void epi_rows(EpiRows& p, const h16* __restrict__ R, 
             p.rs[i] = st.x, p.mr[i] = st.y;
         }
     }
-    if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM)) {
+    if ((EP & (EP_RESID | EP_GELUBWD | EP_DELTA)) && !(EP & EP_QNORM)) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int gm = min(m0 + q * 8 + (lane >> 3), M - 1), gn = n0 + (lane & 7) * 8;   // (rows beyond M are not stored)
@@ -213,8 +230,10 @@ template <int EP>
 __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16& t01, const f32x16& t10, const f32x16& t11, h16* img,
                                                 const EpiCols& pc, const EpiRows& pr, const h16* __restrict__ R, h16* __restrict__ C, int ldc,
                                                 h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane,
-                                                const float* __restrict__ bias = nullptr, int ldr = 0) {
+                                                const float* __restrict__ bias = nullptr, int ldr = 0, const EpiAux& aux = EpiAux{}) {
     const int hi = lane >> 5, l31 = lane & 31;
+    // EP_PACK: the third of q | k | v this part lies in (uniform over the wave)
+    const int pk_third = (EP & EP_PACK) ? n0 / (ldr / 3) : 0;
     // EP_QKN: which third of the fused projection this part lies in (uniform over the wave) and that third's norm parameters
     const int qkn_third = (EP & EP_QKN) ? n0 / (ldr / 3) : 0;
     const float* qkn = (EP & EP_QKN) ? bias + 2 * ldr + 132 * qkn_third : nullptr;
@@ -299,12 +318,30 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                     for (int e = 0; e < 8; e++) C2[(size_t)(gn + e) * ldc2 + pm] = v[e];
                 }
             }
+            if ((EP & EP_PACK) && pass == 1 && pk_third < 2) {   // the final values back into the image, for the transposed read below
+                half8 vs = v;
+                if (pk_third == 0) {   // the scaled copy of Q (rounded to fp16 once more, as k_geo_transpose_perm did)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) vs[e] = (h16)((float)v[e] * aux.qscale);
+                    if (aux.qs) *reinterpret_cast<half8*>(aux.qs + (size_t)gm * (ldr / 3) + gn) = vs;
+                }
+                *reinterpret_cast<half8*>(img + ml * CPAD + ch * 8) = vs;
+            }
+            if ((EP & EP_DELTA) && pass == 1) {
+                const half8 r = pr.r[q];
+                float dot = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) dot = __builtin_fmaf((float)v[e], (float)r[e], dot);
+                dot = sum8(dot);
+                if (ch == 0 && gm < M) aux.ndelta[(size_t)gm * aux.heads + (n0 >> 6)] = -dot;
+            }
             if ((EP & (EP_RESID | EP_GELUBWD)) && !(EP & EP_QNORM) && pass == 1) {
                 const half8 r = pr.r[q];
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (EP & EP_RESID) ? (h16)((float)v[e] + (float)r[e]) : (h16)((float)v[e] * gelu_grad((float)r[e]));
             }
-            if (gm < M && !(EP & EP_LOGIT)) *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
+            // (EP_QKN's pre-activation copy: V is not normalised, nothing reads its copy -- that third of C2 stays unwritten)
+            if (gm < M && !(EP & EP_LOGIT) && !((EP & EP_QKN) && pass == 0 && qkn_third == 2)) *reinterpret_cast<half8*>(dst + (size_t)gm * ldd + gn) = v;
             if ((EP & (EP_STATS | EP_LOGIT)) && pass == 1) {   // the row's 64 (rounded) values sit in 8 consecutive lanes
                 float x[8], sm = 0.0f;
 #pragma unroll
@@ -333,6 +370,30 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                 }
             }
         }
+        if ((EP & EP_PACK) && pass == 1) {
+            // the part's transpose: lane = column, 16 rows of a block in operand order -> 32 contiguous bytes of the column's row
+            const int w3 = ldr / 3, cn = n0 - pk_third * w3 + lane, im = m0 / aux.lt;
+            h16* T = pk_third == 0 ? aux.qst : (pk_third == 1 ? aux.kt : aux.vt);
+            const size_t ldT = pk_third == 0 ? (size_t)aux.ldqst : (size_t)aux.lt;
+            const size_t at = pk_third == 0 ? (size_t)m0 : (size_t)im * w3 * aux.lt + (size_t)(m0 - im * aux.lt);
+            if (T && m0 < M) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+                    half8 lo, hi8;
+#pragma unroll
+                    for (int pos = 0; pos < 16; pos++) {
+                        const int kq = (pos & 3) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+                        const h16 x = img[(blk * 16 + kq) * CPAD + lane];
+                        if (pos < 8) lo[pos] = x;
+                        else hi8[pos - 8] = x;
+                    }
+                    h16* d = T + (size_t)cn * ldT + at + blk * 16;
+                    *reinterpret_cast<half8*>(d) = lo;
+                    *reinterpret_cast<half8*>(d + 8) = hi8;
+                }
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is reused
     }
 }
@@ -347,7 +408,7 @@ template <int EP>
 __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                      const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                      h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                     int ldc2, const int* __restrict__ Mdev) {
+                                                     int ldc2, const int* __restrict__ Mdev, EpiAux aux = EpiAux{}) {
     __shared__ uint4 lds[2][2][GM * GK * 2 / 16];  // [buffer][A | W][128 rows x 8 chunks] = 64 KB
     if (Mdev) M = min(M, *Mdev);   // device-resident row count (foho_geo_decode_bwd_rows): tiles beyond it leave at once
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -452,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_gemm(const h16* __restrict__ A, 
     EpiRows pr;
     epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
     epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
-    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -470,7 +531,7 @@ template <int EP>
 __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                         h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                        int ldc2, const int* __restrict__ Mdev) {
+                                                        int ldc2, const int* __restrict__ Mdev, EpiAux aux = EpiAux{}) {
     __shared__ uint4 lds[4][2][GM * GK * 2 / 16];  // [stage][A | W][128 rows x 8 chunks] = 128 KB
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -574,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_geo_gemm_d4(const h16* __restrict__ 
     EpiRows pr;
     epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
     epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
-    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -587,7 +648,7 @@ template <int EP>
 __global__ __launch_bounds__(512, 1) void k_geo_gemm_pc(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                         h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                        int ldc2, const int* __restrict__ Mdev) {
+                                                        int ldc2, const int* __restrict__ Mdev, EpiAux aux = EpiAux{}) {
     __shared__ uint4 lds[4][2][GM * GK * 2 / 16];  // [stage][A | W][128 rows x 8 chunks] = 128 KB
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -685,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm_pc(const h16* __restrict__ 
     EpiRows pr;
     epi_cols<EP>(pc, bias, ldr, ldc2, n0 + wc * 64, lane);
     epi_rows<EP>(pr, R, ldr, M, m0 + wr * 64, n0 + wc * 64, lane);
-    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr, R, C, ldc, C2, ldc2, M, scale, m0 + wr * 64, n0 + wc * 64, lane, bias, ldr, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +761,7 @@ template <int EP>
 __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                         const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                         h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                        int ldc2, const int* __restrict__ Mdev) {
+                                                        int ldc2, const int* __restrict__ Mdev, EpiAux aux = EpiAux{}) {
     __shared__ uint4 lds[2][2][HM * GK * 2 / 16];  // [buffer][A | W][256 rows x 8 chunks] = 128 KB
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5, l31 = lane & 31;
@@ -802,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 #pragma unroll
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane, bias, ldr);
+                            scale, m0 + wr * 128 + half * 64, n0 + wc * 64, lane, bias, ldr, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -829,7 +890,7 @@ template <int EP>
 __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
-                                                       int ldc2, const int* __restrict__ Mdev) {
+                                                       int ldc2, const int* __restrict__ Mdev, EpiAux aux = EpiAux{}) {
     // [buffer][A | W][256 rows x 8 chunks] = 128 KB, + 9.5 KB: the epilogue's image (8 waves x 64 rows x 72 halfs = 72 KB) lies over buffer 1
     // and this tail, so that buffer 0 can take the NEXT tile's first K tile while the epilogue runs
     __shared__ uint4 ldsx[2 * 2 * (HM * GK * 2 / 16) + 608];
@@ -1095,7 +1156,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 #pragma unroll
     for (int half = 0; half < 2; half++)
         gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane, bias, ldr);
+                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane, bias, ldr, aux);
     P8_TL(4);
     P8_TL_DUMP(L);
     if (!more) break;
@@ -2333,20 +2394,21 @@ static unsigned cu_count() {   // a multiple of 8: the tile order deals consecut
 }
 template <int EP>
 static void launch_gemm(int variant, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
-                        h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev) {
+                        h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev, const EpiAux& aux) {
     if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
-        hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else if (variant == GV_PC) hipLaunchKernelGGL(k_geo_gemm_pc<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else if (variant == GV_DEEP) hipLaunchKernelGGL(k_geo_gemm_d4<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else if (variant == GV_LOCKSTEP) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
-    else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev);
+        hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
+    else if (variant == GV_PC) hipLaunchKernelGGL(k_geo_gemm_pc<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
+    else if (variant == GV_DEEP) hipLaunchKernelGGL(k_geo_gemm_d4<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
+    else if (variant == GV_LOCKSTEP) hipLaunchKernelGGL(k_geo_gemm256<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
+    else hipLaunchKernelGGL(k_geo_gemm<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
 }
 
 // ep: bit mask of EP_*.  R: the residual (EP_RESID) or the saved pre-activation (EP_GELUBWD); C2: the pre-activation output
 // (EP_SAVEZ, leading dimension ldc2) or the transposed copy (EP_TRANS, row length ldc2).  Mdev: optional DEVICE row count (the
 // launch is sized for M, the kernel works on min(M, *Mdev) rows).  variant: GV_*.
 static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr, h16* C, int ldc, int M,
-                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr, int variant = GV_AUTO) {
+                int N, int K, float scale, hipStream_t s, h16* C2 = nullptr, int ldc2 = 0, const int* Mdev = nullptr, int variant = GV_AUTO,
+                EpiAux aux = EpiAux{}) {
     if (M <= 0) return FOHO_OK;
     if (N % GN || K % GK || (lda & 7) || (ldw & 7) || (ldc & 7) || (R && !(ep & (EP_QNORM | EP_PREAFF)) && (ldr & 7))) return fail(FOHO_ERR_BAD_ARG, "geo gemm: N % 128, K % 64, leading dimensions % 8");
     if ((ep & (EP_RESID | EP_GELUBWD | EP_QNORM | EP_PREAFF)) && !R) return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue operand missing");
@@ -2367,11 +2429,14 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, and with one wave per SIMD the ring's fill and the matrix
     // work add up (NOTEBOOK round 6) -> the eight-wave kernel whose waves 4-7 fill while waves 0-3 multiply
     if (variant == GV_128 && auto_choice && 8L * (((M + GM - 1) / GM + 7) / 8) * (N / GN) <= (long)cu_count() && K / GK >= 4) variant = GV_PC;
+    if ((ep & EP_PACK) && (!(ep & EP_PREAFF) || N % 3 || (N / 3) % 64 || M % 64 || aux.lt <= 0 || aux.lt % 64 || M % aux.lt || (aux.qst && aux.ldqst < M)))
+        return fail(FOHO_ERR_BAD_ARG, "geo gemm: EP_PACK operands");
+    if ((ep & EP_DELTA) && (!(ep & EP_TRANS) || !R || !aux.ndelta || aux.heads * 64 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: EP_DELTA operands");
     const bool big = variant != GV_128 && variant != GV_DEEP && variant != GV_PC;
     const int tn = big ? HN : GN, tm = big ? HM : GM;
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
-#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(variant, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev); break
+#define GEO_GEMM_CASE(E) case E: launch_gemm<E>(variant, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux); break
     switch (ep) {
         GEO_GEMM_CASE(0);
         GEO_GEMM_CASE(EP_GELU);
@@ -2385,10 +2450,12 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
         GEO_GEMM_CASE(EP_GELU | EP_PREAFF);
         GEO_GEMM_CASE(EP_RESID | EP_LOGIT);
         // the ShapeVAE transformer's (foho_vae.inc): fused q | k | v behind a folded LayerNorm (+ qk_norm, + the un-normalised copy), fc1 keeping its pre-activation
-        GEO_GEMM_CASE(EP_PREAFF);
-        GEO_GEMM_CASE(EP_PREAFF | EP_QKN);
-        GEO_GEMM_CASE(EP_PREAFF | EP_QKN | EP_SAVEZ);
+        // (+ EP_PACK: the transposed / scaled copies the attention kernels stream; EP_TRANS | EP_DELTA: dO, dO^T and the backward's delta)
+        GEO_GEMM_CASE(EP_PREAFF | EP_PACK);
+        GEO_GEMM_CASE(EP_PREAFF | EP_QKN | EP_PACK);
+        GEO_GEMM_CASE(EP_PREAFF | EP_QKN | EP_SAVEZ | EP_PACK);
         GEO_GEMM_CASE(EP_GELU | EP_PREAFF | EP_SAVEZ);
+        GEO_GEMM_CASE(EP_TRANS | EP_DELTA);
         default: return fail(FOHO_ERR_BAD_ARG, "geo gemm: epilogue");
     }
 #undef GEO_GEMM_CASE
