@@ -147,6 +147,7 @@ class HipGeoDecoder:
         self.query_cache_limit = 4 << 30  # bytes: grids whose cached query side (4 KB per point at width 1024) fits are cached
         self._qcache = None               # (weakref to the query tensor, its version, shape, cache buffer)
         self._prepared = None
+        self._ws_epoch = 0                # bumped by everything that rewrites the workspace's latent side (prepare, set_kv, a re-allocation)
         for fn in (self.lib.foho_geo_workspace_bytes, self.lib.foho_geo_bwd_workspace_bytes):
             fn.restype = ctypes.c_size_t
             fn.argtypes = [ctypes.POINTER(FohoGeoWeights), ctypes.c_int32]
@@ -172,6 +173,7 @@ class HipGeoDecoder:
         self._check(self.lib.foho_geo_prepare(ctypes.byref(self.w), L.vp(lat.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
                                               ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_prepare")
         self._lat = lat        # kept alive until the stream has consumed it
+        self._ws_epoch += 1
 
     def _size_for(self, n_latents):
         if n_latents != self.w.n_latents or self.workspace is None:
@@ -181,6 +183,7 @@ class HipGeoDecoder:
                 raise L.FohoError(f"HipGeoDecoder: {self.lib.foho_geo_last_error().decode()}")
             self.workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
             self.bwd_workspace = None
+            self._ws_epoch += 1
 
     def kv_of(self, latents):
         """c_kv(ln(latents)) with torch ops, rows [K of all heads | V of all heads], fp16: the part of the decoder autograd
@@ -205,6 +208,7 @@ class HipGeoDecoder:
         self._check(self.lib.foho_geo_set_kv(ctypes.byref(self.w), L.vp(kv.data_ptr()), ctypes.c_int32(self.chunk), L.vp(self.workspace.data_ptr()),
                                              ctypes.c_size_t(self.workspace.numel()), L.vp(stream)), "foho_geo_set_kv")
         self._prepared = None
+        self._ws_epoch += 1
 
     @property
     def ln_fuse(self):
@@ -386,6 +390,7 @@ class _GeoDecodeFn(torch.autograd.Function):
     def forward(ctx, kv, queries, dec):
         dec.set_kv(kv)
         ctx.dec = dec
+        ctx.epoch = dec._ws_epoch
         ctx.mode = dec.backward_mode
         if ctx.mode == "keep":
             out, saved = dec.decode_keep(queries)
@@ -399,7 +404,8 @@ class _GeoDecodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         kv, queries, *saved = ctx.saved_tensors
-        ctx.dec.set_kv(kv)                    # the workspace may have served another decode since
+        if ctx.dec._ws_epoch != ctx.epoch:    # the workspace has served another set of tokens since (else K / V^T / the folded weights are
+            ctx.dec.set_kv(kv)                # still this forward's: four launches less in the guidance loop's backward)
         if ctx.mode == "rows":
             return ctx.dec.decode_bwd_rows(queries, grad).to(kv.dtype), None, None
         return ctx.dec.decode_bwd(queries, grad, saved[0] if saved else None).to(kv.dtype), None, None

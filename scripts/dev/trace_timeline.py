@@ -16,8 +16,9 @@ def short(n):
     m = re.search(r"(k_[a-z_0-9]+)", n)
     if m:
         return m.group(1)
-    m = re.search(r"(Cijk_\w{0,20}|[a-zA-Z_]+::[a-zA-Z_:]+<[^,>]{0,40}|[a-z_A-Z0-9]+)", n)
-    return (m.group(1) if m else n)[:60]
+    n = re.sub(r"^void ", "", n)
+    m = re.search(r"(Cijk_\w{0,20}|[a-zA-Z_]+::[a-zA-Z_:() ]+<[^>]{0,90}|[a-z_A-Z0-9]+)", n)
+    return (m.group(1) if m else n)[:110]
 
 
 prev_end = t0

@@ -312,6 +312,40 @@ def test_latent2sdf_uses_the_hip_decoder_with_and_without_gradients():
     assert err <= 2e-2 * lat_r.grad.abs().max().item(), (err, lat_r.grad.abs().max().item())
 
 
+@gpu
+def test_backward_reinstalls_its_tokens_only_when_the_workspace_served_others_in_between():
+    """_GeoDecodeFn.backward: the workspace still holds this forward's K / V^T when nothing else was decoded since (the guidance loop:
+    four launches less per iteration); a decode of OTHER tokens in between bumps the epoch and the backward installs its own again --
+    either way the gradient is the one of the undisturbed call, bit for bit."""
+    from followmyhold_amd import geo_decode, pipeline, standins
+    from followmyhold_amd.facade import generate_dense_grid_points
+    torch.manual_seed(1)
+    vae = standins.StandInShapeVAE(num_latents=128, embed_dim=8, width=128, heads=2, layers=1, num_freqs=8).cuda().eval()
+    xyz, gsz, _ = generate_dense_grid_points(np.array([-1.1] * 3), np.array([1.1] * 3), 4, "ij")
+    xyz = torch.as_tensor(xyz, dtype=torch.float32)
+    lat, other = torch.randn(1, 128, 8, device="cuda"), torch.randn(1, 128, 8, device="cuda")
+    wgt = torch.randn(1, *[int(v) for v in gsz], device="cuda")
+    dec = geo_decode.install(vae)
+    calls = []
+    real = dec.set_kv
+    dec.set_kv = lambda kv: (calls.append(1), real(kv))[1]
+
+    def grad_of(disturb):
+        calls.clear()
+        a = lat.clone().requires_grad_(True)
+        sdf = pipeline.latent2sdf(a, xyz, gsz, vae, "cuda")
+        if disturb:
+            with torch.no_grad():
+                pipeline.latent2sdf(other, xyz, gsz, vae, "cuda")       # prepare() of other tokens: the workspace is theirs now
+        (sdf * wgt).sum().backward()
+        return a.grad.clone(), len(calls)
+
+    g0, n0 = grad_of(False)
+    g1, n1 = grad_of(True)
+    assert n0 == 1 and n1 == 2, (n0, n1)            # forward only | forward + the backward's re-install
+    assert torch.isfinite(g0).all() and g0.abs().max().item() > 0 and torch.equal(g0, g1)
+
+
 from followmyhold_amd.standins import Hy3dgenLayoutDecoder as _Hy3dLikeDecoder   # the hy3dgen attribute layout, restated
 
 
