@@ -97,6 +97,37 @@ def test_gemm_epilogues_against_torch(M, N, K, mode):
 
 
 @gpu
+@pytest.mark.parametrize("M,N,K,resid", [(3072, 1024, 1024, True), (3072, 1024, 4096, False), (1000, 256, 256, True), (95, 128, 512, False), (2304, 512, 512, True)])
+def test_gemm_kernel_variants_give_the_same_bits(M, N, K, resid):
+    """Every kernel variant of foho_geo_gemm (`gelu | 2` 128 x 128, `| 4` lock-step 256 x 256, `| 8` deep ring, `| 16` phased, `| 32` fill + matrix
+    waves -- ragged last tiles included) accumulates a K tile after the other in fp32 on the same matrix
+    instruction and shares one epilogue: the outputs are equal bit for bit, and right against torch."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).half().cuda() if resid else None
+    lib.foho_geo_gemm.restype = ctypes.c_int
+    outs = {}
+    for flag in (0, 2, 4, 8, 16, 32):
+        C = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), _p(R) if resid else None, _p(C), M, N, K, flag, ctypes.c_float(1.0),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.foho_geo_last_error()
+        torch.cuda.synchronize()
+        outs[flag] = C
+    ref = A.float() @ W.float().T + b
+    if resid:
+        ref = ref.half().float() + R.float()
+    for flag, C in outs.items():
+        assert torch.isfinite(C.float()).all(), flag
+        err = (C.float() - ref).abs().max().item()
+        assert err <= 2e-3 * max(ref.abs().max().item(), 1.0), (flag, err)
+        assert torch.equal(C, outs[2]), flag
+
+
+@gpu
 @pytest.mark.parametrize("M,Lk,heads", [(256, 64, 2), (1000, 256, 4), (700, 3072, 16)])
 def test_attention_against_torch(M, Lk, heads):
     L, lib = _lib()
