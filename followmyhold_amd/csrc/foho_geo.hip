@@ -207,11 +207,11 @@ __device__ __forceinline__ void epi_cols(EpiCols& c, const float* __restrict__ b
         c.g0 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn), c.g1 = *reinterpret_cast<const f32x4*>(bias + 64 * ldc2 + gn + 4);
     }
 }
-template <int EP>
+template <int EP, int RB = 2>   // RB: 32-row blocks of the part (2: 64 x 64; 1: 32 x 64, the last part of a 192-row tile of k_geo_gemm8p)
 __device__ __forceinline__ void epi_rows(EpiRows& p, const h16* __restrict__ R, int ldr, int M, int m0, int n0, int lane) {
     if (EP & EP_PREAFF) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < RB; i++) {
             const int gm = min(m0 + i * 32 + (lane & 31), M - 1);
             const float2 st = reinterpret_cast<const float2*>(R)[gm];
             p.rs[i] = st.x, p.mr[i] = st.y;
@@ -219,14 +219,14 @@ __device__ __forceinline__ void epi_rows(EpiRows& p, const h16* __restrict__ R, 
     }
     if ((EP & (EP_RESID | EP_GELUBWD | EP_DELTA)) && !(EP & EP_QNORM)) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 4 * RB; q++) {
             const int gm = min(m0 + q * 8 + (lane >> 3), M - 1), gn = n0 + (lane & 7) * 8;   // (rows beyond M are not stored)
             p.r[q] = *reinterpret_cast<const half8*>(R + (size_t)gm * ldr + gn);
         }
     }
 }
 
-template <int EP>
+template <int EP, int RB = 2>
 __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16& t01, const f32x16& t10, const f32x16& t11, h16* img,
                                                 const EpiCols& pc, const EpiRows& pr, const h16* __restrict__ R, h16* __restrict__ C, int ldc,
                                                 h16* __restrict__ C2, int ldc2, int M, float scale, int m0, int n0, int lane,
@@ -246,7 +246,7 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
                 const int nl = jn * 32 + 8 * g + 4 * hi;  // first of this lane's 4 consecutive columns (within the 64)
                 const f32x4 b4 = pc.b[jn * 4 + g];
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < RB; i++) {
                     const f32x16& t = jn == 0 ? (i == 0 ? t00 : t01) : (i == 0 ? t10 : t11);
                     half4 o;
                     if ((EP & EP_GELU) && pass == 1) {   // (scale is 1 on the GELU path: fc1)
@@ -290,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
         h16* dst = (pass == 0) ? C2 : C;
         const int ldd = (pass == 0) ? ldc2 : ldc;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 4 * RB; q++) {
             const int ml = q * 8 + (lane >> 3), ch = lane & 7;
             const int gm = m0 + ml, gn = n0 + ch * 8;
             half8 v = *reinterpret_cast<const half8*>(img + ml * CPAD + ch * 8);
@@ -379,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue64(const f32x16& t00, const f32x16&
             if (T && m0 < M) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int blk = 0; blk < 4; blk++) {
+                for (int blk = 0; blk < 2 * RB; blk++) {
                     half8 lo, hi8;
 #pragma unroll
                     for (int pos = 0; pos < 16; pos++) {
@@ -886,7 +886,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wav
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int EP>
+template <int EP, int TM = HM>   // TM: rows of a tile, 256 or 192 (see the note on 192-row tiles in front of the kernel)
 __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
@@ -902,7 +902,9 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     if (Mdev) M = min(M, *Mdev);
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = N / HN, ntm = (M + HM - 1) / HM;
+    constexpr int GR = TM / 2, S1T = (GR - 64) / 32;   // rows per wave group; 32-row tiles in its second half ("sub 1": rows 64 .. GR - 1)
+    static_assert(TM == 256 || TM == 192, "k_geo_gemm8p: 256- or 192-row tiles");
+    const int ntn = N / HN, ntm = (M + TM - 1) / TM;
     // PERSISTENT: a workgroup walks the tiles L = blockIdx.x, + gridDim.x, ... (the host launches one workgroup per CU when there are
     // more tiles than CUs).  Measured per tile of the fc1 shape before (shader cycles, scripts/dev_p8_timeline.py): K loop 36 900, but
     // 8 300 from entry to the first matrix instruction (the first K tile's DMA: 2 700 until this wave's pieces land + 3 900 until the
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     const int total = 8 * ((ntm + 7) / 8) * ntn;
     auto tile_of = [&](int L_, int& m0_, int& n0_) {
         const int xcd = L_ & 7, j = L_ >> 3, mp = (j / ntn) * 8 + xcd;
-        m0_ = mp * HM, n0_ = (j % ntn) * HN;
+        m0_ = mp * TM, n0_ = (j % ntn) * HN;
         return mp < ntm;
     };
     int L = blockIdx.x, m0 = 0, n0 = 0;
@@ -949,6 +951,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     // the parity of row0 / 8, which is the parity of the piece's index in its quarter: pieces 2w (even) and 2w + 1 (odd).
     const int srow = lane >> 3, sslot = lane & 7;
     const int va0 = (srow * lda + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, va1 = (srow * lda + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
+    const int va_s1 = (w & 1) ? va1 : va0;   // the swizzle of a wave's single sub-1 piece (192-row tiles) goes by the parity of its index: w
     const int vw0 = (srow * ldw + ((sslot ^ ((srow >> 1) & 7)) << 3)) * 2, vw1 = (srow * ldw + ((sslot ^ ((4 + (srow >> 1)) & 7)) << 3)) * 2;
     // tile rows of the pieces, by quarter: W columns sub 0 (phase 0), A rows sub 0 (phase 1), A rows sub 1 (phase 2), W columns sub 1 (phase 3)
     int rowq[4][2];
@@ -956,8 +959,9 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     for (int e = 0; e < 2; e++) {
         const int Lp = 2 * w + e;
         rowq[0][e] = 64 * (Lp >> 2) + 8 * (Lp & 3);
-        rowq[1][e] = 128 * (Lp >> 3) + 8 * (Lp & 7);
-        rowq[2][e] = 128 * (Lp >> 3) + 64 + 8 * (Lp & 7);
+        rowq[1][e] = GR * (Lp >> 3) + 8 * (Lp & 7);
+        // (192-row tiles: sub 1 is 32 rows per group = 8 pieces, ONE per wave -- piece w: group w / 4, rows 64 + 8 (w % 4); only e = 0 is used)
+        rowq[2][e] = S1T == 2 ? GR * (Lp >> 3) + 64 + 8 * (Lp & 7) : GR * (w >> 2) + 64 + 8 * (w & 3);
         rowq[3][e] = 64 * (Lp >> 2) + 32 + 8 * (Lp & 3);
     }
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
@@ -976,6 +980,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         if ((q) == 0 || (q) == 3) {                                                                                                \
             dma16(rw_, &lds[nb][1][rowq[q][0] * 8], vw0, sq[q][0] + (koff));                                                       \
             dma16(rw_, &lds[nb][1][rowq[q][1] * 8], vw1, sq[q][1] + (koff));                                                       \
+        } else if ((q) == 2 && S1T == 1) {                                                                                         \
+            dma16(ra_, &lds[nb][0][rowq[2][0] * 8], va_s1, sq[2][0] + (koff));                                                     \
         } else {                                                                                                                   \
             dma16(ra_, &lds[nb][0][rowq[q][0] * 8], va0, sq[q][0] + (koff));                                                       \
             dma16(ra_, &lds[nb][0][rowq[q][1] * 8], va1, sq[q][1] + (koff));                                                       \
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 
     f32x16 acc[2][4];  // [n tile][m tile]
 
-    const int ra = wr * 128 + l31, rw = wc * 64 + l31;
+    const int ra = wr * GR + l31, rw = wc * 64 + l31;
     const unsigned base = lds_addr(&lds[0][0][0]);
     unsigned aa[4], aw[4];
 #pragma unroll
@@ -1016,7 +1022,9 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     P8_DMA(1, 1, GK * 2);
     P8_DMA(2, 1, GK * 2);
     P8_TL(5);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (everything older than the six pieces: the first K tile -- and the previous tile's stores)
+    // (everything older than the six -- 192-row tiles: five -- pieces just issued: the first K tile, and the previous tile's stores)
+    if (S1T == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     P8_TL(6);
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1049,12 +1057,31 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         P8_STAMP(6);                                                                                                                \
         P8_ACC();                                                                                                                   \
     } while (0)
+    /* ... the same with ONE 32-row tile of A (sub 1 of a 192-row tile): four matrix instructions */                                  \
+#define P8_COMPUTE1(ACC0, FW, FA, WAITN)                                                                                           \
+    do {                                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
+            ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW[kk], FA[kk][0], ACC0, 0, 0, 0);                                        \
+            if (kk == 0) __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+        P8_WAIT(WAITN);                                                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+    } while (0)
 #define P8_SYNC8(F)                                                                                                                 \
     do {                                                                                                                            \
         P8_STAMP(1);                                                                                                                \
         __builtin_amdgcn_s_barrier();                                                                                               \
         P8_STAMP(2);                                                                                                                \
         asm volatile(P8_LGKM : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1])); \
+    } while (0)
+#define P8_SYNC4A(F)                                                                               \
+    do {                                                                                           \
+        __builtin_amdgcn_s_barrier();                                                              \
+        asm volatile(P8_LGKM : "+v"(F[0][0]), "+v"(F[1][0]), "+v"(F[2][0]), "+v"(F[3][0]));        \
     } while (0)
 #define P8_SYNC4(F)                                                                                \
     do {                                                                                           \
@@ -1081,19 +1108,25 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         if (I0) P8_DMA(3, nb, k1);                                                                                                  \
         P8_SYNC8(fa0);                                                                                                              \
         P8_COMPUTE(acc[0][0], acc[0][1], fw0, fa0, W0);                                                            \
-        /* phase 1: A rows sub 1 (x) W columns sub 0 */                                                                             \
+        /* phase 1: A rows sub 1 (x) W columns sub 0 (sub 1 of a 192-row tile is ONE 32-row tile: four matrix instructions) */      \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                                          \
             P8_DSR(fa1[kk][0], aa[kk] + bo, 8192);                                                                                  \
-            P8_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                                 \
+            if (S1T == 2) P8_DSR(fa1[kk][1], aa[kk] + bo, 12288);                                                                   \
         }                                                                                                                           \
         if (I1) P8_DMA(0, cb, k2);                                                                                                  \
-        P8_SYNC8(fa1);                                                                                                              \
-        P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                            \
+        if (S1T == 2) {                                                                                                             \
+            P8_SYNC8(fa1);                                                                                                          \
+            P8_COMPUTE(acc[0][2], acc[0][3], fw0, fa1, W1);                                                                         \
+        } else {                                                                                                                    \
+            P8_SYNC4A(fa1);                                                                                                         \
+            P8_COMPUTE1(acc[0][2], fw0, fa1, W1);                                                                                   \
+        }                                                                                                                           \
         /* phase 2: A rows sub 1 (x) W columns sub 1 */                                                                             \
         _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw1[kk], aw[kk] + bo, 32768 + 4096);                                \
         if (I2) P8_DMA(1, cb, k2);                                                                                                  \
         P8_SYNC4(fw1);                                                                                                              \
-        P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                            \
+        if (S1T == 2) P8_COMPUTE(acc[1][2], acc[1][3], fw1, fa1, W2);                                                               \
+        else P8_COMPUTE1(acc[1][2], fw1, fa1, W2);                                                                                  \
         /* phase 3: A rows sub 0 (x) W columns sub 1; W columns sub 0 of the NEXT tile come in for its phase 0 */                   \
         if (I0) {                                                                                                                   \
             _Pragma("unroll") for (int kk = 0; kk < 4; kk++) P8_DSR(fw0[kk], aw[kk] + bn, 32768);                                   \
@@ -1105,8 +1138,13 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 
     P8_STAMP_DECL;
     int t = 0;
-    for (; t < nk - 2; t++) P8_TILE(1, 1, 1, 1, 8, 8, 8, 8);
-    P8_TILE(1, 0, 0, 0, 8, 6, 4, 2);   // t = nk - 2: only W columns sub 1 of the last tile is still to come
+    if (S1T == 2) {
+        for (; t < nk - 2; t++) P8_TILE(1, 1, 1, 1, 8, 8, 8, 8);
+        P8_TILE(1, 0, 0, 0, 8, 6, 4, 2);   // t = nk - 2: only W columns sub 1 of the last tile is still to come
+    } else {   // 192-row tiles: the phase that issues A rows sub 1 issues ONE piece -- 7 in any four phases
+        for (; t < nk - 2; t++) P8_TILE(1, 1, 1, 1, 7, 7, 7, 7);
+        P8_TILE(1, 0, 0, 0, 7, 5, 3, 2);
+    }
     t++;
     P8_TILE(0, 0, 0, 0, 0, 0, 0, 0);   // t = nk - 1
     P8_STAMP_DUMP(w, nk);
@@ -1129,7 +1167,7 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
         for (int half = 0; half < 2; half++)
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const float2 st = ext_r[wr * 128 + half * 64 + i * 32 + l31];
+                const float2 st = ext_r[wr * GR + half * 64 + i * 32 + l31];   // (192-row tiles: half 1, i = 1 is read and not used)
                 pr[half].rs[i] = st.x, pr[half].mr[i] = st.y;
             }
     }
@@ -1141,8 +1179,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     if (more) P8_EV_WRITE();
     // ... the residual rows of BOTH parts from global memory (a later load would queue behind the next tile's DMA: vmcnt is in order) ...
     if (!(EP & EP_PREAFF)) {
-        epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * 128, n0 + wc * 64, lane);
-        epi_rows<EP>(pr[1], R, ldr, M, m0 + wr * 128 + 64, n0 + wc * 64, lane);
+        epi_rows<EP>(pr[0], R, ldr, M, m0 + wr * GR, n0 + wc * 64, lane);
+        epi_rows<EP, S1T>(pr[1], R, ldr, M, m0 + wr * GR + 64, n0 + wc * 64, lane);
     }
     const int m0c = m0, n0c = n0;
     if (more) {   // ... and the next tile's first K tile into buffer 0, on its way during the epilogue
@@ -1153,10 +1191,10 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
     }
 
     h16* img = reinterpret_cast<h16*>(&lds[1][0][0]) + w * (64 * CPAD);
-#pragma unroll
-    for (int half = 0; half < 2; half++)
-        gemm_epilogue64<EP>(acc[0][2 * half], acc[0][2 * half + 1], acc[1][2 * half], acc[1][2 * half + 1], img, pc, pr[half], R, C, ldc, C2, ldc2, M,
-                            scale, m0c + wr * 128 + half * 64, n0c + wc * 64, lane, bias, ldr, aux);
+    gemm_epilogue64<EP>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], img, pc, pr[0], R, C, ldc, C2, ldc2, M, scale, m0c + wr * GR, n0c + wc * 64, lane, bias, ldr, aux);
+    // (the wave's second part: 64 rows of a 256-row tile, 32 of a 192-row tile)
+    gemm_epilogue64<EP, S1T>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], img, pc, pr[1], R, C, ldc, C2, ldc2, M, scale, m0c + wr * GR + 64, n0c + wc * 64, lane, bias,
+                             ldr, aux);
     P8_TL(4);
     P8_TL_DUMP(L);
     if (!more) break;
@@ -1168,6 +1206,8 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A
 #undef P8_COMPUTE
 #undef P8_SYNC8
 #undef P8_SYNC4
+#undef P8_SYNC4A
+#undef P8_COMPUTE1
 #undef P8_DMA
 #undef P8_WAIT
 #undef P8_DSR
@@ -2383,7 +2423,7 @@ static bool launch_ok(const char* what) {
 
 // Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
 // measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
-enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5 };   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
+enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5, GV_PHASED192 = 6 };   // GV_PHASED192: k_geo_gemm8p on 192-row tiles   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
 static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
     static const unsigned ncu = [] {
         int dev = 0, n = 0;
@@ -2395,7 +2435,9 @@ static unsigned cu_count() {   // a multiple of 8: the tile order deals consecut
 template <int EP>
 static void launch_gemm(int variant, dim3 grid, hipStream_t s, const h16* A, int lda, const h16* Wt, int ldw, const float* bias, const h16* R, int ldr,
                         h16* C, int ldc, int M, int N, int K, float scale, h16* C2, int ldc2, const int* Mdev, const EpiAux& aux) {
-    if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
+    if (variant == GV_PHASED192)
+        hipLaunchKernelGGL((k_geo_gemm8p<EP, 192>), dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
+    else if (variant == GV_PHASED)   // persistent: one workgroup per CU walks the tiles
         hipLaunchKernelGGL(k_geo_gemm8p<EP>, dim3(std::min(grid.x, cu_count())), dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
     else if (variant == GV_PC) hipLaunchKernelGGL(k_geo_gemm_pc<EP>, grid, dim3(512), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
     else if (variant == GV_DEEP) hipLaunchKernelGGL(k_geo_gemm_d4<EP>, grid, dim3(256), 0, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux);
@@ -2424,7 +2466,12 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     const long tiles256 = (long)((M + HM - 1) / HM) * (N / HN);
     const bool auto_choice = variant == GV_AUTO;
     if (variant == GV_AUTO) variant = (can_big && M >= 2048 && tiles256 >= 128) ? (can_phased ? GV_PHASED : GV_LOCKSTEP) : GV_128;
-    if (variant == GV_PHASED && !can_phased) variant = can_big ? GV_LOCKSTEP : GV_128;
+    if ((variant == GV_PHASED || variant == GV_PHASED192) && !can_phased) variant = can_big ? GV_LOCKSTEP : GV_128;
+    // one round of 256-row tiles that leaves CUs idle (the transformer's M = 3072: 12 x 16 tiles on 256 CUs) -> 192-row tiles when those still are one
+    // round: every CU multiplies three quarters of a tile (16 x 16 tiles; 16 x 12 for q | k | v: no more CUs, less on each)
+    if (variant == GV_PHASED && auto_choice && tiles256 <= (long)cu_count() && 8L * (((M + 191) / 192 + 7) / 8) * (N / HN) <= (long)cu_count() && M > 192 &&
+        !((ep & EP_PACK) && aux.lt % 192))
+        variant = GV_PHASED192;
     if (variant == GV_LOCKSTEP && !can_big) variant = GV_128;
     // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, and with one wave per SIMD the ring's fill and the matrix
     // work add up (NOTEBOOK round 6) -> the eight-wave kernel whose waves 4-7 fill while waves 0-3 multiply
@@ -2432,8 +2479,9 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     if ((ep & EP_PACK) && (!(ep & EP_PREAFF) || N % 3 || (N / 3) % 64 || M % 64 || aux.lt <= 0 || aux.lt % 64 || M % aux.lt || (aux.qst && aux.ldqst < M)))
         return fail(FOHO_ERR_BAD_ARG, "geo gemm: EP_PACK operands");
     if ((ep & EP_DELTA) && (!(ep & EP_TRANS) || !R || !aux.ndelta || aux.heads * 64 != N)) return fail(FOHO_ERR_BAD_ARG, "geo gemm: EP_DELTA operands");
+    if (variant == GV_PHASED192 && (ep & EP_PACK) && aux.lt % 192) variant = GV_PHASED;   // (a 32-row part would straddle two images)
     const bool big = variant != GV_128 && variant != GV_DEEP && variant != GV_PC;
-    const int tn = big ? HN : GN, tm = big ? HM : GM;
+    const int tn = big ? HN : GN, tm = variant == GV_PHASED192 ? 192 : (big ? HM : GM);
     const int ntn = N / tn, ntm = (M + tm - 1) / tm;
     const dim3 grid(8 * ((ntm + 7) / 8) * ntn);
 #define GEO_GEMM_CASE(E) case E: launch_gemm<E>(variant, grid, s, A, lda, Wt, ldw, bias, R, ldr, C, ldc, M, N, K, scale, C2, ldc2, Mdev, aux); break
@@ -3118,7 +3166,7 @@ extern "C" int foho_geo_gemm(const void* A, const void* Wt, const float* bias, c
                              int32_t gelu, float scale, void* stream) {
     if (!A || !Wt || !bias || !C) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: null argument");
     if ((gelu & 1) && R) return fail(FOHO_ERR_BAD_ARG, "foho_geo_gemm: GELU and a residual are not combined on this path");
-    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : (gelu & 32) ? GV_PC : GV_AUTO;
+    const int variant = (gelu & 2) ? GV_128 : (gelu & 4) ? GV_LOCKSTEP : (gelu & 8) ? GV_DEEP : (gelu & 16) ? GV_PHASED : (gelu & 32) ? GV_PC : (gelu & 64) ? GV_PHASED192 : GV_AUTO;
     gelu &= 1;
     return gemm(gelu ? EP_GELU : (R ? EP_RESID : 0), (const h16*)A, K, (const h16*)Wt, K, bias, (const h16*)R, N, (h16*)C, N, M, N, K, scale,
                 (hipStream_t)stream, nullptr, 0, nullptr, variant);

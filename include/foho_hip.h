@@ -580,7 +580,8 @@ FOHO_API int foho_vae_bwd(const foho_vae_desc* d, const void* grad_out, void* gr
  * with epilogue = GELU when `gelu & 1`, x scale, + R (M,N) when R is not NULL (not both); N % 128 == 0, K % 64 == 0.
  * Shapes with N % 256 == 0, K >= 256 and M >= 2048 run on 256 x 256 tiles (the phased, persistent kernel) unless `gelu & 2` asks
  * for the 128 x 128 kernel, `gelu & 4` for the lock-step 256 x 256 one, `gelu & 8` for the 128 x 128 kernel with the four-deep ring, `gelu & 32`
- * for its eight-wave form with fill waves and matrix waves (what launches of at most one workgroup per CU get), `gelu & 16` for the phased one (arguments of THIS call: the library keeps no mode state).
+ * for its eight-wave form with fill waves and matrix waves (what launches of at most one workgroup per CU get), `gelu & 16` for the phased one,
+ * `gelu & 64` for the phased one on 192 x 256 tiles (what a single, under-filled round of 256-row tiles gets) (arguments of THIS call: the library keeps no mode state).
  * foho_geo_attention: O (M, 64 heads) = softmax(Q K^T) V per head with Q (M, 64 heads) pre-scaled by log2(e) / 8, KV
  * (n_latents, 128 heads) = [K | V] as the projection leaves them, Vt_scratch room for 64 heads x n_latents fp16. */
 FOHO_API int foho_geo_gemm(const void* A, const void* Wt, const float* bias, const void* R, void* C, int32_t M, int32_t N, int32_t K,

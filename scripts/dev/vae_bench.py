@@ -81,7 +81,7 @@ if a.gemms:
             b = torch.zeros(N, device=dev); C = torch.empty(M, N, device=dev).half()
             res = []
             ref_c = torch.nn.functional.linear(A.float(), W.float())
-            for name, flag in (("auto", 0), ("128", 2), ("deep128", 8), ("fill+mma128", 32), ("phased256", 16)):
+            for name, flag in (("auto", 0), ("128", 2), ("deep128", 8), ("fill+mma128", 32), ("phased256", 16), ("phased192", 64)):
                 t = timed(lambda: lib.foho_geo_gemm(P(A), P(W), P(b), None, P(C), M, N, K, flag, ctypes.c_float(1.0), st), reps=20)
                 err = ((C.float() - ref_c).abs().max() / ref_c.abs().max()).item()
                 res.append(f"{name} {t * 1e3:.1f} us ({2 * M * N * K / t / 1e9:.0f} TF{'' if err < 2e-3 else f' WRONG {err:.2e}'})")

@@ -100,7 +100,7 @@ def test_gemm_epilogues_against_torch(M, N, K, mode):
 @pytest.mark.parametrize("M,N,K,resid", [(3072, 1024, 1024, True), (3072, 1024, 4096, False), (1000, 256, 256, True), (95, 128, 512, False), (2304, 512, 512, True)])
 def test_gemm_kernel_variants_give_the_same_bits(M, N, K, resid):
     """Every kernel variant of foho_geo_gemm (`gelu | 2` 128 x 128, `| 4` lock-step 256 x 256, `| 8` deep ring, `| 16` phased, `| 32` fill + matrix
-    waves -- ragged last tiles included) accumulates a K tile after the other in fp32 on the same matrix
+    waves, `| 64` phased on 192-row tiles -- ragged last tiles included) accumulates a K tile after the other in fp32 on the same matrix
     instruction and shares one epilogue: the outputs are equal bit for bit, and right against torch."""
     L, lib = _lib()
     g = torch.Generator().manual_seed(M + N + K)
@@ -110,7 +110,7 @@ def test_gemm_kernel_variants_give_the_same_bits(M, N, K, resid):
     R = torch.randn(M, N, generator=g).half().cuda() if resid else None
     lib.foho_geo_gemm.restype = ctypes.c_int
     outs = {}
-    for flag in (0, 2, 4, 8, 16, 32):
+    for flag in (0, 2, 4, 8, 16, 32, 64):
         C = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
         rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), _p(R) if resid else None, _p(C), M, N, K, flag, ctypes.c_float(1.0),
                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -656,7 +656,7 @@ def test_active_row_backward_is_graph_capturable():
 @gpu
 def test_unit_gemm_variants_beside_a_decode_on_another_thread_leave_its_bits_alone():
     """The library keeps no mode state (re-entrant): while one thread hammers `foho_geo_gemm` with every kernel-variant bit
-    (`gelu | 2` = 128 x 128 tiles, `| 4` lock-step, `| 8` deep ring, `| 16` phased, `| 32` fill + matrix waves) on its own stream, decodes on another thread give the
+    (`gelu | 2` = 128 x 128 tiles, `| 4` lock-step, `| 8` deep ring, `| 16` phased, `| 32` fill + matrix waves, `| 64` phased on 192-row tiles) on its own stream, decodes on another thread give the
     bits they give alone.  (Until round 5 the variant was a process-global the unit entry point set and reset around its launch.)"""
     import threading
     from followmyhold_amd.geo_decode import HipGeoDecoder
@@ -682,7 +682,7 @@ def test_unit_gemm_variants_beside_a_decode_on_another_thread_leave_its_bits_alo
             C = torch.empty(M, N, dtype=torch.float16, device="cuda")
             with torch.cuda.stream(st):
                 while not stop.is_set():
-                    for flag in (2, 4, 8, 16, 32, 0):
+                    for flag in (2, 4, 8, 16, 32, 64, 0):
                         rc = lib.foho_geo_gemm(_p(A), _p(W), _p(b), None, _p(C), M, N, K, flag, ctypes.c_float(1.0), ctypes.c_void_p(st.cuda_stream))
                         assert rc == 0, lib.foho_geo_last_error()
                         count[0] += 1
