@@ -1004,11 +1004,18 @@ def pipeline_iteration_record(E, torch, scene, dev, iters=5):
                 PLN._bound_active_rows(vae, rows)
             loss.sum().backward()
         loop_body()
-        torch.cuda.synchronize(dev); a = time.perf_counter()
-        for _ in range(iters):
-            loop_body()
-        torch.cuda.synchronize(dev)
-        rec["iteration_ms"] = (time.perf_counter() - a) * 1e3 / iters
+
+        def batch():
+            torch.cuda.synchronize(dev); a = time.perf_counter()
+            for _ in range(iters):
+                loop_body()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - a) * 1e3 / iters
+        # five batches of `iters` iterations, the median batch: one batch is 90 ms of wall clock with a host round trip per iteration, and
+        # the same library on the same box gave 17.6 and 18.3 ms in two such batches minutes apart
+        batches = [batch() for _ in range(5)]
+        rec["iteration_ms"] = float(np.median(batches))
+        rec["iteration_ms_batches"] = [round(b, 3) for b in batches]
         rec["grad_finite"] = bool(torch.isfinite(noise.grad).all())     # (fp16 leaf, random networks: its magnitude means nothing)
         out[name] = rec
     # ... and four images through one iteration the way GuidedShapePipeline.call_batch runs them ("batch the rank's images

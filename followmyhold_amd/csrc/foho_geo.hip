@@ -2467,11 +2467,14 @@ static int gemm(int ep, const h16* A, int lda, const h16* Wt, int ldw, const flo
     const bool auto_choice = variant == GV_AUTO;
     if (variant == GV_AUTO) variant = (can_big && M >= 2048 && tiles256 >= 128) ? (can_phased ? GV_PHASED : GV_LOCKSTEP) : GV_128;
     if ((variant == GV_PHASED || variant == GV_PHASED192) && !can_phased) variant = can_big ? GV_LOCKSTEP : GV_128;
-    // one round of 256-row tiles that leaves CUs idle (the transformer's M = 3072: 12 x 16 tiles on 256 CUs) -> 192-row tiles when those still are one
-    // round: every CU multiplies three quarters of a tile (16 x 16 tiles; 16 x 12 for q | k | v: no more CUs, less on each)
-    if (variant == GV_PHASED && auto_choice && tiles256 <= (long)cu_count() && 8L * (((M + 191) / 192 + 7) / 8) * (N / HN) <= (long)cu_count() && M > 192 &&
-        !((ep & EP_PACK) && aux.lt % 192))
-        variant = GV_PHASED192;
+    // 256-row tiles whose last round leaves CUs idle (the transformer's M = 3072: 12 x 16 tiles on 256 CUs; four images' q | k | v: 2.25 rounds) ->
+    // 192-row tiles when the busiest CU then multiplies fewer rows: rounds x rows per tile, 192-row rounds counted 8 % dearer (their phases 1 and 2
+    // run four matrix instructions behind the same two barriers; the decoder's 49 152-row blocks are exact rounds either way and stay)
+    if (variant == GV_PHASED && auto_choice && M > 192 && !((ep & EP_PACK) && aux.lt % 192)) {
+        const long cu = (long)cu_count();
+        const long t256 = 8L * (((M + HM - 1) / HM + 7) / 8) * (N / HN), t192 = 8L * (((M + 191) / 192 + 7) / 8) * (N / HN);
+        if (((t192 + cu - 1) / cu) * 192 * 108 < ((t256 + cu - 1) / cu) * 256 * 100) variant = GV_PHASED192;
+    }
     if (variant == GV_LOCKSTEP && !can_big) variant = GV_128;
     // 128 x 128 tiles that do not even fill the chip once: one workgroup per CU, and with one wave per SIMD the ring's fill and the matrix
     // work add up (NOTEBOOK round 6) -> the eight-wave kernel whose waves 4-7 fill while waves 0-3 multiply
