@@ -169,7 +169,10 @@ def _decoder(width, heads, n_lat, hidden_ratio=4, seed=0):
 
 
 @gpu
-@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384)])
+# (8192-row blocks at width 1024: c_proj and fc2 -- EP_RESID | EP_STATS, EP_RESID | EP_LOGIT -- are one round of 256-row tiles on half the chip and
+# go to k_geo_gemm8p's 192-row tiles, whose last epilogue part is 32 rows; 3000 rows: fc1 + GELU behind the folded LayerNorm on them)
+@pytest.mark.parametrize("width,heads,n_lat,n_q,chunk", [(256, 4, 256, 5000, 2048), (1024, 16, 3072, 20000, 16384), (1024, 16, 3072, 11000, 8192),
+                                                         (1024, 16, 3072, 3000, 16384)])
 def test_decoder_chain_against_the_torch_module(width, heads, n_lat, n_q, chunk):
     """Fourier embedding -> query projection -> cross attention -> MLP -> LayerNorm -> logit, all queries in one call (row
     blocks of `chunk`, the last one ragged), against the float32 torch module on the same fp16-rounded inputs."""
