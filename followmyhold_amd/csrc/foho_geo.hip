@@ -880,13 +880,21 @@ __global__ __launch_bounds__(512, 1) void k_geo_gemm256(const h16* __restrict__ 
 // Staging by buffer_load_dwordx4 ... lds: resource + scalar offset per piece (the addresses of all pieces of a wave differ by
 // scalars), rows beyond M read zeros (the resource's bound) instead of a clamped row.  The schedule is the "8-phase" form of
 // cdna_hip_programming.md section 5 (T3 + T4 + T5) laid over this kernel's 32 x 32 x 16 fragments.
+//
+// 192-row tiles (template parameter TM = 192, late round 6).  A launch that is ONE round of 256-row tiles with CUs left over -- the ShapeVAE
+// transformer's M = 3072 x N = 4096: 12 x 16 tiles on 256 CUs -- is bound by what one CU multiplies; 16 x 16 tiles of 192 rows give every CU
+// three quarters of that (34.4 -> 28.0 us; gemm() chooses).  Same LDS layout (the A region keeps its 256 rows, 64 unused), same phases; a
+// wave's part is 96 x 64: "A rows sub 0" stays two 32-row tiles, "sub 1" is ONE -- phases 1 and 2 run four matrix instructions
+// (P8_COMPUTE1), the DMA quarter "A rows sub 1" is one piece per wave (piece w: group w / 4, rows 64 + 8 (w % 4); swizzle by the parity of
+// w), so any four consecutive phases issue 7 pieces instead of 8 and the counted waits are vmcnt(7) (7 / 5 / 3 / 2 in the tile before last,
+// vmcnt(5) behind the prologue); the wave's second epilogue part is 32 x 64 (gemm_epilogue64<EP, 1>).
 // ------------------------------------------------------------------------------------------------
 // (development builds -DP8_STAMPS / -DP8_TIMELINE: the P8_STAMP / P8_TL hooks below are defined in foho_geo_stamps.h; empty otherwise)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int EP, int TM = HM>   // TM: rows of a tile, 256 or 192 (see the note on 192-row tiles in front of the kernel)
+template <int EP, int TM = HM>   // TM: rows of a tile, 256 or 192 (the note on 192-row tiles above)
 __global__ __launch_bounds__(512, 1) void k_geo_gemm8p(const h16* __restrict__ A, int lda, const h16* __restrict__ Wt, int ldw,
                                                        const float* __restrict__ bias, const h16* __restrict__ R, int ldr,
                                                        h16* __restrict__ C, int ldc, int M, int N, int K, float scale, h16* __restrict__ C2,
@@ -2423,7 +2431,15 @@ static bool launch_ok(const char* what) {
 
 // Which kernel a GEMM runs on.  GV_AUTO: by shape (gemm() below); the others are for the unit entry point foho_geo_gemm (tests, A/B
 // measurements) -- an ARGUMENT of the call, no process state: the library is driven from several threads (MeshGuidanceRunner, call_batch).
-enum { GV_AUTO = 0, GV_128 = 1, GV_LOCKSTEP = 2, GV_PHASED = 3, GV_DEEP = 4, GV_PC = 5, GV_PHASED192 = 6 };   // GV_PHASED192: k_geo_gemm8p on 192-row tiles   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_PC: k_geo_gemm_pc (fill waves + matrix waves)   // GV_DEEP: 128 x 128 tiles, four-deep ring (k_geo_gemm_d4)
+enum {
+    GV_AUTO = 0,
+    GV_128 = 1,         // k_geo_gemm: 128 x 128 tiles, two stages
+    GV_LOCKSTEP = 2,    // k_geo_gemm256
+    GV_PHASED = 3,      // k_geo_gemm8p, 256 x 256 tiles
+    GV_DEEP = 4,        // k_geo_gemm_d4: 128 x 128 tiles, four-deep ring
+    GV_PC = 5,          // k_geo_gemm_pc: the same with fill waves and matrix waves
+    GV_PHASED192 = 6    // k_geo_gemm8p on 192 x 256 tiles
+};
 static unsigned cu_count() {   // a multiple of 8: the tile order deals consecutive tiles to the 8 XCDs
     static const unsigned ncu = [] {
         int dev = 0, n = 0;
